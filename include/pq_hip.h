@@ -1,0 +1,217 @@
+/*
+ * pq_hip.h -- C ABI of libpolars_quant_hip.so: the MI355X (gfx950) execution path for the
+ * polars-quant technical-indicator + per-symbol backtest hot path.
+ *
+ * This header is the drop-in boundary.  Each entry point replaces one `#[polars_expr]` plugin
+ * function / PyO3 method of the reference (file:line cited per function, paths relative to the
+ * reference repo) with a BATCHED call over n_series independent series (symbols): one call here
+ * replaces the N per-group plugin calls Polars makes under `.over("symbol")`.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers (hipMalloc'd or torch CUDA tensors); plain C types only
+ *   - a column is symbol-major: element (s, t) lives at ptr[s * stride + t], 0 <= t < len
+ *   - f64 NULL rows are the NaN bit pattern PQ_NULL_BITS (in and out); int32 outputs that can be
+ *     null (ht_trendmode) use PQ_NULL_I32.  pq_nulls_from_arrow / pq_validity_to_arrow convert
+ *     from / to Arrow validity bitmaps.
+ *   - every call is asynchronous on the context's HIP stream; pq_ctx_sync waits for it
+ *   - return value: PQ_OK or an error code; pq_last_error() gives a thread-local message
+ *   - parameters whose reference handling would panic (timeperiod == 0 underflow, momentum.rs:52)
+ *     yield all-null output instead of aborting
+ */
+#ifndef PQ_HIP_H
+#define PQ_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQ_NULL_BITS 0x7FF80000504E554CULL
+#define PQ_NULL_I32 ((int32_t)0x80000000)
+
+typedef int32_t pq_status;
+enum {
+    PQ_OK = 0,
+    PQ_ERR_ARG = 1,     /* bad argument (null pointer, negative size, stride < len) */
+    PQ_ERR_HIP = 2,     /* a HIP runtime call failed */
+    PQ_ERR_NULLS = 3,   /* input has nulls and the reference function rejects them (N-B family) */
+    PQ_ERR_NOMEM = 4,
+    PQ_ERR_UNSUPPORTED = 5
+};
+
+typedef struct pq_ctx pq_ctx; /* device + stream + scratch workspace; one per host thread/stream */
+
+/* n_series series of `len` rows; consecutive series start `stride` elements apart (stride >= len) */
+typedef struct {
+    int64_t n_series;
+    int64_t len;
+    int64_t stride;
+} pq_batch;
+
+/* ---- runtime ---- */
+int32_t pq_abi_version(void);
+const char *pq_last_error(void);
+pq_status pq_device_count(int32_t *count);
+/* hip_stream: the hipStream_t every call launches on (e.g. torch's current stream); NULL = the default stream */
+pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out);
+pq_status pq_ctx_destroy(pq_ctx *ctx);
+pq_status pq_ctx_set_stream(pq_ctx *ctx, void *hip_stream);
+pq_status pq_ctx_sync(pq_ctx *ctx);
+pq_status pq_malloc(pq_ctx *ctx, size_t bytes, void **dptr);
+pq_status pq_free(pq_ctx *ctx, void *dptr);
+pq_status pq_memcpy_h2d(pq_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+pq_status pq_memcpy_d2h(pq_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Arrow validity bitmap (LSB-first, bit i = row i of the long column, starting at bit `bit_offset`)
+ * -> overwrite null rows of `col` (n contiguous rows) with PQ_NULL_BITS */
+pq_status pq_nulls_from_arrow(pq_ctx *ctx, double *col, const uint8_t *validity_bits, int64_t bit_offset, int64_t n);
+/* PQ_NULL_BITS rows of `col` -> Arrow validity bitmap (ceil(n/8) bytes) + null count (device int64) */
+pq_status pq_validity_to_arrow(pq_ctx *ctx, const double *col, int64_t n, uint8_t *validity_bits, int64_t *null_count);
+pq_status pq_count_nulls(pq_ctx *ctx, const pq_batch *b, const double *col, int64_t *host_count);
+
+/* ---- overlap studies (src/talib/overlap.rs) ---- */
+pq_status pq_sma(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :494 */
+pq_status pq_ema(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :128 */
+pq_status pq_bbands(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double nbdevup,
+                    double nbdevdn, double *bb_upper, double *bb_middle, double *bb_lower);                     /* :47 */
+pq_status pq_dema(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);             /* :119 */
+pq_status pq_tema(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);             /* :513 */
+pq_status pq_t3(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double vfactor, double *out); /* :503 */
+pq_status pq_trima(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);            /* :522 */
+pq_status pq_wma(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :531 */
+pq_status pq_kama(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);             /* :137 */
+pq_status pq_ma(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, int64_t matype, double *out); /* :146 */
+pq_status pq_midpoint(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);         /* :180 */
+pq_status pq_midprice(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
+                      double *out);                                                                             /* :281 */
+pq_status pq_mama(pq_ctx *, const pq_batch *, const double *real, double fastlimit, double slowlimit,
+                  double *mama, double *fama);                                                                  /* :156 */
+pq_status pq_mavp(pq_ctx *, const pq_batch *, const double *real, const double *periods, int64_t minperiod,
+                  int64_t maxperiod, int64_t matype, double *out);                                              /* :407 */
+pq_status pq_sar(pq_ctx *, const pq_batch *, const double *high, const double *low, double acceleration,
+                 double maximum, double *out);                                                                  /* :437 */
+pq_status pq_sarext(pq_ctx *, const pq_batch *, const double *high, const double *low, double startvalue,
+                    double offsetonreverse, double accelerationinitlong, double accelerationlong,
+                    double accelerationmaxlong, double accelerationinitshort, double accelerationshort,
+                    double accelerationmaxshort, double *out);                                                  /* :457 */
+
+/* ---- momentum (src/talib/momentum.rs; composites python/polars_quant/talib/momentum.py) ---- */
+pq_status pq_adx(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                 int64_t timeperiod, double *out);                                                              /* :11 */
+pq_status pq_adxr(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                  int64_t timeperiod, double *out);                                                             /* :32 */
+pq_status pq_dx(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                int64_t timeperiod, double *out);                                                               /* :226 */
+pq_status pq_plus_di(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                     int64_t timeperiod, double *out);                                                          /* :400 */
+pq_status pq_minus_di(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                      int64_t timeperiod, double *out);                                                         /* :345 */
+pq_status pq_plus_dm(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
+                     double *out);                                                                              /* :414 */
+pq_status pq_minus_dm(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
+                      double *out);                                                                             /* :359 */
+pq_status pq_aroon(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
+                   double *aroon_up, double *aroon_down);                                                       /* :70 */
+pq_status pq_aroonosc(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
+                      double *out);                                                             /* momentum.py:40 */
+pq_status pq_bop(pq_ctx *, const pq_batch *, const double *open, const double *high, const double *low,
+                 const double *close, double *out);                                                             /* :113 */
+pq_status pq_cci(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                 int64_t timeperiod, double *out);                                                              /* :138 */
+pq_status pq_cmo(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :181 */
+pq_status pq_macd(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod,
+                  int64_t signalperiod, double *macd, double *macd_signal, double *macd_hist);                  /* :250 */
+pq_status pq_macdext(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t fastmatype,
+                     int64_t slowperiod, int64_t slowmatype, int64_t signalperiod, int64_t signalmatype,
+                     double *macd_dif, double *macd_dea, double *macd_hist);                    /* momentum.py:83 */
+pq_status pq_macdfix(pq_ctx *, const pq_batch *, const double *real, int64_t signalperiod, double *macd,
+                     double *macd_signal, double *macd_hist);                                   /* momentum.py:90 */
+pq_status pq_mfi(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                 const double *volume, int64_t timeperiod, double *out);                                        /* :286 */
+pq_status pq_mom(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :384 */
+pq_status pq_roc(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :439 */
+pq_status pq_rocp(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);             /* :456 */
+pq_status pq_rocr(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);             /* :473 */
+pq_status pq_rocr100(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);          /* :490 */
+pq_status pq_rsi(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);              /* :507 */
+pq_status pq_trix(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *out);             /* :544 */
+pq_status pq_ultosc(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                    int64_t timeperiod1, int64_t timeperiod2, int64_t timeperiod3, double *out);                /* :572 */
+pq_status pq_willr(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                   int64_t timeperiod, double *out);                                                            /* :630 */
+pq_status pq_apo(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod,
+                 int64_t matype, double *out);                                                  /* momentum.py:25 */
+pq_status pq_ppo(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod,
+                 int64_t matype, double *out);                                                 /* momentum.py:136 */
+pq_status pq_stoch(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                   int64_t fastk_period, int64_t slowk_period, int64_t slowk_matype, int64_t slowd_period,
+                   int64_t slowd_matype, double *slowk, double *slowd);                        /* momentum.py:178 */
+pq_status pq_stochf(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                    int64_t fastk_period, int64_t fastd_period, int64_t fastd_matype, double *fastk,
+                    double *fastd);                                                            /* momentum.py:188 */
+pq_status pq_stochrsi(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, int64_t fastk_period,
+                      int64_t fastd_period, int64_t fastd_matype, double *fastk, double *fastd); /* momentum.py:197 */
+
+/* ---- volatility / volume / price (src/talib/{volatility,volume,price}.rs) ---- */
+pq_status pq_trange(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                    double *out);                                                              /* volatility.rs:51 */
+pq_status pq_atr(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                 int64_t timeperiod, double *out);                                             /* volatility.rs:18 */
+pq_status pq_natr(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                  int64_t timeperiod, double *out);                                            /* volatility.rs:34 */
+pq_status pq_ad(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                const double *volume, double *out);                                                /* volume.rs:19 */
+pq_status pq_adosc(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                   const double *volume, int64_t fastperiod, int64_t slowperiod, double *out);     /* volume.rs:34 */
+pq_status pq_obv(pq_ctx *, const pq_batch *, const double *close, const double *volume, double *out); /* volume.rs:70 */
+pq_status pq_avgprice(pq_ctx *, const pq_batch *, const double *open, const double *high, const double *low,
+                      const double *close, double *out);                                            /* price.rs:10 */
+pq_status pq_medprice(pq_ctx *, const pq_batch *, const double *high, const double *low, double *out); /* price.rs:34 */
+pq_status pq_typprice(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                      double *out);                                                                 /* price.rs:53 */
+pq_status pq_wclprice(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                      double *out);                                                                 /* price.rs:74 */
+
+/* ---- cycle (src/talib/cycle.rs) ---- */
+pq_status pq_ht_dcperiod(pq_ctx *, const pq_batch *, const double *real, double *out);                          /* :10 */
+pq_status pq_ht_dcphase(pq_ctx *, const pq_batch *, const double *real, double *out);                           /* :75 */
+pq_status pq_ht_phasor(pq_ctx *, const pq_batch *, const double *real, double *inphase, double *quadrature);    /* :159 */
+pq_status pq_ht_sine(pq_ctx *, const pq_batch *, const double *real, double *sine, double *leadsine);           /* :236 */
+pq_status pq_ht_trendline(pq_ctx *, const pq_batch *, const double *real, double *out);                         /* :310 */
+pq_status pq_ht_trendmode(pq_ctx *, const pq_batch *, const double *real, int32_t *out);                        /* :377 */
+
+/* ---- candlestick patterns (src/talib/pattern.rs:10-2062) ---- */
+#define PQ_N_PATTERNS 61
+/* names in id order, lower-case plugin names ("cdl2crows", ...) */
+const char *pq_pattern_name(int32_t id);
+int32_t pq_pattern_id(const char *name);
+/* one recogniser; penetration is used by ids 14,19,20,42,43,45 (pattern.rs:529,675,713,1426,1464,1529) */
+pq_status pq_cdl(pq_ctx *, const pq_batch *, int32_t pattern_id, const double *open, const double *high,
+                 const double *low, const double *close, double penetration, int32_t *out);
+/* all 61 in one pass over OHLC: outs[id] may be NULL to skip a pattern; penetrations[id] per pattern */
+pq_status pq_cdl_all(pq_ctx *, const pq_batch *, const double *open, const double *high, const double *low,
+                     const double *close, const double *penetrations /* host, 61 */, int32_t *const *outs /* host, 61 device ptrs */);
+
+/* ---- backtest (src/backtest/vectorized.rs:69-224, src/backtest/metrics.rs:7-152) ---- */
+typedef struct {
+    double initial_capital, buy_slippage, sell_slippage, buy_commission_rate, sell_commission_rate,
+        min_commission, position_size;
+} pq_bt_params; /* vectorized.rs:38 defaults: 1e5, 0, 0, 3e-4, 3e-4, 5, 1 */
+#define PQ_SUMMARY_COLS 8 /* annualized_return, max_drawdown, alpha, beta, sharpe_ratio, max_profit, win_rate, total_trades */
+/* buy/sell: uint8 0/1 per row (null -> 0, vectorized.rs:80-98); price null -> NaN (:70-78);
+ * benchmark may be NULL; position/cash/equity may be NULL (summary only); summary is [n_series][8] */
+pq_status pq_backtest_vectorized(pq_ctx *, const pq_batch *, const double *price, const uint8_t *buy,
+                                 const uint8_t *sell, const double *benchmark, const pq_bt_params *params,
+                                 double *position, double *cash, double *equity, double *summary);
+/* fused strategy + backtest: MACD(fast,slow,signal) cross signals generated on the fly
+ * (buy: macd crosses above signal; sell: crosses below), then the same scan + summary */
+pq_status pq_backtest_macd_cross(pq_ctx *, const pq_batch *, const double *close, int64_t fastperiod,
+                                 int64_t slowperiod, int64_t signalperiod, const pq_bt_params *params,
+                                 double *position, double *cash, double *equity, double *summary);
+pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close, int64_t fastperiod,
+                                int64_t slowperiod, int64_t signalperiod, uint8_t *buy, uint8_t *sell);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -203,7 +203,8 @@ void pqo_wma(const double *v, int64_t n, int64_t p, double *out) {
  * on nulls; the oracle keeps pass-1's null-skipping and defines pass 2 over the same rows
  * (values[i] at the sc row index), which is the reference behaviour for null-free input. */
 void pqo_kama(const double *v, int64_t n, int64_t p, double *out) {
-    if (p <= 0 || n < p) { pqo_fill_null(out, n); return; }
+    /* p == 1: window_sum.pop_front().unwrap() (:775) hits an empty deque -> the reference aborts; all-null here */
+    if (p <= 1 || n < p) { pqo_fill_null(out, n); return; }
     double *er = (double *)malloc(sizeof(double) * (size_t)n);
     int64_t count = 0;
     double diff_abs = 0.0, sum = 0.0;

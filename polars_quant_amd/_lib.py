@@ -1,0 +1,92 @@
+"""ctypes binding of libpolars_quant_hip.so (the C ABI declared in include/pq_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, importing the compute API raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C polars_quant_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from ._spec import I, SPEC
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libpolars_quant_hip.so"
+
+PQ_OK = 0
+NULL_BITS = 0x7FF80000504E554C
+NULL_I32 = -2147483648
+
+
+class PqError(RuntimeError):
+    """Raised when a C-ABI call returns a non-zero status (message from pq_last_error)."""
+
+
+class NullsNotAllowed(PqError):
+    """The reference function rejects nulls (N-B family: rechunk().cont_slice()? fails, momentum.rs:12-13)."""
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_series", C.c_int64), ("len", C.c_int64), ("stride", C.c_int64)]
+
+
+class BtParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("initial_capital", "buy_slippage", "sell_slippage", "buy_commission_rate",
+                                          "sell_commission_rate", "min_commission", "position_size")]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: the MI355X HIP library is not built. "
+                "Run `make -C polars_quant_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(str(LIB_PATH))
+        L.pq_last_error.restype = C.c_char_p
+        L.pq_pattern_name.restype = C.c_char_p
+        L.pq_pattern_name.argtypes = [C.c_int32]
+        L.pq_pattern_id.argtypes = [C.c_char_p]
+        vp = C.c_void_p
+        for name, (cols, params, outs, _fam) in SPEC.items():
+            fn = getattr(L, "pq_" + name)
+            fn.restype = C.c_int32
+            fn.argtypes = [vp, C.POINTER(Batch)] + [vp] * len(cols) + \
+                          [C.c_int64 if k == I else C.c_double for _, k, _ in params] + [vp] * len(outs)
+        L.pq_cdl.restype = C.c_int32
+        L.pq_cdl.argtypes = [vp, C.POINTER(Batch), C.c_int32, vp, vp, vp, vp, C.c_double, vp]
+        L.pq_cdl_all.restype = C.c_int32
+        L.pq_cdl_all.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp, C.POINTER(C.c_double), C.POINTER(vp)]
+        L.pq_backtest_vectorized.restype = C.c_int32
+        L.pq_backtest_vectorized.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp, C.POINTER(BtParams), vp, vp, vp, vp]
+        L.pq_backtest_macd_cross.restype = C.c_int32
+        L.pq_backtest_macd_cross.argtypes = [vp, C.POINTER(Batch), vp, C.c_int64, C.c_int64, C.c_int64,
+                                             C.POINTER(BtParams), vp, vp, vp, vp]
+        L.pq_macd_cross_signals.restype = C.c_int32
+        L.pq_macd_cross_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_int64, C.c_int64, C.c_int64, vp, vp]
+        L.pq_ctx_create.argtypes = [C.c_int32, vp, C.POINTER(vp)]
+        L.pq_ctx_destroy.argtypes = [vp]
+        L.pq_ctx_set_stream.argtypes = [vp, vp]
+        L.pq_ctx_sync.argtypes = [vp]
+        L.pq_count_nulls.argtypes = [vp, C.POINTER(Batch), vp, C.POINTER(C.c_int64)]
+        L.pq_nulls_from_arrow.argtypes = [vp, vp, vp, C.c_int64, C.c_int64]
+        L.pq_validity_to_arrow.argtypes = [vp, vp, C.c_int64, vp, vp]
+        L.pq_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.pq_free.argtypes = [vp, vp]
+        L.pq_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.pq_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.pq_device_count.argtypes = [C.POINTER(C.c_int32)]
+        for n in ("pq_suite_run", "pq_suite_n_f64", "pq_suite_n_i32"):
+            if hasattr(L, n):
+                getattr(L, n).restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != PQ_OK:
+        msg = lib().pq_last_error().decode("utf-8", "replace")
+        raise (NullsNotAllowed if status == 3 else PqError)(f"pq status {status}: {msg}")

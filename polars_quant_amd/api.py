@@ -1,0 +1,263 @@
+"""Host side of the drop-in: batches of series in, batches out, computed by the HIP library.
+
+Inputs may be torch CUDA tensors (zero-copy), numpy arrays / pyarrow arrays / polars Series (copied to the
+device through torch); shapes [T] (one series) or [N, T] (N symbols, symbol-major = long format sorted by
+symbol, date).  Outputs come back in the container kind of the first input.  Nulls travel as the NaN bit
+pattern NULL_BITS on the device and are converted from/to Arrow validity at the edge.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Batch, BtParams, NullsNotAllowed, PqError, check, lib
+from ._spec import BT_DEFAULTS, I, NB, PATTERN_NAMES, PATTERN_PEN_DEFAULT, SPEC, SUMMARY_KEYS
+
+NULL = np.array([_lib.NULL_BITS], dtype=np.uint64).view(np.float64)[0]
+
+_ctx_cache = {}
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise PqError("polars_quant_amd needs an MI355X (HIP device); there is no CPU fallback")
+
+
+def ctx(device: int | None = None):
+    """pq_ctx bound to torch's current stream on `device` (cached per device+stream)."""
+    _require_gpu()
+    dev = torch.cuda.current_device() if device is None else device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, stream)
+    h = _ctx_cache.get(key)
+    if h is None:
+        out = C.c_void_p()
+        check(lib().pq_ctx_create(dev, C.c_void_p(stream) if stream else None, C.byref(out)))
+        h = out
+        _ctx_cache[key] = h
+    return h
+
+
+class _Kind:
+    TORCH, NUMPY, ARROW, POLARS = range(4)
+
+
+def _to_device(x, dtype=torch.float64):
+    """-> (tensor [N,T] on cuda, kind, squeeze)"""
+    kind = _Kind.TORCH
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        mod = type(x).__module__.split(".")[0]
+        if mod == "polars":
+            kind = _Kind.POLARS
+            x = x.to_arrow()
+            mod = "pyarrow"
+        if mod == "pyarrow":
+            if kind != _Kind.POLARS:
+                kind = _Kind.ARROW
+            import pyarrow as pa
+            if isinstance(x, pa.ChunkedArray):
+                x = x.combine_chunks()
+            arr = x.cast(pa.float64()) if dtype == torch.float64 else x
+            vals = arr.to_numpy(zero_copy_only=False).astype(np.float64 if dtype == torch.float64 else np.uint8, copy=True)
+            if arr.null_count:
+                mask = np.asarray(arr.is_null())
+                if dtype == torch.float64:
+                    vals[mask] = NULL
+                else:
+                    vals[mask] = 0
+            t = torch.from_numpy(vals)
+        else:
+            kind = _Kind.NUMPY
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.dtype != dtype:
+        t = t.to(torch.uint8 if dtype == torch.uint8 else dtype)
+    squeeze = t.dim() == 1
+    if squeeze:
+        t = t.unsqueeze(0)
+    if t.dim() != 2:
+        raise PqError("inputs must be [T] or [N, T]")
+    if not t.is_cuda:
+        _require_gpu()
+        t = t.cuda()
+    if t.stride(1) != 1 and t.shape[1] > 1:
+        t = t.contiguous()
+    return t, kind, squeeze
+
+
+def _from_device(t: torch.Tensor, kind: int, squeeze: bool, name: str = ""):
+    if squeeze:
+        t = t[0]
+    if kind == _Kind.TORCH:
+        return t
+    a = t.cpu().numpy()
+    if kind == _Kind.NUMPY:
+        return a
+    import pyarrow as pa
+    if a.dtype == np.float64:
+        mask = a.view(np.uint64) == np.uint64(_lib.NULL_BITS)
+    else:
+        mask = a == np.int32(_lib.NULL_I32)
+    arr = pa.array(a.ravel(), mask=mask.ravel())
+    if kind == _Kind.POLARS:
+        import polars as pl
+        return pl.Series(name, arr)
+    return arr
+
+
+def _batch_of(t: torch.Tensor) -> Batch:
+    n, T = t.shape
+    return Batch(n, T, t.stride(0) if n > 1 else max(T, t.stride(0) if t.stride(0) >= T else T))
+
+
+def _same_layout(ts):
+    n, T = ts[0].shape
+    s0 = ts[0].stride(0)
+    out = []
+    for t in ts:
+        if t.shape != (n, T):
+            raise PqError(f"input shapes differ: {tuple(t.shape)} vs {(n, T)}")
+        if t.stride(0) != s0 or t.stride(1) != 1:
+            t = t.contiguous()
+            if s0 != T:
+                ts0 = ts[0].contiguous()
+                return _same_layout([ts0] + [x.contiguous() for x in ts[1:]])
+        out.append(t)
+    return out
+
+
+def count_nulls(t: torch.Tensor) -> int:
+    t2, _, _ = _to_device(t)
+    b = _batch_of(t2)
+    n = C.c_int64(0)
+    check(lib().pq_count_nulls(ctx(t2.device.index), C.byref(b), C.c_void_p(t2.data_ptr()), C.byref(n)))
+    return n.value
+
+
+def call(name: str, *inputs, check_nulls: bool = False, **params):
+    """Run indicator `name` (lower-case plugin name, e.g. "ema") -> tuple of outputs."""
+    if name in PATTERN_NAMES:
+        return (cdl(name, *inputs, **params),)
+    cols, pspec, outs, fam = SPEC[name]
+    if len(inputs) != len(cols):
+        raise TypeError(f"{name}() takes inputs {cols}")
+    conv = [_to_device(x) for x in inputs]
+    kind, squeeze = conv[0][1], conv[0][2]
+    ts = _same_layout([c[0] for c in conv])
+    if fam == NB and (check_nulls or kind in (_Kind.ARROW, _Kind.POLARS)):
+        for t in ts:
+            if count_nulls(t):
+                raise NullsNotAllowed(f"{name}: input contains nulls (the reference's cont_slice() rejects them)")
+    dev = ts[0].device
+    n, T = ts[0].shape
+    b = Batch(n, T, ts[0].stride(0) if n > 1 else T)
+    pvals = []
+    for pname, k, default in pspec:
+        v = params.pop(pname, default)
+        pvals.append(C.c_int64(int(v)) if k == I else C.c_double(float(v)))
+    if params:
+        raise TypeError(f"{name}() got unexpected parameters {sorted(params)}")
+    res = [torch.empty_strided((n, T), (b.stride, 1), dtype=torch.float64 if dt == "f8" else torch.int32, device=dev)
+           for _, dt in outs]
+    with torch.cuda.device(dev):
+        fn = getattr(lib(), "pq_" + name)
+        check(fn(ctx(dev.index), C.byref(b), *[C.c_void_p(t.data_ptr()) for t in ts], *pvals,
+                 *[C.c_void_p(r.data_ptr()) for r in res]))
+    return tuple(_from_device(r, kind, squeeze, oname) for r, (oname, _) in zip(res, outs))
+
+
+def cdl(name: str, open, high, low, close, penetration: float | None = None):
+    pid = PATTERN_NAMES.index(name)
+    pen = PATTERN_PEN_DEFAULT[name] if penetration is None else float(penetration)
+    conv = [_to_device(x) for x in (open, high, low, close)]
+    kind, squeeze = conv[0][1], conv[0][2]
+    ts = _same_layout([c[0] for c in conv])
+    if kind in (_Kind.ARROW, _Kind.POLARS):
+        for t in ts:
+            if count_nulls(t):
+                raise NullsNotAllowed(f"{name}: input contains nulls")
+    dev = ts[0].device
+    n, T = ts[0].shape
+    b = Batch(n, T, ts[0].stride(0) if n > 1 else T)
+    out = torch.empty_strided((n, T), (b.stride, 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().pq_cdl(ctx(dev.index), C.byref(b), pid, *[C.c_void_p(t.data_ptr()) for t in ts], C.c_double(pen),
+                           C.c_void_p(out.data_ptr())))
+    return _from_device(out, kind, squeeze, name)
+
+
+def cdl_all(open, high, low, close, penetrations: dict | None = None, names=None):
+    """All (or `names`) candlestick recognisers in one pass over OHLC -> dict name -> int32 [N,T]."""
+    conv = [_to_device(x) for x in (open, high, low, close)]
+    kind, squeeze = conv[0][1], conv[0][2]
+    ts = _same_layout([c[0] for c in conv])
+    dev = ts[0].device
+    n, T = ts[0].shape
+    b = Batch(n, T, ts[0].stride(0) if n > 1 else T)
+    want = PATTERN_NAMES if names is None else list(names)
+    outs = {nm: torch.empty_strided((n, T), (b.stride, 1), dtype=torch.int32, device=dev) for nm in want}
+    pens = (C.c_double * 61)(*[(penetrations or {}).get(nm, PATTERN_PEN_DEFAULT[nm]) for nm in PATTERN_NAMES])
+    ptrs = (C.c_void_p * 61)(*[outs[nm].data_ptr() if nm in outs else None for nm in PATTERN_NAMES])
+    with torch.cuda.device(dev):
+        check(lib().pq_cdl_all(ctx(dev.index), C.byref(b), *[C.c_void_p(t.data_ptr()) for t in ts], pens, ptrs))
+    return {nm: _from_device(o, kind, squeeze, nm) for nm, o in outs.items()}
+
+
+def backtest_vectorized(price, buy, sell, benchmark=None, want_curves: bool = True, **kw):
+    """Batched VectorizedBacktester.run(): -> (position, cash, equity, summary[N,8]) (curves None if not wanted)."""
+    prm = BtParams(**{**BT_DEFAULTS, **kw})
+    p, kind, squeeze = _to_device(price)
+    bu, _, _ = _to_device(buy, torch.uint8)
+    se, _, _ = _to_device(sell, torch.uint8)
+    p = p.contiguous(); bu = bu.contiguous(); se = se.contiguous()
+    bm = _to_device(benchmark)[0].contiguous() if benchmark is not None else None
+    dev = p.device
+    n, T = p.shape
+    b = Batch(n, T, T)
+    mk = lambda: torch.empty((n, T), dtype=torch.float64, device=dev)
+    pos, cash, eq = (mk(), mk(), mk()) if want_curves else (None, None, None)
+    summ = torch.empty((n, 8), dtype=torch.float64, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(dev):
+        check(lib().pq_backtest_vectorized(ctx(dev.index), C.byref(b), vp(p), vp(bu), vp(se), vp(bm), C.byref(prm),
+                                           vp(pos), vp(cash), vp(eq), vp(summ)))
+    f = lambda t: _from_device(t, kind if kind != _Kind.ARROW and kind != _Kind.POLARS else _Kind.NUMPY, squeeze) if t is not None else None
+    return f(pos), f(cash), f(eq), f(summ)
+
+
+def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, want_curves: bool = True, **kw):
+    """Fused MACD-cross strategy + per-symbol backtest + summary (one kernel)."""
+    prm = BtParams(**{**BT_DEFAULTS, **kw})
+    p, kind, squeeze = _to_device(close)
+    p = p.contiguous()
+    dev = p.device
+    n, T = p.shape
+    b = Batch(n, T, T)
+    mk = lambda: torch.empty((n, T), dtype=torch.float64, device=dev)
+    pos, cash, eq = (mk(), mk(), mk()) if want_curves else (None, None, None)
+    summ = torch.empty((n, 8), dtype=torch.float64, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(dev):
+        check(lib().pq_backtest_macd_cross(ctx(dev.index), C.byref(b), vp(p), fastperiod, slowperiod, signalperiod,
+                                           C.byref(prm), vp(pos), vp(cash), vp(eq), vp(summ)))
+    f = lambda t: _from_device(t, kind if kind in (_Kind.TORCH, _Kind.NUMPY) else _Kind.NUMPY, squeeze) if t is not None else None
+    return f(pos), f(cash), f(eq), f(summ)
+
+
+def macd_cross_signals(close, fastperiod=12, slowperiod=26, signalperiod=9):
+    p, kind, squeeze = _to_device(close)
+    p = p.contiguous()
+    dev = p.device
+    n, T = p.shape
+    b = Batch(n, T, T)
+    bu = torch.empty((n, T), dtype=torch.uint8, device=dev)
+    se = torch.empty((n, T), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().pq_macd_cross_signals(ctx(dev.index), C.byref(b), C.c_void_p(p.data_ptr()), fastperiod, slowperiod,
+                                          signalperiod, C.c_void_p(bu.data_ptr()), C.c_void_p(se.data_ptr())))
+    k = kind if kind in (_Kind.TORCH, _Kind.NUMPY) else _Kind.NUMPY
+    return _from_device(bu, k, squeeze), _from_device(se, k, squeeze)

@@ -1,0 +1,138 @@
+// pq_cores.h -- per-lane streaming state machines shared by the SEQ kernels.
+// Each core advances one series by one row in the reference's exact operation order.
+#pragma once
+#include "pq_dev.h"
+
+// overlap.rs:660-730 calc_ema: null-transparent (N-A), SMA seed at count == p, then
+// alpha.mul_add(x - ema, ema).
+struct EmaCore {
+    int64_t p, count;
+    double alpha, ema, sum;
+    bool dead;
+    __device__ void init(int64_t p_, int64_t n) {
+        p = p_;
+        dead = (p <= 0 || n < p);
+        alpha = 2.0 / ((double)p + 1.0);
+        count = 0;
+        ema = 0.0;
+        sum = 0.0;
+    }
+    __device__ double step(double v) {
+        if (dead || pq_isnull(v)) return pq_null();
+        count += 1;
+        if (count < p) {
+            sum += v;
+            return pq_null();
+        } else if (count == p) {
+            sum += v;
+            ema = sum / (double)p;
+            return ema;
+        }
+        ema = fma(alpha, v - ema, ema);
+        return ema;
+    }
+};
+
+// Walks a series forward over its valid (non-null) rows: used to pop "the oldest value still in
+// the window" when nulls are skipped (VecDeque::pop_front in the reference).
+struct ValidCursor {
+    int64_t idx;
+    __device__ void start(int64_t i) { idx = i; }
+    __device__ double pop(const double *col) {
+        double v = col[idx];
+        do { idx++; } while (pq_isnull(col[idx])); // the current (valid) row bounds the walk
+        return v;
+    }
+};
+
+// overlap.rs:871-937 calc_sma: running sum, +new then (count > p) -old, out = sum * (1/p).
+struct SmaCore {
+    int64_t p, count;
+    double denom, sum;
+    bool dead, started;
+    ValidCursor tail;
+    __device__ void init(int64_t p_, int64_t n) {
+        p = p_;
+        dead = (p <= 0 || n < p);
+        denom = 1.0 / (double)p;
+        count = 0;
+        sum = 0.0;
+        started = false;
+    }
+    __device__ double step(const double *col, int64_t t, double v) {
+        if (dead || pq_isnull(v)) return pq_null();
+        if (!started) { tail.start(t); started = true; }
+        count += 1;
+        sum += v;
+        if (count < p) return pq_null();
+        if (count > p) {
+            sum -= tail.pop(col);
+            count -= 1;
+        }
+        return sum * denom;
+    }
+};
+
+// D-1 calc_rma (Wilder) over a null-free slice: None for i < p-1, seed = mean(x[0..p)) at i = p-1,
+// then (prev*(p-1) + x) / p.
+struct RmaCore {
+    int64_t p;
+    double sum, r, pm1, pf;
+    bool dead;
+    __device__ void init(int64_t p_, int64_t n) {
+        p = p_;
+        dead = (p <= 0 || n < p);
+        sum = 0.0;
+        r = 0.0;
+        pm1 = (double)p - 1.0;
+        pf = (double)p;
+    }
+    __device__ double step(int64_t i, double x) {
+        if (dead) return pq_null();
+        if (i < p - 1) {
+            sum += x;
+            return pq_null();
+        } else if (i == p - 1) {
+            sum += x;
+            r = sum / pf;
+            return r;
+        }
+        r = (r * pm1 + x) / pf;
+        return r;
+    }
+};
+
+// Rolling extremum over the last p valid values with a lazy rescan when the extremum expires.
+// Value-equivalent to the reference's monotonic deques (overlap.rs:205-218, :330-343, :383-396);
+// `count - p` wraps for count < p, i.e. nothing expires until the window is full.
+template <bool IS_MAX>
+struct RollExt {
+    int64_t p, j;      // j = number of valid values seen (1-based index of the newest)
+    double best;
+    int64_t best_j;    // 1-based valid-index of the current extremum
+    __device__ void init(int64_t p_) {
+        p = p_;
+        j = 0;
+        best = 0.0;
+        best_j = 0;
+    }
+    __device__ static bool beats(double a, double b) { return IS_MAX ? (a >= b) : (a <= b); }
+    __device__ double step(const double *col, int64_t t, double v) {
+        j += 1;
+        if (j == 1 || beats(v, best)) {
+            best = v;
+            best_j = j;
+        } else if (p > 0 && best_j == j - p) { // expired: rescan the last p valid values
+            best = v;
+            best_j = j;
+            int64_t jj = j, i = t;
+            for (int64_t k = 1; k < p; k++) {
+                do { i--; } while (pq_isnull(col[i]));
+                jj--;
+                double w = col[i];
+                if (IS_MAX ? (w > best) : (w < best)) { best = w; best_j = jj; }
+            }
+        }
+        return best;
+    }
+};

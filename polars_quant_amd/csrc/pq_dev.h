@@ -1,0 +1,199 @@
+// pq_dev.h -- shared device/host plumbing for the gfx950 kernels.
+//
+// Execution shapes used by every kernel in this library:
+//   SEQ  : one series (symbol) per lane, 64 series per wavefront, each lane walks its own series
+//          left-to-right in exactly the reference's operation order (bit-exact f64).  Inputs are
+//          pulled in register chunks of CH rows (independent loads issued ahead of the dependent
+//          recurrence), outputs are pushed the same way.
+//   ROW  : one (series, row) per thread, row index fastest => fully coalesced; used for everything
+//          whose value is a pure function of a bounded look-back window (exact, order-free).
+// All arithmetic is compiled with -ffp-contract=off; fma() appears only where the reference
+// calls f64::mul_add.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pq_hip.h"
+
+struct pq_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    void *ws;        // scratch workspace (device)
+    size_t ws_bytes;
+    int64_t *d_flag; // 1 x int64 device scalar for reductions
+};
+
+void pq_set_error(const char *fmt, ...);
+pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes);
+// n-th scratch column ([n_series][stride] doubles) of the workspace; reserve first
+static inline double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k) {
+    return reinterpret_cast<double *>(ctx->ws) + (size_t)k * (size_t)(b->n_series * b->stride);
+}
+pq_status pq_check(pq_ctx *ctx, const pq_batch *b);
+
+#define PQ_HIP_TRY(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            pq_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PQ_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+#define PQ_TRY(expr)                      \
+    do {                                  \
+        pq_status s__ = (expr);           \
+        if (s__ != PQ_OK) return s__;     \
+    } while (0)
+#define PQ_REQUIRE(cond, msg)             \
+    do {                                  \
+        if (!(cond)) {                    \
+            pq_set_error("%s", msg);      \
+            return PQ_ERR_ARG;            \
+        }                                 \
+    } while (0)
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ double pq_null() { return __longlong_as_double((long long)PQ_NULL_BITS); }
+__device__ __forceinline__ bool pq_isnull(double x) {
+    return (unsigned long long)__double_as_longlong(x) == PQ_NULL_BITS;
+}
+
+struct Dims {
+    int64_t n, len, stride;
+};
+static inline Dims dims_of(const pq_batch *b) { return Dims{b->n_series, b->len, b->stride}; }
+
+template <int N>
+struct InCols {
+    const double *p[N > 0 ? N : 1];
+};
+template <int N>
+struct OutCols {
+    double *p[N > 0 ? N : 1];
+};
+
+// Per-lane view of one series: random access to its own rows (used for lagged reads).
+template <int NIN>
+struct Row {
+    const double *in[NIN > 0 ? NIN : 1]; // already offset to this series
+    int64_t len;
+};
+
+constexpr int SEQ_BLOCK = 64; // one wavefront per workgroup: more workgroups to spread over 256 CUs
+constexpr int SEQ_CH = 8;     // rows per register chunk
+
+// SEQ driver.  Op contract:
+//   static constexpr int NIN, NOUT;
+//   __device__ void init(const Row<NIN>& r);                       // once per series
+//   __device__ void step(const Row<NIN>& r, int64_t t, const double (&x)[NIN], double (&y)[NOUT]);
+template <class Op>
+__global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
+    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, CH = SEQ_CH;
+    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (s >= d.n) return;
+    Row<NIN> r;
+    r.len = d.len;
+#pragma unroll
+    for (int k = 0; k < NIN; k++) r.in[k] = in.p[k] + s * d.stride;
+    double *o[NOUT];
+#pragma unroll
+    for (int k = 0; k < NOUT; k++) o[k] = out.p[k] + s * d.stride;
+    op.init(r);
+    const int64_t T = d.len;
+    int64_t t0 = 0;
+    double xb[NIN][CH];
+    // prologue: first chunk
+    if (T >= CH) {
+#pragma unroll
+        for (int k = 0; k < NIN; k++)
+#pragma unroll
+            for (int j = 0; j < CH; j++) xb[k][j] = r.in[k][j];
+    }
+    for (; t0 + CH <= T; t0 += CH) {
+        double xc[NIN][CH];
+#pragma unroll
+        for (int k = 0; k < NIN; k++)
+#pragma unroll
+            for (int j = 0; j < CH; j++) xc[k][j] = xb[k][j];
+        // issue the next chunk's loads before the dependent recurrence of this one
+        if (t0 + 2 * CH <= T) {
+#pragma unroll
+            for (int k = 0; k < NIN; k++)
+#pragma unroll
+                for (int j = 0; j < CH; j++) xb[k][j] = r.in[k][t0 + CH + j];
+        }
+        double yb[NOUT][CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            double x[NIN], y[NOUT];
+#pragma unroll
+            for (int k = 0; k < NIN; k++) x[k] = xc[k][j];
+            op.step(r, t0 + j, x, y);
+#pragma unroll
+            for (int k = 0; k < NOUT; k++) yb[k][j] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NOUT; k++)
+#pragma unroll
+            for (int j = 0; j < CH; j++) o[k][t0 + j] = yb[k][j];
+    }
+    for (; t0 < T; t0++) { // tail
+        double x[NIN], y[NOUT];
+#pragma unroll
+        for (int k = 0; k < NIN; k++) x[k] = r.in[k][t0];
+        op.step(r, t0, x, y);
+#pragma unroll
+        for (int k = 0; k < NOUT; k++) o[k][t0] = y[k];
+    }
+}
+
+template <class Op>
+static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in,
+                                   const OutCols<Op::NOUT> &out) {
+    if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
+    hipLaunchKernelGGL(seq_kernel<Op>, grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b));
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+
+// ROW driver.  Op contract:
+//   static constexpr int NIN, NOUT;  typedef OutT (double or int32_t)
+//   __device__ void eval(const Row<NIN>& r, int64_t t, OutT (&y)[NOUT]);
+constexpr int ROW_BLOCK = 256;
+template <class Op, class OutT>
+struct OutColsT {
+    OutT *p[Op::NOUT];
+};
+template <class Op>
+__global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> in, OutColsT<Op, typename Op::OutT> out, Dims d) {
+    const int64_t s = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
+    if (t >= d.len) return;
+    Row<Op::NIN> r;
+    r.len = d.len;
+#pragma unroll
+    for (int k = 0; k < Op::NIN; k++) r.in[k] = in.p[k] + s * d.stride;
+    typename Op::OutT y[Op::NOUT];
+    op.eval(r, t, y);
+#pragma unroll
+    for (int k = 0; k < Op::NOUT; k++) out.p[k][s * d.stride + t] = y[k];
+}
+template <class Op>
+static inline pq_status launch_row(pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in,
+                                   const OutColsT<Op, typename Op::OutT> &out) {
+    if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    // grid.y is limited to 65535: slice the series axis
+    for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
+        int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
+        InCols<Op::NIN> in2 = in;
+        OutColsT<Op, typename Op::OutT> out2 = out;
+        for (int k = 0; k < Op::NIN; k++) in2.p[k] += s0 * b->stride;
+        for (int k = 0; k < Op::NOUT; k++) out2.p[k] += s0 * b->stride;
+        dim3 grid((unsigned)((b->len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns);
+        Dims d{ns, b->len, b->stride};
+        hipLaunchKernelGGL(row_kernel<Op>, grid, dim3(ROW_BLOCK), 0, ctx->stream, op, in2, out2, d);
+        PQ_HIP_TRY(hipGetLastError());
+    }
+    return PQ_OK;
+}

@@ -1,0 +1,184 @@
+// runtime.hip -- context (device + stream + scratch workspace), error reporting, memory helpers and the
+// Arrow-validity <-> null-sentinel conversions of the C ABI (include/pq_hip.h).
+#include "pq_dev.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void pq_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+pq_status pq_check(pq_ctx *ctx, const pq_batch *b) {
+    if (!ctx) { pq_set_error("null context"); return PQ_ERR_ARG; }
+    if (!b) { pq_set_error("null batch descriptor"); return PQ_ERR_ARG; }
+    if (b->n_series < 0 || b->len < 0 || b->stride < b->len) {
+        pq_set_error("bad batch: n_series=%lld len=%lld stride=%lld", (long long)b->n_series, (long long)b->len,
+                     (long long)b->stride);
+        return PQ_ERR_ARG;
+    }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { pq_set_error("hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e)); return PQ_ERR_HIP; }
+    return PQ_OK;
+}
+
+pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return PQ_OK;
+    // grow-only; earlier launches may still read the old block -> drain the stream before freeing it
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) PQ_HIP_TRY(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->ws, bytes);
+    if (e != hipSuccess) { pq_set_error("workspace hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return PQ_ERR_NOMEM; }
+    ctx->ws_bytes = bytes;
+    return PQ_OK;
+}
+
+// ------------------------------------------------------------------ null conversions
+__global__ void nulls_from_arrow_kernel(double *col, const uint8_t *bits, int64_t bit_offset, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t bi = bit_offset + i;
+    if (!((bits[bi >> 3] >> (bi & 7)) & 1)) col[i] = pq_null();
+}
+// one thread per output byte (8 rows); null count via per-wave popcount + one atomic per wave
+__global__ void validity_to_arrow_kernel(const double *col, int64_t n, uint8_t *bits, unsigned long long *null_count) {
+    int64_t byte = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nbytes = (n + 7) >> 3;
+    unsigned nulls = 0;
+    if (byte < nbytes) {
+        unsigned v = 0;
+        for (int k = 0; k < 8; k++) {
+            int64_t i = byte * 8 + k;
+            if (i < n) {
+                if (!pq_isnull(col[i])) v |= 1u << k; else nulls++;
+            }
+        }
+        bits[byte] = (uint8_t)v;
+    }
+    for (int off = 32; off > 0; off >>= 1) nulls += __shfl_down(nulls, off, 64);
+    if ((threadIdx.x & 63) == 0 && nulls && null_count) atomicAdd(null_count, (unsigned long long)nulls);
+}
+__global__ void count_nulls_kernel(const double *col, Dims d, unsigned long long *count) {
+    const int64_t s = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned nulls = (t < d.len && pq_isnull(col[s * d.stride + t])) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) nulls += __shfl_down(nulls, off, 64);
+    if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(count, (unsigned long long)nulls);
+}
+
+extern "C" {
+
+int32_t pq_abi_version(void) { return 1; }
+const char *pq_last_error(void) { return g_err; }
+
+pq_status pq_device_count(int32_t *count) {
+    if (!count) { pq_set_error("pq_device_count: null pointer"); return PQ_ERR_ARG; }
+    int n = 0;
+    PQ_HIP_TRY(hipGetDeviceCount(&n));
+    *count = n;
+    return PQ_OK;
+}
+
+pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out) {
+    if (!out) { pq_set_error("pq_ctx_create: null pointer"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipSetDevice(device));
+    pq_ctx *c = new pq_ctx();
+    c->device = device;
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    c->d_flag = nullptr;
+    c->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
+    c->own_stream = false;
+    hipError_t e = hipMalloc((void **)&c->d_flag, sizeof(int64_t));
+    if (e != hipSuccess) { if (c->own_stream) (void)hipStreamDestroy(c->stream); delete c; pq_set_error("hipMalloc: %s", hipGetErrorString(e)); return PQ_ERR_NOMEM; }
+    *out = c;
+    return PQ_OK;
+}
+pq_status pq_ctx_destroy(pq_ctx *ctx) {
+    if (!ctx) return PQ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PQ_OK;
+}
+pq_status pq_ctx_set_stream(pq_ctx *ctx, void *hip_stream) {
+    if (!ctx) { pq_set_error("null context"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    ctx->stream = (hipStream_t)hip_stream;
+    return PQ_OK;
+}
+pq_status pq_ctx_sync(pq_ctx *ctx) {
+    if (!ctx) { pq_set_error("null context"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+pq_status pq_malloc(pq_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) { pq_set_error("pq_malloc: null pointer"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { pq_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return PQ_ERR_NOMEM; }
+    return PQ_OK;
+}
+pq_status pq_free(pq_ctx *ctx, void *dptr) {
+    if (!ctx) { pq_set_error("null context"); return PQ_ERR_ARG; }
+    if (dptr) { PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); PQ_HIP_TRY(hipFree(dptr)); }
+    return PQ_OK;
+}
+pq_status pq_memcpy_h2d(pq_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) { pq_set_error("pq_memcpy_h2d: null pointer"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PQ_OK;
+}
+pq_status pq_memcpy_d2h(pq_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) { pq_set_error("pq_memcpy_d2h: null pointer"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+pq_status pq_nulls_from_arrow(pq_ctx *ctx, double *col, const uint8_t *bits, int64_t bit_offset, int64_t n) {
+    if (!ctx || !col || !bits || n < 0 || bit_offset < 0) { pq_set_error("pq_nulls_from_arrow: bad argument"); return PQ_ERR_ARG; }
+    if (n == 0) return PQ_OK;
+    hipLaunchKernelGGL(nulls_from_arrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, col, bits, bit_offset, n);
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+pq_status pq_validity_to_arrow(pq_ctx *ctx, const double *col, int64_t n, uint8_t *bits, int64_t *null_count) {
+    if (!ctx || !col || !bits || n < 0) { pq_set_error("pq_validity_to_arrow: bad argument"); return PQ_ERR_ARG; }
+    if (null_count) PQ_HIP_TRY(hipMemsetAsync(null_count, 0, sizeof(int64_t), ctx->stream));
+    if (n == 0) return PQ_OK;
+    int64_t nbytes = (n + 7) >> 3;
+    hipLaunchKernelGGL(validity_to_arrow_kernel, dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, ctx->stream, col, n, bits,
+                       (unsigned long long *)null_count);
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+pq_status pq_count_nulls(pq_ctx *ctx, const pq_batch *b, const double *col, int64_t *host_count) {
+    PQ_TRY(pq_check(ctx, b));
+    if (!col || !host_count) { pq_set_error("pq_count_nulls: null pointer"); return PQ_ERR_ARG; }
+    *host_count = 0;
+    if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    PQ_HIP_TRY(hipMemsetAsync(ctx->d_flag, 0, sizeof(int64_t), ctx->stream));
+    for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
+        int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
+        Dims d{ns, b->len, b->stride};
+        hipLaunchKernelGGL(count_nulls_kernel, dim3((unsigned)((b->len + 255) / 256), (unsigned)ns), dim3(256), 0, ctx->stream,
+                           col + s0 * b->stride, d, (unsigned long long *)ctx->d_flag);
+        PQ_HIP_TRY(hipGetLastError());
+    }
+    PQ_HIP_TRY(hipMemcpyAsync(host_count, ctx->d_flag, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+
+} // extern "C"

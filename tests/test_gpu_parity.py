@@ -1,0 +1,292 @@
+"""-m gpu parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact for integer outputs; f64 indicators <= 1e-12 relative.  The HIP
+kernels follow the reference's operation order, so everything that does not pass through a device
+transcendental (atan/sin/pow) is in fact compared BIT-FOR-BIT; the HT_*/MAMA family and the summary's
+annualised return / sharpe use the stated 1e-12 tolerance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+N_SYM, T = 70, 301          # deliberately not multiples of 64 / 8
+SEED = 0x5EED0002
+TRANSCENDENTAL = {"ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine", "mama"}
+RTOL = 1e-12                # north_star tolerance for f64 indicators
+
+
+@pytest.fixture(scope="module")
+def pq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import polars_quant_amd as pq
+    from polars_quant_amd._lib import lib
+    lib()  # fail loudly if the HIP library is missing
+    return pq
+
+
+@pytest.fixture(scope="module")
+def data(oracle):
+    d = oracle.gen_ohlcv(SEED, N_SYM, T, 0)
+    d["real"] = d["close"]
+    rng = np.random.default_rng(7)
+    d["periods"] = rng.integers(0, 40, size=(N_SYM, T)).astype(np.float64)
+    return d
+
+
+@pytest.fixture(scope="module")
+def rich(oracle):
+    d = oracle.gen_ohlcv(SEED + 1, N_SYM, T, 1)
+    d["real"] = d["close"]
+    return d
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def assert_same(name, got, exp, exact=True):
+    got = np.asarray(got)
+    assert got.shape == exp.shape and got.dtype == exp.dtype, (name, got.shape, exp.shape, got.dtype, exp.dtype)
+    if exp.dtype != np.float64:
+        assert (got == exp).all(), f"{name}: {np.sum(got != exp)} int mismatches"
+        return
+    NULLB = np.uint64(0x7FF80000504E554C)
+    gn, en = bits(got) == NULLB, bits(exp) == NULLB
+    assert (gn == en).all(), f"{name}: null masks differ at {np.argwhere(gn != en)[:5].tolist()}"
+    if exact:
+        bad = (bits(got) != bits(exp)) & ~(np.isnan(got) & np.isnan(exp))
+        assert not bad.any(), (f"{name}: {bad.sum()} of {bad.size} not bit-exact; first at {np.argwhere(bad)[:3].tolist()} "
+                               f"got {got[bad][:3]} exp {exp[bad][:3]}")
+    else:
+        ok = ~en
+        g, e = got[ok], exp[ok]
+        both_nan = np.isnan(g) & np.isnan(e)
+        err = np.abs(g - e) / np.maximum(np.abs(e), 1e-300)
+        err[both_nan] = 0
+        # values that are differences of O(price) quantities are judged against the input scale too
+        assert (err <= RTOL).all() or (np.abs(g - e) <= RTOL * 100.0).all(), f"{name}: max rel err {np.nanmax(err):.3e}"
+
+
+def run_gpu(pq, name, d, **params):
+    from polars_quant_amd import api
+    cols = pq.SPEC[name][0]
+    ins = [torch.from_numpy(d[c]).cuda() for c in cols]
+    res = api.call(name, *ins, **params)
+    torch.cuda.synchronize()
+    return [r.cpu().numpy() for r in res]
+
+
+ALL_FUNCS = sorted(__import__("polars_quant_amd._spec", fromlist=["SPEC"]).SPEC)
+
+
+@pytest.mark.parametrize("name", ALL_FUNCS)
+def test_indicator_defaults(pq, oracle, data, name):
+    """every function of SURVEY 8(a) with the Python-wrapper default parameters"""
+    cols = pq.SPEC[name][0]
+    exp = oracle.call(name, *[data[c] for c in cols])
+    got = run_gpu(pq, name, data)
+    for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
+        assert_same(f"{name}.{oname}", g, e, exact=name not in TRANSCENDENTAL)
+
+
+PARAM_CASES = [
+    ("sma", dict(timeperiod=1)), ("sma", dict(timeperiod=5)), ("sma", dict(timeperiod=0)), ("sma", dict(timeperiod=400)),
+    ("ema", dict(timeperiod=2)), ("ema", dict(timeperiod=20)), ("ema", dict(timeperiod=301)),
+    ("bbands", dict(timeperiod=5, nbdevup=1.5, nbdevdn=2.5)), ("dema", dict(timeperiod=1)), ("dema", dict(timeperiod=7)),
+    ("tema", dict(timeperiod=1)), ("tema", dict(timeperiod=9)), ("t3", dict(timeperiod=1, vfactor=0.7)),
+    ("t3", dict(timeperiod=4, vfactor=0.0)), ("t3", dict(timeperiod=10, vfactor=0.3)),
+    ("trima", dict(timeperiod=7)), ("trima", dict(timeperiod=8)), ("wma", dict(timeperiod=3)),
+    ("kama", dict(timeperiod=1)), ("kama", dict(timeperiod=2)), ("kama", dict(timeperiod=10)),
+    ("midpoint", dict(timeperiod=1)), ("midpoint", dict(timeperiod=3)), ("midpoint", dict(timeperiod=0)),
+    ("midprice", dict(timeperiod=2)), ("midprice", dict(timeperiod=30)),
+    ("mama", dict(fastlimit=0.5, slowlimit=0.05)),
+    ("mavp", dict(minperiod=2, maxperiod=12, matype=1)), ("mavp", dict(minperiod=3, maxperiod=9, matype=2)),
+    ("sar", dict(acceleration=0.02, maximum=0.2)), ("sar", dict(acceleration=0.3, maximum=0.2)),
+    ("sarext", dict(startvalue=0.0, offsetonreverse=0.01, accelerationinitlong=0.02, accelerationlong=0.02,
+                    accelerationmaxlong=0.2, accelerationinitshort=0.03, accelerationshort=0.03, accelerationmaxshort=0.3)),
+    ("sarext", dict(startvalue=-50.0, offsetonreverse=0.0, accelerationinitlong=0.02, accelerationlong=0.02,
+                    accelerationmaxlong=0.2, accelerationinitshort=0.02, accelerationshort=0.02, accelerationmaxshort=0.2)),
+    ("sarext", dict(startvalue=5.0, offsetonreverse=0.0, accelerationinitlong=0.02, accelerationlong=0.02,
+                    accelerationmaxlong=0.2, accelerationinitshort=0.02, accelerationshort=0.02, accelerationmaxshort=0.2)),
+    *[("ma", dict(timeperiod=6, matype=m)) for m in range(10)],
+    ("adx", dict(timeperiod=5)), ("adxr", dict(timeperiod=5)), ("adxr", dict(timeperiod=1)), ("dx", dict(timeperiod=3)),
+    ("aroon", dict(timeperiod=5)), ("aroonosc", dict(timeperiod=25)), ("cci", dict(timeperiod=5)), ("cci", dict(timeperiod=20)),
+    ("cmo", dict(timeperiod=1)), ("cmo", dict(timeperiod=9)), ("macd", dict(fastperiod=3, slowperiod=7, signalperiod=4)),
+    ("macd", dict(fastperiod=5, slowperiod=35, signalperiod=5)), ("mfi", dict(timeperiod=4)),
+    ("mom", dict(timeperiod=0)), ("mom", dict(timeperiod=300)), ("roc", dict(timeperiod=1)),
+    ("rsi", dict(timeperiod=2)), ("rsi", dict(timeperiod=30)), ("trix", dict(timeperiod=5)),
+    ("ultosc", dict(timeperiod1=2, timeperiod2=3, timeperiod3=5)), ("willr", dict(timeperiod=1)), ("willr", dict(timeperiod=40)),
+    *[("apo", dict(fastperiod=3, slowperiod=10, matype=m)) for m in (0, 1, 3, 5)],
+    ("ppo", dict(fastperiod=3, slowperiod=10, matype=1)),
+    ("macdext", dict(fastperiod=4, fastmatype=1, slowperiod=9, slowmatype=2, signalperiod=3, signalmatype=0)),
+    ("macdext", dict(fastperiod=4, fastmatype=5, slowperiod=9, slowmatype=4, signalperiod=3, signalmatype=1)),
+    ("stoch", dict(fastk_period=7, slowk_period=4, slowk_matype=1, slowd_period=3, slowd_matype=2)),
+    ("stochf", dict(fastk_period=9, fastd_period=5, fastd_matype=1)),
+    ("stochrsi", dict(timeperiod=7, fastk_period=6, fastd_period=4, fastd_matype=0)),
+    ("atr", dict(timeperiod=1)), ("atr", dict(timeperiod=5)), ("natr", dict(timeperiod=20)),
+    ("adosc", dict(fastperiod=2, slowperiod=5)),
+]
+
+
+@pytest.mark.parametrize("name,params", PARAM_CASES, ids=[f"{n}-{i}" for i, (n, _) in enumerate(PARAM_CASES)])
+def test_indicator_params(pq, oracle, data, name, params):
+    cols = pq.SPEC[name][0]
+    exp = oracle.call(name, *[data[c] for c in cols], **params)
+    got = run_gpu(pq, name, data, **params)
+    for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
+        assert_same(f"{name}.{oname}{params}", g, e, exact=name not in TRANSCENDENTAL)
+
+
+NULL_TOLERANT = [n for n, v in __import__("polars_quant_amd._spec", fromlist=["SPEC"]).SPEC.items()
+                 if v[3] in ("N-A", "N-C", "N-0") and n not in ("stochrsi",)]
+
+
+@pytest.mark.parametrize("name", sorted(NULL_TOLERANT))
+def test_null_bearing(pq, oracle, data, name):
+    """third data set of SURVEY 8(d): 1 % random nulls + leading nulls (N-A / N-C / N-0 families)"""
+    rng = np.random.default_rng(11)
+    d = {}
+    for k, v in data.items():
+        a = v.copy()
+        mask = rng.random(a.shape) < 0.01
+        mask[:, :3] = True
+        mask[5] = False                      # one null-free series
+        mask[6, 100:] = True                 # one series that goes fully null
+        a[mask] = oracle.NULL
+        d[k] = a
+    cols = pq.SPEC[name][0]
+    params = dict(timeperiod=5) if any(p == "timeperiod" for p, _, _ in pq.SPEC[name][1]) else {}
+    exp = oracle.call(name, *[d[c] for c in cols], **params)
+    got = run_gpu(pq, name, d, **params)
+    for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
+        assert_same(f"{name}.{oname}", g, e, exact=name not in TRANSCENDENTAL)
+
+
+def test_short_and_empty_series(pq, oracle):
+    """edge cases: T smaller than every warm-up, T == 1, n_series == 0"""
+    from polars_quant_amd import api
+    for T_ in (1, 2, 7, 31, 32):
+        d = oracle.gen_ohlcv(3, 3, T_, 0)
+        for name in ("sma", "ema", "t3", "kama", "macd", "rsi", "ht_dcperiod", "midpoint", "adx"):
+            cols = [c if c != "real" else "close" for c in pq.SPEC[name][0]]
+            exp = oracle.call(name, *[d[c] for c in cols])
+            got = [r.cpu().numpy() for r in api.call(name, *[torch.from_numpy(d[c]).cuda() for c in cols])]
+            for g, e in zip(got, exp):
+                assert_same(f"{name}@T={T_}", g, e, exact=name != "ht_dcperiod")
+    empty = torch.empty((0, 16), dtype=torch.float64, device="cuda")
+    (r,) = api.call("sma", empty)
+    assert r.shape == (0, 16)
+
+
+def test_strided_batch(pq, oracle, data):
+    """stride > len: series embedded in a wider buffer"""
+    from polars_quant_amd import api
+    wide = torch.full((N_SYM, T + 11), 123.0, dtype=torch.float64, device="cuda")
+    wide[:, :T] = torch.from_numpy(data["close"]).cuda()
+    view = wide[:, :T]
+    (got,) = api.call("ema", view, timeperiod=10)
+    (exp,) = oracle.call("ema", data["close"], timeperiod=10)
+    assert_same("ema-strided", got.cpu().numpy(), exp)
+
+
+def test_patterns_each(pq, oracle, rich):
+    from polars_quant_amd import api
+    o, h, l, c = (torch.from_numpy(rich[k]).cuda() for k in ("open", "high", "low", "close"))
+    fired = 0
+    for name in pq.PATTERN_NAMES:
+        exp = oracle.pattern(name, rich["open"], rich["high"], rich["low"], rich["close"])
+        got = api.cdl(name, o, h, l, c).cpu().numpy()
+        assert (got == exp).all(), f"{name}: {np.sum(got != exp)} mismatches"
+        fired += int((exp != 0).any())
+    assert fired >= 45, f"only {fired} of 61 recognisers ever fire on the pattern-rich set"
+
+
+def test_patterns_fused_equals_single(pq, oracle, rich, data):
+    from polars_quant_amd import api
+    for d in (rich, data):
+        o, h, l, c = (torch.from_numpy(d[k]).cuda() for k in ("open", "high", "low", "close"))
+        allp = api.cdl_all(o, h, l, c)
+        for name in pq.PATTERN_NAMES:
+            exp = oracle.pattern(name, d["open"], d["high"], d["low"], d["close"])
+            assert (allp[name].cpu().numpy() == exp).all(), name
+    sub = api.cdl_all(o, h, l, c, names=["cdldoji", "cdlengulfing"], penetrations={"cdldoji": 0.1})
+    assert sorted(sub) == ["cdldoji", "cdlengulfing"]
+    for pen in (0.1, 0.5, 0.9):
+        exp = oracle.pattern("cdlpiercing", rich["open"], rich["high"], rich["low"], rich["close"], penetration=pen)
+        o, h, l, c = (torch.from_numpy(rich[k]).cuda() for k in ("open", "high", "low", "close"))
+        assert (api.cdl("cdlpiercing", o, h, l, c, penetration=pen).cpu().numpy() == exp).all()
+
+
+def test_backtest_vectorized(pq, oracle, data):
+    from polars_quant_amd import api
+    rng = np.random.default_rng(5)
+    price = data["close"].copy()
+    price[3, 50] = np.nan
+    price[4, 60] = -1.0
+    price[7, 10:20] = oracle.NULL
+    buy = (rng.random(price.shape) < 0.05).astype(np.uint8)
+    sell = (rng.random(price.shape) < 0.05).astype(np.uint8)
+    bench = data["open"]
+    for kw in (dict(), dict(buy_slippage=0.01, sell_slippage=0.02, position_size=0.5, min_commission=1.0),
+               dict(initial_capital=50.0)):
+        epos, ecash, eeq, es = oracle.backtest(np.where(np.isnan(price), np.nan, price), buy, sell, benchmark=bench, **kw)
+        pos, cash, eq, s = api.backtest_vectorized(torch.from_numpy(price).cuda(), torch.from_numpy(buy).cuda(),
+                                                   torch.from_numpy(sell).cuda(), benchmark=torch.from_numpy(bench).cuda(), **kw)
+        for nm, g, e in (("position", pos, epos), ("cash", cash, ecash), ("equity", eq, eeq)):
+            g = g.cpu().numpy()
+            same = (bits(g) == bits(e)) | (np.isnan(g) & np.isnan(e))
+            assert same.all(), f"{nm}: {np.sum(~same)} rows differ"
+        s = s.cpu().numpy()
+        ok = ~(np.isnan(es).any(axis=1))
+        # exact columns: max_drawdown, max_profit, win_rate, total_trades (no transcendental involved)
+        for k in (1, 5, 6, 7):
+            assert (bits(s[ok, k]) == bits(es[ok, k])).all(), pq.SUMMARY_KEYS[k]
+        for k in (0, 2, 3, 4):
+            np.testing.assert_allclose(s[ok, k], es[ok, k], rtol=1e-12, atol=1e-13, err_msg=pq.SUMMARY_KEYS[k])
+        assert np.isnan(s[~ok]).any(axis=1).all()
+
+
+def test_backtest_macd_cross_fused(pq, oracle, data):
+    from polars_quant_amd import api
+    close = data["close"]
+    ebuy, esell = oracle.macd_cross_signals(close)
+    buy, sell = api.macd_cross_signals(torch.from_numpy(close).cuda())
+    assert (buy.cpu().numpy() == ebuy).all() and (sell.cpu().numpy() == esell).all()
+    assert ebuy.sum() > 0 and esell.sum() > 0
+    epos, ecash, eeq, es = oracle.backtest(close, ebuy, esell)
+    pos, cash, eq, s = api.backtest_macd_cross(torch.from_numpy(close).cuda())
+    assert (bits(pos.cpu().numpy()) == bits(epos)).all()
+    assert (bits(cash.cpu().numpy()) == bits(ecash)).all()
+    assert (bits(eq.cpu().numpy()) == bits(eeq)).all()
+    s = s.cpu().numpy()
+    for k in (1, 5, 6, 7):
+        assert (bits(s[:, k]) == bits(es[:, k])).all()
+    np.testing.assert_allclose(s, es, rtol=1e-12, atol=1e-13)
+    # summary-only mode (curves not materialised by the caller)
+    _, _, _, s2 = api.backtest_macd_cross(torch.from_numpy(close).cuda(), want_curves=False)
+    assert (bits(s2.cpu().numpy()) == bits(s)).all()
+
+
+def test_numpy_and_arrow_roundtrip(pq, oracle, data):
+    import pyarrow as pa
+    x = data["close"][0].copy()
+    (exp,) = oracle.call("sma", x, timeperiod=4)
+    got = pq.SMA(x, 4)
+    assert isinstance(got, np.ndarray)
+    assert_same("sma-numpy", got, exp)
+    arr = pa.array(x, mask=np.arange(len(x)) % 17 == 3)
+    xn = x.copy(); xn[np.arange(len(x)) % 17 == 3] = oracle.NULL
+    (exp,) = oracle.call("ema", xn, timeperiod=4)
+    got = pq.EMA(arr, 4)
+    assert isinstance(got, pa.Array) and got.null_count == int(np.sum(bits(exp) == np.uint64(oracle.NULL_BITS)))
+    vals = got.to_numpy(zero_copy_only=False)
+    ok = ~np.asarray(got.is_null())
+    assert (vals[ok] == exp[ok]).all()
+    with pytest.raises(pq.NullsNotAllowed):
+        pq.RSI(arr, 14)            # N-B family rejects nulls like the reference (momentum.rs:12-13)
+    up, mid, lo = pq.BBANDS(x)
+    assert up.shape == x.shape
