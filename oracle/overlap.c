@@ -259,6 +259,9 @@ void pqo_ma(const double *v, int64_t n, int64_t p, int64_t matype, double *out) 
  * window_max.front() (:227-231, :264-268), and `count - timeperiod` is a wrapping usize
  * subtraction.  No warm-up nulls. */
 void pqo_midpoint(const double *v, int64_t n, int64_t p, double *out) {
+    /* D-7b: timeperiod <= 0 is degenerate in the reference (for p == 0 the mis-targeted expiry test fires
+     * whenever the new value is the running max); defined as all-null here and in the HIP path. */
+    if (p <= 0) { pqo_fill_null(out, n); return; }
     uint64_t count = 0;
     double mx = 0.0, mn = 0.0;
     pqo_ideque wmax, wmin; idq_init(&wmax, n); idq_init(&wmin, n);
@@ -286,6 +289,7 @@ void pqo_midpoint(const double *v, int64_t n, int64_t p, double *out) {
  * produce equal-length columns when a null is present, so (decision D-7) a null in either input
  * yields a null output row and does not advance that input's window. */
 void pqo_midprice(const double *h, const double *l, int64_t n, int64_t p, double *out) {
+    if (p <= 0) { pqo_fill_null(out, n); return; } /* D-7b */
     double *hm = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     double *lm = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     pqo_ideque w; idq_init(&w, n);

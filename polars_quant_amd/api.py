@@ -165,8 +165,9 @@ def call(name: str, *inputs, check_nulls: bool = False, **params):
            for _, dt in outs]
     with torch.cuda.device(dev):
         fn = getattr(lib(), "pq_" + name)
-        check(fn(ctx(dev.index), C.byref(b), *[C.c_void_p(t.data_ptr()) for t in ts], *pvals,
-                 *[C.c_void_p(r.data_ptr()) for r in res]))
+        if n * T > 0:  # an empty batch has no device storage to point at
+            check(fn(ctx(dev.index), C.byref(b), *[C.c_void_p(t.data_ptr()) for t in ts], *pvals,
+                     *[C.c_void_p(r.data_ptr()) for r in res]))
     return tuple(_from_device(r, kind, squeeze, oname) for r, (oname, _) in zip(res, outs))
 
 

@@ -233,7 +233,7 @@ struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires =
     __device__ void init(const Row<1> &) { mx.init(p); mn = 0.0; any = false; }
     __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
         double v = x[0];
-        if (pq_isnull(v)) { y[0] = pq_null(); return; }
+        if (p <= 0 || pq_isnull(v)) { y[0] = pq_null(); return; } // p <= 0: decision D-7b
         double m = mx.step(r.in[0], t, v);
         if (!any || v <= mn) { mn = v; any = true; }
         y[0] = (m + mn) / 2.0;
@@ -248,6 +248,7 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
     __device__ void init(const Row<2> &) { mx.init(p); mn.init(p); }
     __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
         double hm = pq_null(), lm = pq_null();
+        if (p <= 0) { y[0] = pq_null(); return; } // decision D-7b
         if (!pq_isnull(x[0])) hm = mx.step(r.in[0], t, x[0]);
         if (!pq_isnull(x[1])) lm = mn.step(r.in[1], t, x[1]);
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;

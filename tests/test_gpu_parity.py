@@ -101,7 +101,7 @@ PARAM_CASES = [
     ("t3", dict(timeperiod=4, vfactor=0.0)), ("t3", dict(timeperiod=10, vfactor=0.3)),
     ("trima", dict(timeperiod=7)), ("trima", dict(timeperiod=8)), ("wma", dict(timeperiod=3)),
     ("kama", dict(timeperiod=1)), ("kama", dict(timeperiod=2)), ("kama", dict(timeperiod=10)),
-    ("midpoint", dict(timeperiod=1)), ("midpoint", dict(timeperiod=3)), ("midpoint", dict(timeperiod=0)),
+    ("midpoint", dict(timeperiod=1)), ("midpoint", dict(timeperiod=3)), ("midpoint", dict(timeperiod=0)), ("midprice", dict(timeperiod=0)),
     ("midprice", dict(timeperiod=2)), ("midprice", dict(timeperiod=30)),
     ("mama", dict(fastlimit=0.5, slowlimit=0.05)),
     ("mavp", dict(minperiod=2, maxperiod=12, matype=1)), ("mavp", dict(minperiod=3, maxperiod=9, matype=2)),
