@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""bench.py -- indicator + backtest rows/sec on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+A step = one pass of the hot path over one synthetic symbol-major OHLCV block already resident in HBM:
+the full talib suite (every function of SURVEY 8(a), Python-wrapper default parameters, all 61 candlestick
+recognisers fused) + the fused MACD-cross per-symbol backtest with summary.  N GPUs: each rank owns its own
+shard of symbols (static split, no data-path collective); the only exchange is one all_gather of the
+[n_local, 8] summary table per step.  rows = symbols x days.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_SYM, T_DAYS, SEED = 5000, 2520, 0x5EED0002
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def make_inputs(n_sym: int, T: int, seed: int, device):
+    """SURVEY 8(d) generator, evaluated on the device (same integer hash + f64 arithmetic as oracle/backtest.c)."""
+    from oracle import pq_oracle as oracle  # generator only: synthetic inputs, not part of the measured path
+    d = oracle.gen_ohlcv(seed, n_sym, T, 0)
+    return {k: torch.from_numpy(v).to(device) for k, v in d.items()}
+
+
+def cpu_baseline(sample_syms: int, T: int):
+    from oracle import pq_oracle as oracle
+    d = oracle.gen_ohlcv(SEED, sample_syms, T, 0)
+    cores = len(os.sched_getaffinity(0))
+    oracle.suite_bench({k: v[:8] for k, v in d.items()}, cores)  # spin up the OpenMP team
+    t0 = time.perf_counter(); oracle.suite_bench(d, cores); t_all = time.perf_counter() - t0
+    small = {k: v[: max(8, sample_syms // 8)] for k, v in d.items()}
+    t0 = time.perf_counter(); oracle.suite_bench(small, 1); t_one = time.perf_counter() - t0
+    rows = sample_syms * T
+    return {"value": rows / t_all, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_syms} symbols x {T} days, same suite+backtest, oracle (scalar C restatement, gcc -O2, OpenMP over symbols)",
+            "value_1thread": small["close"].shape[0] * T / t_one}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--symbols", type=int, default=N_SYM, help="symbols per GPU (weak scaling)")
+    ap.add_argument("--days", type=int, default=T_DAYS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from polars_quant_amd.suite import Suite
+    n_local, T = args.symbols, args.days
+    ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
+    suite = Suite(n_local, T, dev)
+    gathered = torch.empty((world * n_local, 8), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        suite.run(ohlcv)
+        if world > 1:   # the one exchange of the path: per-symbol summary rows to every rank (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, suite.summary)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel: per-task device time with events on the launch stream ----
+    per_task = {}
+    for name in suite.tasks():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        suite.run_one(name, ohlcv)
+        e0.record()
+        for _ in range(reps):
+            suite.run_one(name, ohlcv)
+        e1.record()
+        e1.synchronize()
+        per_task[name] = e0.elapsed_time(e1) / reps  # ms
+    dom = max(per_task, key=per_task.get)
+    rows_local = n_local * T
+    alg_bytes = suite.bytes_per_row[dom] * rows_local
+    achieved = alg_bytes / (per_task[dom] * 1e-3) / 1e9
+    suite_bytes = suite.suite_bytes_per_row() * rows_local
+    suite_gbs = suite_bytes / (elapsed / args.steps) / 1e9
+
+    if rank == 0:
+        rows_total = world * rows_local * args.steps
+        line = {
+            "metric": "indicator+backtest rows/sec, 5000 sym x 2520 day f64 OHLCV",
+            "value": rows_total / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
+                                   f"recognisers) + fused MACD-cross backtest with summary, {n_local} symbols x {T} days "
+                                   "f64 OHLCV per GPU, inputs resident in HBM",
+                       "symbols_per_gpu": n_local, "days": T, "parallelism": f"symbol-sharded x{world}",
+                       "algorithmic_bytes_per_row": suite.suite_bytes_per_row(),
+                       "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_task[dom]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(1024, T)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

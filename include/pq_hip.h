@@ -211,6 +211,21 @@ pq_status pq_backtest_macd_cross(pq_ctx *, const pq_batch *, const double *close
 pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close, int64_t fastperiod,
                                 int64_t slowperiod, int64_t signalperiod, uint8_t *buy, uint8_t *sell);
 
+/* ---- suites: record many calls, replay them as a few chip-filling grids ----
+ * One indicator over N symbols is only N/64 wavefronts -- far too few for 256 CUs -- but a DataFrame query asks
+ * for many indicators at once (df.with_columns([...]) in the reference; Polars then calls the plugin once per
+ * expression and group).  Between pq_suite_begin and pq_suite_end every pq_* compute call on `ctx` is RECORDED
+ * instead of launched (same batch shape for all; pointers must stay valid for the suite's lifetime);
+ * pq_suite_run replays the whole set: per dependency phase ONE grid runs all sequential jobs
+ * (blockIdx.y = job) and the row-parallel launches follow.  Results are bit-identical to the direct calls. */
+typedef struct pq_suite pq_suite;
+pq_status pq_suite_begin(pq_ctx *ctx, const pq_batch *b);
+pq_status pq_suite_end(pq_ctx *ctx, pq_suite **out);
+pq_status pq_suite_abort(pq_ctx *ctx);
+pq_status pq_suite_run(pq_ctx *ctx, pq_suite *suite);
+pq_status pq_suite_destroy(pq_ctx *ctx, pq_suite *suite);
+pq_status pq_suite_info(const pq_suite *suite, int32_t *n_phases, int32_t *n_seq_jobs, int32_t *n_row_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,9 +79,12 @@ def lib() -> C.CDLL:
         L.pq_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.pq_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.pq_device_count.argtypes = [C.POINTER(C.c_int32)]
-        for n in ("pq_suite_run", "pq_suite_n_f64", "pq_suite_n_i32"):
-            if hasattr(L, n):
-                getattr(L, n).restype = C.c_int32
+        L.pq_suite_begin.argtypes = [vp, C.POINTER(Batch)]
+        L.pq_suite_end.argtypes = [vp, C.POINTER(vp)]
+        L.pq_suite_abort.argtypes = [vp]
+        L.pq_suite_run.argtypes = [vp, vp]
+        L.pq_suite_destroy.argtypes = [vp, vp]
+        L.pq_suite_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 

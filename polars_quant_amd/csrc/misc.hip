@@ -1,217 +1,6 @@
 // misc.hip -- kernels + C ABI for volatility / volume / price transforms and the Hilbert-transform
 // cycle indicators (reference: src/talib/{volatility,volume,price,cycle}.rs) plus MAMA (D-4).
-#include "pq_cores.h"
-
-__device__ __forceinline__ double n0m(double x) { return pq_isnull(x) ? 0.0 : x; }
-
-// ---------------------------------------------------------------- price.rs (N-C, ROW)
-template <int KIND> // 0 avgprice(o,h,l,c) 1 medprice(h,l) 2 typprice(h,l,c) 3 wclprice(h,l,c)
-struct PriceOp {
-    static constexpr int NIN = (KIND == 0 ? 4 : (KIND == 1 ? 2 : 3)), NOUT = 1;
-    typedef double OutT;
-    __device__ void eval(const Row<NIN> &r, int64_t t, double (&y)[1]) {
-        double a[NIN];
-        bool nul = false;
-#pragma unroll
-        for (int k = 0; k < NIN; k++) { a[k] = r.in[k][t]; nul |= pq_isnull(a[k]); }
-        if (nul) { y[0] = pq_null(); return; }
-        if (KIND == 0) y[0] = (a[0] + a[1] + a[2] + a[NIN - 1]) * 0.25;      // price.rs:25
-        else if (KIND == 1) y[0] = (a[0] + a[1]) * 0.5;                        // price.rs:44
-        else if (KIND == 2) y[0] = (a[0] + a[1] + a[NIN - 1]) / 3.0;          // price.rs:65
-        else y[0] = (a[0] + a[1] + 2.0 * a[NIN - 1]) / 4.0;                   // price.rs:86
-    }
-};
-
-// ---------------------------------------------------------------- volatility.rs
-__device__ __forceinline__ double true_range(double h, double l, double pc) { // volatility.rs:77
-    return fmax(fmax(h - l, fabs(h - pc)), fabs(l - pc));
-}
-struct TrangeOp { // volatility.rs:67-84 (ROW; row 0 null because pre_close = close.shift(1))
-    static constexpr int NIN = 3, NOUT = 1;
-    typedef double OutT;
-    __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {
-        y[0] = pq_null();
-        if (t == 0) return;
-        double h = r.in[0][t], l = r.in[1][t], pc = r.in[2][t - 1];
-        if (pq_isnull(h) || pq_isnull(l) || pq_isnull(pc)) return;
-        y[0] = true_range(h, l, pc);
-    }
-};
-template <bool NATR> // volatility.rs:18-31 / :34-48: calc_ema(trange, 2p-1) [/ close * 100]
-struct AtrOp {
-    static constexpr int NIN = 3, NOUT = 1;
-    int64_t p;
-    EmaCore e;
-    double pc;
-    __device__ void init(const Row<3> &r) { e.init(2 * p - 1, r.len); pc = pq_null(); }
-    __device__ void step(const Row<3> &, int64_t t, const double (&x)[3], double (&y)[1]) {
-        double tr = pq_null();
-        if (t > 0 && !pq_isnull(x[0]) && !pq_isnull(x[1]) && !pq_isnull(pc)) tr = true_range(x[0], x[1], pc);
-        pc = x[2];
-        double a = e.step(tr);
-        if (NATR) y[0] = (pq_isnull(a) || pq_isnull(x[2])) ? pq_null() : a / x[2] * 100.0;
-        else y[0] = a;
-    }
-};
-
-// ---------------------------------------------------------------- volume.rs
-template <bool OSC> // volume.rs:100-126 calc_ad (quirk Q-AD); OSC: volume.rs:34-67 (quirk Q-ADOSC)
-struct AdOp {
-    static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume
-    int64_t fast, slow;
-    double sum, sum2;
-    EmaCore ef, es;
-    __device__ void init(const Row<4> &r) { sum = 0.0; sum2 = 0.0; if (OSC) { ef.init(fast, r.len); es.init(slow, r.len); } }
-    __device__ void step(const Row<4> &, int64_t, const double (&x)[4], double (&y)[1]) {
-        double ad;
-        if (pq_isnull(x[0]) || pq_isnull(x[1]) || pq_isnull(x[2]) || pq_isnull(x[3])) ad = pq_null();
-        else {
-            double diff = x[0] - x[1];
-            if (diff == 0.0) ad = 0.0;
-            else { sum += (2.0 * x[2] - x[1] - x[0]) / diff * x[3]; ad = sum; }
-        }
-        if (!OSC) { y[0] = ad; return; }
-        double adl = pq_null();
-        if (!pq_isnull(ad)) { sum2 += ad; adl = sum2; }
-        double f = ef.step(adl), s = es.step(adl);
-        y[0] = (pq_isnull(f) || pq_isnull(s)) ? pq_null() : f - s;
-    }
-};
-struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
-    static constexpr int NIN = 2, NOUT = 1; // close, volume
-    double sum, pc;
-    __device__ void init(const Row<2> &) { sum = 0.0; pc = pq_null(); }
-    __device__ void step(const Row<2> &, int64_t t, const double (&x)[2], double (&y)[1]) {
-        double prev = pc;
-        pc = x[0];
-        if (t == 0 || pq_isnull(x[0]) || pq_isnull(prev) || pq_isnull(x[1])) { y[0] = pq_null(); return; }
-        double c_diff = prev - x[0];
-        if (c_diff > 0.0) sum += x[1];
-        else if (c_diff < 0.0) sum -= x[1];
-        y[0] = sum;
-    }
-};
-
-// ---------------------------------------------------------------- cycle.rs
-// Shared pipeline cycle.rs:27-63; MODE selects the emitted columns:
-//   0 ht_dcperiod  1 ht_dcphase  2 ht_phasor(2)  3 ht_sine(2)  4 mama(2, decision D-4)
-#define PQ_PI 3.14159265358979323846
-#define PQ_TAU 6.28318530717958647692
-template <int MODE>
-struct HtOp {
-    static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
-    double fastlimit, slowlimit; // MODE 4
-    double rl[4];                // real[i], real[i-1], real[i-2], real[i-3]
-    double sm[7];                // smooth[i] ... smooth[i-6]
-    double detrend[7], q1[7], i1[7];
-    double i2, q2, re, im, period, smooth_period;
-    double mama, fama, prev_phase;
-    bool dead;
-    __device__ static void push7(double (&dq)[7], double v) {
-#pragma unroll
-        for (int k = 6; k >= 1; k--) dq[k] = dq[k - 1];
-        dq[0] = v;
-    }
-    __device__ void init(const Row<1> &r) {
-        dead = r.len < 32; // cycle.rs:16
-#pragma unroll
-        for (int k = 0; k < 7; k++) sm[k] = detrend[k] = q1[k] = i1[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) rl[k] = 0.0;
-        i2 = q2 = re = im = period = smooth_period = 0.0;
-        mama = fama = prev_phase = 0.0;
-    }
-    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[NOUT]) {
-#pragma unroll
-        for (int k = 0; k < NOUT; k++) y[k] = pq_null();
-        if (dead) return;
-        double v = (MODE == 4) ? n0m(x[0]) : x[0];
-        rl[3] = rl[2]; rl[2] = rl[1]; rl[1] = rl[0]; rl[0] = v;
-        // cycle.rs:462-470 calc_smooth (0 for i < 3)
-        double s = (i >= 3) ? (4.0 * rl[0] + 3.0 * rl[1] + 2.0 * rl[2] + rl[3]) * 0.1 : 0.0;
-        push7(sm, s);
-        if (i < 6) return;
-        double prev_period = (i > 6) ? period : 6.0;
-        double adj = 0.075 * prev_period + 0.54;
-        double detrend_curr = (0.0962 * sm[0] + 0.5769 * sm[2] - 0.5769 * sm[4] - 0.0962 * sm[6]) * adj;
-        push7(detrend, detrend_curr);
-        double q1_curr = (0.0962 * detrend[0] + 0.5769 * detrend[2] - 0.5769 * detrend[4] - 0.0962 * detrend[6]) * adj;
-        push7(q1, q1_curr);
-        push7(i1, detrend[3]);
-        double ji = (0.0962 * i1[0] + 0.5769 * i1[2] - 0.5769 * i1[4] - 0.0962 * i1[6]) * adj;
-        double jq = (0.0962 * q1[0] + 0.5769 * q1[2] - 0.5769 * q1[4] - 0.0962 * q1[6]) * adj;
-        double i2_curr = 0.2 * (i1[0] - jq) + 0.8 * i2;
-        double q2_curr = 0.2 * (q1[0] + ji) + 0.8 * q2;
-        double re_curr = 0.2 * (i2_curr * i2 + q2_curr * q2) + 0.8 * re;
-        double im_curr = 0.2 * (i2_curr * q2 - q2_curr * i2) + 0.8 * im;
-        i2 = i2_curr; q2 = q2_curr; re = re_curr; im = im_curr;
-        if (im != 0.0 && re != 0.0) period = PQ_TAU / atan(im / re);
-        double lo = 0.67 * prev_period, hi = 1.5 * prev_period; // f64::clamp twice (cycle.rs:60-62)
-        if (period < lo) period = lo;
-        if (period > hi) period = hi;
-        if (period < 6.0) period = 6.0;
-        if (period > 50.0) period = 50.0;
-        period = 0.2 * period + 0.8 * prev_period;
-        if (MODE == 0) {
-            smooth_period = 0.33 * period + 0.67 * smooth_period;
-            if (i >= 31) y[0] = smooth_period;
-        } else if (MODE == 1) {
-            if (i >= 31) {
-                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
-                dc_phase += 90.0;
-                if (i1[0] < 0.0) dc_phase += 180.0;
-                if (dc_phase > 315.0) dc_phase -= 360.0;
-                y[0] = dc_phase;
-            }
-        } else if (MODE == 2) {
-            if (i >= 31) { y[0] = i1[0]; y[NOUT - 1] = q1[0]; }
-        } else if (MODE == 3) {
-            if (i >= 31) {
-                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
-                y[0] = sin(dc_phase * PQ_PI / 180.0);
-                y[NOUT - 1] = sin((dc_phase + 45.0) * PQ_PI / 180.0);
-            }
-        } else {
-            double phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
-            double dphase = prev_phase - phase;
-            if (dphase < 1.0) dphase = 1.0;
-            double alpha = fastlimit / dphase;
-            if (alpha < slowlimit) alpha = slowlimit;
-            if (alpha > fastlimit) alpha = fastlimit;
-            mama = alpha * v + (1.0 - alpha) * mama;
-            double ha = 0.5 * alpha;
-            fama = ha * mama + (1.0 - ha) * fama;
-            prev_phase = phase;
-            if (i >= 31) { y[0] = mama; y[NOUT - 1] = fama; }
-        }
-    }
-};
-// cycle.rs:310-374 / :377-448: pure functions of real[i-3..i] (the pipeline result is unused)
-struct TrendlineOp {
-    static constexpr int NIN = 1, NOUT = 1;
-    typedef double OutT;
-    __device__ void eval(const Row<1> &r, int64_t i, double (&y)[1]) {
-        y[0] = pq_null();
-        if (r.len < 32 || i < 31) return;
-        double tl = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) tl += r.in[0][i - j];
-        y[0] = tl * 0.25;
-    }
-};
-struct TrendmodeOp {
-    static constexpr int NIN = 1, NOUT = 1;
-    typedef int32_t OutT;
-    __device__ void eval(const Row<1> &r, int64_t i, int32_t (&y)[1]) {
-        y[0] = PQ_NULL_I32;
-        if (r.len < 32 || i < 31) return;
-        double tl = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) tl += r.in[0][i - j];
-        tl *= 0.25;
-        y[0] = (fabs(r.in[0][i] - tl) > 0.01 * tl) ? 1 : 0;
-    }
-};
+#include "ops_misc.h"
 
 // ---------------------------------------------------------------- C ABI
 #define CHK(name, cond) PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(cond, name ": null pointer")

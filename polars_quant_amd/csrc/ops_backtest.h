@@ -1,0 +1,158 @@
+// ops_backtest.h -- per-symbol backtest scan + summary (device body shared by backtest.hip and the suite job grid)
+#pragma once
+#include "pq_cores.h"
+
+__device__ __forceinline__ double z0b(double x) { return pq_isnull(x) ? 0.0 : x; }
+
+struct BtArgs {
+    const double *price;
+    const uint8_t *buy, *sell; // nullptr when MACD signals are generated in-kernel
+    const double *bench;       // nullable
+    double *position, *cash;   // nullable
+    double *equity;            // always present (user buffer or workspace)
+    double *summary;           // [n][8], nullable
+    uint8_t *buy_out, *sell_out; // signals-only mode
+    pq_bt_params prm;
+    int64_t fast, slow, sig;
+};
+
+template <bool MACD_SIGNALS, bool SIGNALS_ONLY>
+__device__ __forceinline__ void backtest_body(const BtArgs &a, const Dims &d, int64_t s) {
+    const int64_t base = s * d.stride, T = d.len;
+    const double *price = a.price + base;
+    const pq_bt_params prm = a.prm;
+
+    EmaCore ef, es, eg;
+    double prev_m = pq_null(), prev_s = pq_null();
+    if (MACD_SIGNALS) { ef.init(a.fast, T); es.init(a.slow, T); eg.init(a.sig, T); }
+
+    double pos = 0.0, avail = prm.initial_capital, peak = prm.initial_capital, entry_cost = 0.0;
+    int64_t trades = 0, wins = 0;
+    // summary pass 1 state (metrics.rs:21-49)
+    double max_dd = 0.0, max_eq = prm.initial_capital, prev_eq = prm.initial_capital, ret_sum = 0.0;
+    double last_eq = prm.initial_capital;
+
+    for (int64_t i = 0; i < T; i++) {
+        double px = price[i];
+        bool buy, sell;
+        if (MACD_SIGNALS) { // momentum.rs:250-283 + D-8 cross rule
+            double f = ef.step(px), sl = es.step(px);
+            double m = (!pq_isnull(f) && !pq_isnull(sl)) ? f - sl : pq_null();
+            double g = eg.step(z0b(m));
+            bool ok = i > 0 && !pq_isnull(m) && !pq_isnull(g) && !pq_isnull(prev_m) && !pq_isnull(prev_s);
+            buy = ok && (prev_m <= prev_s) && (m > g);
+            sell = ok && (prev_m >= prev_s) && (m < g);
+            prev_m = m; prev_s = g;
+            if (SIGNALS_ONLY) { a.buy_out[base + i] = buy; a.sell_out[base + i] = sell; continue; }
+        } else {
+            buy = a.buy[base + i] != 0;
+            sell = a.sell[base + i] != 0;
+        }
+        double eq;
+        if (pq_isnull(px)) px = __longlong_as_double(0x7FF8000000000000LL); // null -> NaN (vectorized.rs:70-78)
+        if (isnan(px) || px <= 0.0) { // vectorized.rs:141-144: state untouched
+            eq = avail + pos * px;
+        } else {
+            if (buy && pos == 0.0) { // :146-161
+                double exec = px + prm.buy_slippage;
+                double cur_eq = avail + pos * px;
+                double deploy = cur_eq * prm.position_size;
+                double qty = floor(deploy / exec);
+                if (qty > 0.0) {
+                    double cost = qty * exec;
+                    double fee = fmax(cost * prm.buy_commission_rate, prm.min_commission);
+                    pos += qty;
+                    avail -= cost + fee;
+                    entry_cost = pos * px;
+                    trades += 1;
+                }
+            } else if (sell && pos > 0.0) { // :162-175
+                double exec = px - prm.sell_slippage;
+                double revenue = pos * exec;
+                double fee = fmax(revenue * prm.sell_commission_rate, prm.min_commission);
+                double net = revenue - fee;
+                if (net > entry_cost) wins += 1;
+                avail += net;
+                pos = 0.0;
+            }
+            eq = avail + pos * px;
+            if (eq > peak) peak = eq;
+        }
+        if (a.position) a.position[base + i] = pos;
+        if (a.cash) a.cash[base + i] = avail;
+        a.equity[base + i] = eq;
+        // metrics.rs:26-49
+        if (eq > max_eq) max_eq = eq;
+        double dd = (max_eq > 0.0) ? (max_eq - eq) / max_eq : 0.0;
+        if (dd > max_dd) max_dd = dd;
+        double r = (prev_eq > 0.0) ? (eq - prev_eq) / prev_eq : 0.0;
+        ret_sum += r;
+        prev_eq = eq;
+        last_eq = eq;
+    }
+    if (SIGNALS_ONLY || a.summary == nullptr) return;
+    double *sm = a.summary + s * PQ_SUMMARY_COLS;
+    if (T == 0) { for (int k = 0; k < 8; k++) sm[k] = 0.0; return; }
+    const double DAYS = 252.0, RF = 0.03;
+    double total_return = (last_eq - prm.initial_capital) / prm.initial_capital;
+    double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
+    double mean = ret_sum / (double)T;
+    double dof = fmax((double)T - 1.0, 1.0);
+    // pass 2: variance of daily returns, recomputed from the lane's own equity rows
+    const double *eqr = a.equity + base;
+    double vs = 0.0, pe = prm.initial_capital;
+    for (int64_t i = 0; i < T; i++) {
+        double e = eqr[i];
+        double r = (pe > 0.0) ? (e - pe) / pe : 0.0;
+        double dlt = r - mean;
+        vs += dlt * dlt;
+        pe = e;
+    }
+    double var = vs / dof;
+    double vol = sqrt(var) * sqrt(DAYS);
+    double sharpe = (vol > 0.0) ? (ann - RF) / vol : 0.0;
+    double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
+    double alpha = 0.0, beta = 0.0;
+    if (a.bench) { // metrics.rs:86-140
+        const double *bm = a.bench + base;
+        double pb = bm[0], bs = 0.0;
+        for (int64_t i = 0; i < T; i++) { double bv = bm[i]; bs += (pb > 0.0) ? (bv - pb) / pb : 0.0; pb = bv; }
+        double bmean = bs / (double)T;
+        double bvar = 0.0, cov = 0.0;
+        pb = bm[0];
+        for (int64_t i = 0; i < T; i++) {
+            double bv = bm[i];
+            double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
+            double dlt = br - bmean;
+            bvar += dlt * dlt;
+            pb = bv;
+        }
+        bvar /= dof;
+        pb = bm[0]; pe = prm.initial_capital;
+        for (int64_t i = 0; i < T; i++) {
+            double bv = bm[i], e = eqr[i];
+            double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
+            double r = (pe > 0.0) ? (e - pe) / pe : 0.0;
+            cov += (r - mean) * (br - bmean);
+            pb = bv; pe = e;
+        }
+        cov /= dof;
+        if (bvar > 0.0) beta = cov / bvar;
+        double b0 = bm[0], b1 = bm[T - 1];
+        double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;
+        double bann = (btr > -1.0) ? pow(1.0 + btr, DAYS / (double)T) - 1.0 : -1.0;
+        alpha = ann - (RF + beta * (bann - RF));
+    }
+    sm[0] = ann; sm[1] = max_dd; sm[2] = alpha; sm[3] = beta; sm[4] = sharpe;
+    sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
+}
+
+
+template <bool MACD_SIGNALS, bool SIGNALS_ONLY>
+__global__ __launch_bounds__(SEQ_BLOCK) void backtest_kernel(BtArgs a, Dims d) {
+    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (s >= d.n) return;
+    backtest_body<MACD_SIGNALS, SIGNALS_ONLY>(a, d, s);
+}
+constexpr int SEQ_ID_BACKTEST = 60; // + (MACD_SIGNALS ? 1 : 0)
+pq_status rec_add_backtest(pq_ctx *ctx, const pq_batch *b, int kind, const BtArgs &a);

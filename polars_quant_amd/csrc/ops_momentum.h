@@ -1,0 +1,349 @@
+// momentum.hip -- kernels + C ABI for the momentum indicators (reference: src/talib/momentum.rs and
+// the pure-Python composites of python/polars_quant/talib/momentum.py).
+// momentum.rs functions are N-B (nulls rejected, momentum.rs:12-13): inputs are assumed null-free
+// here; the host layer calls pq_count_nulls first and raises like the reference does.
+#pragma once
+#include "pq_cores.h"
+
+__device__ __forceinline__ double z0(double x) { return pq_isnull(x) ? 0.0 : x; } // .unwrap_or(0.0)
+#define F64_MAX 1.7976931348623157e308
+
+// ---------------------------------------------------------------- ROW ops (exact, order-free)
+template <int KIND> // 0 mom, 1 roc, 2 rocp, 3 rocr, 4 rocr100   (momentum.rs:384-397, :439-504)
+struct LagOp {
+    static constexpr int NIN = 1, NOUT = 1;
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p < 0 || t < p) return;
+        double c = r.in[0][t], pr = r.in[0][t - p];
+        if (KIND == 0) { y[0] = c - pr; return; }
+        if (pr == 0.0) return;
+        if (KIND == 1) y[0] = (c - pr) / pr * 100.0;
+        else if (KIND == 2) y[0] = (c - pr) / pr;
+        else if (KIND == 3) y[0] = c / pr;
+        else y[0] = (c / pr) * 100.0;
+    }
+};
+struct BopOp { // momentum.rs:113-135
+    static constexpr int NIN = 4, NOUT = 1;
+    typedef double OutT;
+    __device__ void eval(const Row<4> &r, int64_t t, double (&y)[1]) {
+        double diff = r.in[1][t] - r.in[2][t];
+        y[0] = (diff == 0.0) ? 0.0 : (r.in[3][t] - r.in[0][t]) / diff;
+    }
+};
+template <int MODE> // 0: (up, down)  1: up - down (AROONOSC, decision D-6)   momentum.rs:70-110
+struct AroonOp {
+    static constexpr int NIN = 2, NOUT = (MODE == 0 ? 2 : 1);
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<2> &r, int64_t t, double (&y)[NOUT]) {
+#pragma unroll
+        for (int k = 0; k < NOUT; k++) y[k] = pq_null();
+        if (p < 0 || t < p) return;
+        int64_t start = t - p, max_idx = 0, min_idx = 0;
+        double max_val = -F64_MAX, min_val = F64_MAX;
+        for (int64_t j = start; j <= t; j++) {
+            double h = r.in[0][j], l = r.in[1][j];
+            if (h >= max_val) { max_val = h; max_idx = j - start; }
+            if (l <= min_val) { min_val = l; min_idx = j - start; }
+        }
+        double up = ((double)max_idx / (double)p) * 100.0, dn = ((double)min_idx / (double)p) * 100.0;
+        if (MODE == 0) { y[0] = up; y[NOUT - 1] = dn; } else y[0] = up - dn;
+    }
+};
+struct WillrOp { // momentum.rs:630-662
+    static constexpr int NIN = 3, NOUT = 1;
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0 || t < p - 1) return;
+        double max_h = -F64_MAX, min_l = F64_MAX;
+        for (int64_t j = t + 1 - p; j <= t; j++) { max_h = fmax(max_h, r.in[0][j]); min_l = fmin(min_l, r.in[1][j]); }
+        double diff = max_h - min_l;
+        y[0] = (diff == 0.0) ? 0.0 : -100.0 * (max_h - r.in[2][t]) / diff;
+    }
+};
+struct CciDevOp { // momentum.rs:161-176: mean-abs-deviation pass given sma(tp)
+    static constexpr int NIN = 4, NOUT = 1; // high, low, close, sma_tp
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<4> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0 || t < p - 1) return;
+        double avg = r.in[3][t];
+        if (pq_isnull(avg)) return;
+        double mean_dev = 0.0;
+        for (int64_t j = t + 1 - p; j <= t; j++) {
+            double tp = (r.in[0][j] + r.in[1][j] + r.in[2][j]) / 3.0;
+            mean_dev += fabs(tp - avg);
+        }
+        if (mean_dev != 0.0) {
+            mean_dev /= (double)p;
+            double tp = (r.in[0][t] + r.in[1][t] + r.in[2][t]) / 3.0;
+            y[0] = (tp - avg) / (0.015 * mean_dev);
+        }
+    }
+};
+struct AdxrOp { // momentum.rs:50-59
+    static constexpr int NIN = 1, NOUT = 1;
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0 || t < p - 1) return;
+        double curr = r.in[0][t], prev = r.in[0][t - (p - 1)];
+        if (!pq_isnull(curr) && !pq_isnull(prev)) y[0] = (curr + prev) * 0.5;
+    }
+};
+// Polars rolling_min/max(window) + fastk (momentum.py:181-183): null until the frame holds `k` non-null rows
+struct FastkOp {
+    static constexpr int NIN = 3, NOUT = 1; // high, low, close
+    typedef double OutT;
+    int64_t k;
+    __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (k <= 0 || t < k - 1) return;
+        double c = r.in[2][t];
+        if (pq_isnull(c)) return;
+        double hn = r.in[0][t], ln = r.in[1][t];
+        for (int64_t j = t + 1 - k; j <= t; j++) {
+            double h = r.in[0][j], l = r.in[1][j];
+            if (pq_isnull(h) || pq_isnull(l)) return;
+            hn = h > hn ? h : hn;
+            ln = l < ln ? l : ln;
+        }
+        y[0] = (c - ln) * 100.0 / (hn - ln);
+    }
+};
+template <int KIND> // 0: a-b   1: (a-b)/b*100 (null if b == 0)   -- null if either side null
+struct BinOp {
+    static constexpr int NIN = 2, NOUT = 1;
+    typedef double OutT;
+    __device__ void eval(const Row<2> &r, int64_t t, double (&y)[1]) {
+        double a = r.in[0][t], b = r.in[1][t];
+        if (pq_isnull(a) || pq_isnull(b)) { y[0] = pq_null(); return; }
+        if (KIND == 0) y[0] = a - b;
+        else y[0] = (b == 0.0) ? pq_null() : (a - b) / b * 100.0;
+    }
+};
+
+// ---------------------------------------------------------------- SEQ ops
+struct CmoOp { // momentum.rs:181-223: rolling SUMS of up/down moves; the lagged terms are recomputed
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 20;
+    int64_t p;
+    double su, sd, prev;
+    __device__ void init(const Row<1> &) { su = sd = 0.0; prev = 0.0; }
+    __device__ static void updown(double curr, double prv, double &u, double &d) {
+        double diff = curr - prv;
+        u = 0.0; d = 0.0;
+        if (diff > 0.0) u = diff; else d = -diff;
+    }
+    __device__ void step(const Row<1> &r, int64_t i, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0) return;
+        double u = 0.0, d = 0.0;
+        if (i >= 1) updown(x[0], prev, u, d);
+        prev = x[0];
+        su += u; sd += d;
+        if (i >= p) {
+            double ou = 0.0, od = 0.0;
+            if (i - p >= 1) updown(r.in[0][i - p], r.in[0][i - p - 1], ou, od);
+            su -= ou; sd -= od;
+        }
+        if (i >= p - 1) {
+            double total = su + sd;
+            y[0] = (total == 0.0) ? 0.0 : 100.0 * (su - sd) / total;
+        }
+    }
+};
+
+struct RsiOp { // momentum.rs:507-541
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 21;
+    int64_t p;
+    RmaCore au, ad;
+    double prev;
+    __device__ void init(const Row<1> &r) { au.init(p, r.len); ad.init(p, r.len); prev = 0.0; }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[1]) {
+        double u = 0.0, d = 0.0;
+        if (i >= 1) CmoOp::updown(x[0], prev, u, d);
+        prev = x[0];
+        double a = au.step(i, u), b = ad.step(i, d);
+        if (pq_isnull(a) || pq_isnull(b)) { y[0] = pq_null(); return; }
+        if (b == 0.0) y[0] = 100.0;
+        else { double rs = a / b; y[0] = 100.0 - (100.0 / (1.0 + rs)); }
+    }
+};
+
+struct MacdOp { // momentum.rs:250-283 (quirk Q-MACD: signal = EMA(dif with None -> 0.0))
+    static constexpr int NIN = 1, NOUT = 3;
+    static constexpr int SEQ_ID = 22;
+    int64_t fast, slow, sig;
+    EmaCore ef, es, eg;
+    __device__ void init(const Row<1> &r) { ef.init(fast, r.len); es.init(slow, r.len); eg.init(sig, r.len); }
+    __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[3]) {
+        double f = ef.step(x[0]), s = es.step(x[0]);
+        double dif = (!pq_isnull(f) && !pq_isnull(s)) ? f - s : pq_null();
+        double dea = eg.step(z0(dif));
+        y[0] = dif; y[1] = dea;
+        y[2] = (!pq_isnull(dif) && !pq_isnull(dea)) ? dif - dea : pq_null();
+    }
+};
+
+struct TrixOp { // momentum.rs:544-569 (quirk Q-TRIX)
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 23;
+    int64_t p;
+    EmaCore e1, e2, e3;
+    double prev3;
+    __device__ void init(const Row<1> &r) { e1.init(p, r.len); e2.init(p, r.len); e3.init(p, r.len); prev3 = pq_null(); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[1]) {
+        double a = e1.step(x[0]);
+        double b = e2.step(z0(a));
+        double c = e3.step(z0(b));
+        y[0] = pq_null();
+        if (i >= 1 && !pq_isnull(c) && !pq_isnull(prev3) && prev3 != 0.0) y[0] = (c - prev3) / prev3 * 100.0;
+        prev3 = c;
+    }
+};
+
+struct UltoscOp { // momentum.rs:572-627
+    static constexpr int NIN = 3, NOUT = 1; // high, low, close
+    static constexpr int SEQ_ID = 24;
+    int64_t p1, p2, p3;
+    double sb[3], st[3], prev_c;
+    __device__ void init(const Row<3> &) { for (int k = 0; k < 3; k++) sb[k] = st[k] = 0.0; prev_c = 0.0; }
+    __device__ static void bptr(double h, double l, double c, double pc, double &bp, double &tr) {
+        double min_l_pc = fmin(l, pc), max_h_pc = fmax(h, pc);
+        bp = c - min_l_pc; tr = max_h_pc - min_l_pc;
+    }
+    __device__ void step(const Row<3> &r, int64_t i, const double (&x)[3], double (&y)[1]) {
+        y[0] = pq_null();
+        if (p1 <= 0 || p2 <= 0 || p3 <= 0) return;
+        double bp = 0.0, tr = 0.0;
+        if (i >= 1) bptr(x[0], x[1], x[2], prev_c, bp, tr);
+        prev_c = x[2];
+        const int64_t ps[3] = {p1, p2, p3};
+        double a[3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            sb[k] += bp; st[k] += tr;
+            int64_t p = ps[k];
+            if (i >= p) {
+                double obp = 0.0, otr = 0.0;
+                int64_t q = i - p;
+                if (q >= 1) bptr(r.in[0][q], r.in[1][q], r.in[2][q], r.in[2][q - 1], obp, otr);
+                sb[k] -= obp; st[k] -= otr;
+            }
+            if (i >= p - 1 && st[k] != 0.0) a[k] = sb[k] / st[k]; else ok = false;
+        }
+        if (ok) y[0] = 100.0 * (4.0 * a[0] + 2.0 * a[1] + a[2]) / 7.0;
+    }
+};
+
+struct MfiOp { // momentum.rs:286-342
+    static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume
+    static constexpr int SEQ_ID = 25;
+    int64_t p;
+    double pos, neg, prev_tp;
+    __device__ void init(const Row<4> &) { pos = neg = 0.0; prev_tp = 0.0; }
+    __device__ void step(const Row<4> &r, int64_t i, const double (&x)[4], double (&y)[1]) {
+        y[0] = pq_null();
+        double tp = (x[0] + x[1] + x[2]) / 3.0;
+        double mf = tp * x[3];
+        if (i >= 1) {
+            if (tp > prev_tp) pos += mf;
+            else if (tp < prev_tp) neg += mf;
+            if (i >= p) {
+                int64_t q = i - p;
+                if (q > 0) {
+                    double tq = (r.in[0][q] + r.in[1][q] + r.in[2][q]) / 3.0;
+                    double tq1 = (r.in[0][q - 1] + r.in[1][q - 1] + r.in[2][q - 1]) / 3.0;
+                    double mq = tq * r.in[3][q];
+                    if (tq > tq1) pos -= mq;
+                    else if (tq < tq1) neg -= mq;
+                }
+                if (neg == 0.0) y[0] = 100.0;
+                else { double mr = pos / neg; y[0] = 100.0 - (100.0 / (1.0 + mr)); }
+            }
+        }
+        prev_tp = tp;
+    }
+};
+
+// momentum.rs:668-727 calc_dm + its users.  MODE: 0 dx (also plus_di, quirk Q-PDI / D-5), 1 minus_di, 2 adx
+template <int MODE>
+struct DmOp {
+    static constexpr int NIN = 3, NOUT = 1; // high, low, close
+    static constexpr int SEQ_ID = 26 + MODE;
+    int64_t p;
+    RmaCore rp, rm, rt, radx;
+    double ph, pl, pc;
+    __device__ void init(const Row<3> &r) {
+        rp.init(p, r.len); rm.init(p, r.len); rt.init(p, r.len); radx.init(p, r.len);
+        ph = pl = pc = 0.0;
+    }
+    __device__ void step(const Row<3> &, int64_t i, const double (&x)[3], double (&y)[1]) {
+        double p_dm = 0.0, m_dm = 0.0, tr = 0.0;
+        if (i >= 1) {
+            double up_move = x[0] - ph, down_move = pl - x[1];
+            if (up_move > down_move && up_move > 0.0) p_dm = up_move;
+            if (down_move > up_move && down_move > 0.0) m_dm = down_move;
+            tr = fmax(fmax(x[0] - x[1], fabs(x[0] - pc)), fabs(x[1] - pc));
+        }
+        ph = x[0]; pl = x[1]; pc = x[2];
+        double sp = rp.step(i, p_dm), sm = rm.step(i, m_dm), st = rt.step(i, tr);
+        double pdi = pq_null(), mdi = pq_null(), dx = pq_null();
+        if (!pq_isnull(sp) && !pq_isnull(sm) && !pq_isnull(st) && st != 0.0) {
+            pdi = 100.0 * sp / st;
+            mdi = 100.0 * sm / st;
+            double diff = fabs(pdi - mdi), sum = pdi + mdi;
+            dx = (sum == 0.0) ? 0.0 : 100.0 * diff / sum;
+        }
+        if (MODE == 0) y[0] = dx;
+        else if (MODE == 1) y[0] = mdi;
+        else y[0] = radx.step(i, z0(dx)); // momentum.rs:21-27
+    }
+};
+template <bool PLUS> // momentum.rs:414-436 / :359-381
+struct DmRawOp {
+    static constexpr int NIN = 2, NOUT = 1; // high, low
+    static constexpr int SEQ_ID = 29 + (PLUS ? 0 : 1);
+    int64_t p;
+    RmaCore rr;
+    double ph, pl;
+    __device__ void init(const Row<2> &r) { rr.init(p, r.len); ph = pl = 0.0; }
+    __device__ void step(const Row<2> &, int64_t i, const double (&x)[2], double (&y)[1]) {
+        double d = 0.0;
+        if (i >= 1) {
+            double up_move = x[0] - ph, down_move = pl - x[1];
+            if (PLUS) { if (up_move > down_move && up_move > 0.0) d = up_move; }
+            else { if (down_move > up_move && down_move > 0.0) d = down_move; }
+        }
+        ph = x[0]; pl = x[1];
+        y[0] = rr.step(i, d);
+    }
+};
+struct SmaTpOp { // momentum.rs:148-158: calc_sma(tp) on a null-free slice; the lagged tp is recomputed
+    static constexpr int NIN = 3, NOUT = 1;
+    static constexpr int SEQ_ID = 31;
+    int64_t p;
+    double sum, denom;
+    bool dead;
+    __device__ void init(const Row<3> &r) { dead = (p <= 0 || r.len < p); sum = 0.0; denom = 1.0 / (double)p; }
+    __device__ void step(const Row<3> &r, int64_t i, const double (&x)[3], double (&y)[1]) {
+        y[0] = pq_null();
+        if (dead) return;
+        sum += (x[0] + x[1] + x[2]) / 3.0;
+        if (i < p - 1) return;
+        if (i >= p) { int64_t q = i - p; sum -= (r.in[0][q] + r.in[1][q] + r.in[2][q]) / 3.0; }
+        y[0] = sum * denom;
+    }
+};
+

@@ -1,0 +1,393 @@
+// overlap.hip -- SEQ kernels + C ABI for the overlap studies (reference: src/talib/overlap.rs).
+// One series per lane, reference operation order, null-transparent streaming (N-A).
+#pragma once
+#include "pq_cores.h"
+
+// ---------------------------------------------------------------- functors
+struct SmaOp { // overlap.rs:871-937
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 1;
+    int64_t p;
+    SmaCore c;
+    __device__ void init(const Row<1> &r) { c.init(p, r.len); }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) { y[0] = c.step(r.in[0], t, x[0]); }
+};
+
+struct EmaOp { // overlap.rs:660-730
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 2;
+    int64_t p;
+    EmaCore c;
+    __device__ void init(const Row<1> &r) { c.init(p, r.len); }
+    __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.step(x[0]); }
+};
+
+struct BbandsOp { // overlap.rs:47-116
+    static constexpr int NIN = 1, NOUT = 3;
+    static constexpr int SEQ_ID = 3;
+    int64_t p;
+    double up, dn;
+    int64_t count;
+    double sum, sum_sq;
+    bool dead, started;
+    ValidCursor tail;
+    __device__ void init(const Row<1> &r) {
+        dead = (p <= 0 || r.len < p);
+        count = 0; sum = 0.0; sum_sq = 0.0; started = false;
+    }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[3]) {
+        y[0] = y[1] = y[2] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        if (!started) { tail.start(t); started = true; }
+        count += 1; sum += v; sum_sq += v * v;
+        if (count < p) return;
+        if (count > p) {
+            double old = tail.pop(r.in[0]);
+            sum -= old; sum_sq -= old * old; count -= 1;
+        }
+        double mean = sum / (double)p;
+        double variance = (sum_sq / (double)p) - mean * mean;
+        double sd = sqrt(fmax(variance, 0.0));
+        y[0] = mean + up * sd; y[1] = mean; y[2] = mean - dn * sd;
+    }
+};
+
+struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 4;
+    int64_t p, count;
+    double alpha, e0, e1, s0, s1;
+    bool dead;
+    __device__ void init(const Row<1> &r) {
+        dead = (p <= 0 || r.len < 2 * p - 1);
+        alpha = 2.0 / ((double)p + 1.0);
+        count = 0; e0 = e1 = s0 = s1 = 0.0;
+    }
+    __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        count += 1;
+        if (count < p) { s0 += v; }
+        else if (count == p) { s0 += v; e0 = s0 / (double)p; s1 = e0; }
+        else if (count < 2 * p - 1) { e0 = fma(alpha, v - e0, e0); s1 += e0; }
+        else if (count == 2 * p - 1) { e0 = fma(alpha, v - e0, e0); s1 += e0; e1 = s1 / (double)p; }
+        else {
+            e0 = fma(alpha, v - e0, e0);
+            e1 = fma(alpha, e0 - e1, e1);
+            y[0] = 2.0 * e0 - e1;
+        }
+    }
+};
+
+struct TemaOp { // overlap.rs:1177-1311
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 5;
+    int64_t p, count;
+    double alpha, e0, e1, e2, s0, s1, s2;
+    bool dead;
+    __device__ void init(const Row<1> &r) {
+        dead = (p <= 0 || r.len < 3 * p - 2);
+        alpha = 2.0 / ((double)p + 1.0);
+        count = 0; e0 = e1 = e2 = s0 = s1 = s2 = 0.0;
+    }
+    __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        count += 1;
+        if (count < p) { s0 += v; return; }
+        if (count == p) { s0 += v; e0 = s0 / (double)p; s1 = e0; return; }
+        e0 = fma(alpha, v - e0, e0);
+        if (count < 2 * p - 1) { s1 += e0; return; }
+        if (count == 2 * p - 1) { s1 += e0; e1 = s1 / (double)p; s2 = e1; return; }
+        e1 = fma(alpha, e0 - e1, e1);
+        if (count < 3 * p - 2) { s2 += e1; return; }
+        if (count == 3 * p - 2) { s2 += e1; e2 = s2 / (double)p; }
+        else e2 = fma(alpha, e1 - e2, e2);
+        y[0] = 3.0 * e0 - 3.0 * e1 + e2;
+    }
+};
+
+struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e5 never seeded)
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 6;
+    int64_t p, count;
+    double alpha, c1, c2, c3, c4;
+    double e0, e1, e2, e3, e4, e5, s0, s1, s2, s3, s4, s5;
+    bool dead;
+    __device__ void init(const Row<1> &r) {
+        dead = (p <= 0 || r.len < 6 * p - 5);
+        alpha = 2.0 / ((double)p + 1.0);
+        count = 0;
+        e0 = e1 = e2 = e3 = e4 = e5 = s0 = s1 = s2 = s3 = s4 = s5 = 0.0;
+    }
+    __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        count += 1;
+        if (count < p) { s0 += v; return; }
+        if (count == p) { s0 += v; e0 = s0 / (double)p; s1 = e0; return; }
+        e0 = fma(alpha, v - e0, e0);
+        if (count < 2 * p - 1) { s1 += e0; return; }
+        if (count == 2 * p - 1) { s1 += e0; e1 = s1 / (double)p; s2 = e1; return; }
+        e1 = fma(alpha, e0 - e1, e1);
+        if (count < 3 * p - 2) { s2 += e1; return; }
+        if (count == 3 * p - 2) { s2 += e1; e2 = s2 / (double)p; s3 = e2; return; }
+        e2 = fma(alpha, e1 - e2, e2);
+        if (count < 4 * p - 3) { s3 += e2; return; }
+        if (count == 4 * p - 3) { s3 += e2; e3 = s3 / (double)p; s4 = e3; return; }
+        e3 = fma(alpha, e2 - e3, e3);
+        if (count < 5 * p - 4) { s4 += e3; return; }
+        if (count == 5 * p - 4) { s4 += e3; e4 = s4 / (double)p; s5 = e4; return; }
+        e4 = fma(alpha, e3 - e4, e4);
+        if (count < 6 * p - 5) { s5 += e4; return; }
+        e5 = fma(alpha, e4 - e5, e5);
+        y[0] = fma(c1, e5, fma(c2, e4, fma(c3, e3, c4 * e2)));
+    }
+};
+
+struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 7;
+    int64_t p, count;
+    double denominator, numerator;
+    bool dead, started;
+    ValidCursor tail;
+    __device__ void init(const Row<1> &r) {
+        dead = (p <= 0 || r.len < p);
+        denominator = (double)(p * (p + 1) / 2);
+        numerator = 0.0; count = 0; started = false;
+    }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        if (!started) { tail.start(t); started = true; }
+        count += 1;
+        numerator += ((double)count) * v;
+        if (count < p) return;
+        if (count > p) {
+            double old = tail.pop(r.in[0]);
+            numerator -= ((double)p) * old;
+            count -= 1;
+        }
+        y[0] = numerator / denominator;
+    }
+};
+
+struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 8;
+    int64_t p;
+    int64_t count;    // pass-1 count (saturates at p)
+    int64_t j;        // number of valid values seen before the current one
+    double sum, x0;
+    int64_t c2;       // pass-2 count
+    double kama, sum2;
+    bool dead;
+    ValidCursor cur_a; // x[j-p]      : window.pop_front()
+    ValidCursor cur_b; // x[j-p+1]    : newer end of the popped diff
+    ValidCursor cur_c; // x[j-2p+1]   : older end of the popped diff (once that diff is a p-lag diff)
+    int64_t first_idx;
+    __device__ void init(const Row<1> &r) {
+        dead = (p <= 1 || r.len < p); // p == 1: the reference pops an empty VecDeque and aborts (:775)
+        count = 0; j = 0; sum = 0.0; x0 = 0.0; c2 = 0; kama = 0.0; sum2 = 0.0; first_idx = -1;
+    }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        const double *col = r.in[0];
+        double er;
+        if (count == 0) { // :760-764
+            count = 1; x0 = v; first_idx = t; j = 1;
+            cur_a.start(t); cur_c.start(t);
+            return;
+        }
+        if (j == 1) cur_b.start(t); // second valid value = index 1 of the compacted series
+        if (count < p) { // :765-772: diffs against window.front() == first valid value
+            count += 1;
+            sum += fabs(v - x0);
+            j += 1;
+            return;
+        }
+        // :773-779
+        double diff_abs = fabs(v - cur_a.pop(col));
+        // popped diff has compacted index k = j-p+1: |x_k - x_0| while k < p, else |x_k - x_{k-p}|
+        int64_t k = j - p + 1;
+        double xk = cur_b.pop(col);
+        double popped = (k < p) ? fabs(xk - x0) : fabs(xk - cur_c.pop(col));
+        sum += diff_abs - popped;
+        er = diff_abs / sum;
+        j += 1;
+        // pass 2 (:815-852)
+        double sc_sqrt = er * (2.0 / 3.0 - 2.0 / 31.0) + 2.0 / 31.0;
+        double sc = sc_sqrt * sc_sqrt;
+        if (c2 < p) { c2 += 1; sum2 += v; return; }
+        if (c2 == p) { c2 += 1; kama = sum2 / (double)p; y[0] = kama; return; }
+        kama = fma(sc, v - kama, kama);
+        y[0] = kama;
+    }
+};
+
+struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires => cumulative min)
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 9;
+    int64_t p;
+    RollExt<true> mx;
+    double mn;
+    bool any;
+    __device__ void init(const Row<1> &) { mx.init(p); mn = 0.0; any = false; }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
+        double v = x[0];
+        if (p <= 0 || pq_isnull(v)) { y[0] = pq_null(); return; } // p <= 0: decision D-7b
+        double m = mx.step(r.in[0], t, v);
+        if (!any || v <= mn) { mn = v; any = true; }
+        y[0] = (m + mn) / 2.0;
+    }
+};
+
+struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either input -> null (D-7)
+    static constexpr int NIN = 2, NOUT = 1;
+    static constexpr int SEQ_ID = 10;
+    int64_t p;
+    RollExt<true> mx;
+    RollExt<false> mn;
+    __device__ void init(const Row<2> &) { mx.init(p); mn.init(p); }
+    __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
+        double hm = pq_null(), lm = pq_null();
+        if (p <= 0) { y[0] = pq_null(); return; } // decision D-7b
+        if (!pq_isnull(x[0])) hm = mx.step(r.in[0], t, x[0]);
+        if (!pq_isnull(x[1])) lm = mn.step(r.in[1], t, x[1]);
+        y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
+    }
+};
+
+// SAR / SAREXT (decision D-4: TA-Lib algorithm; nulls -> 0.0 as overlap.rs:445-450)
+__device__ __forceinline__ double n0(double x) { return pq_isnull(x) ? 0.0 : x; }
+
+struct SarextOp {
+    static constexpr int NIN = 2, NOUT = 1;
+    static constexpr int SEQ_ID = 11;
+    bool ext; // false: plain SAR (no offset, no negation)
+    double startvalue, offset, ai_long, a_long, am_long, ai_short, a_short, am_short;
+    double af_long, af_short, ep, sar, new_low, new_high;
+    bool is_long;
+    __device__ void init(const Row<2> &r) {
+        af_long = ai_long; af_short = ai_short;
+        if (af_long > am_long) af_long = ai_long = am_long;
+        if (a_long > am_long) a_long = am_long;
+        if (af_short > am_short) af_short = ai_short = am_short;
+        if (a_short > am_short) a_short = am_short;
+        if (r.len < 2) return;
+        double h0 = n0(r.in[0][0]), l0 = n0(r.in[1][0]), h1 = n0(r.in[0][1]), l1 = n0(r.in[1][1]);
+        if (startvalue == 0.0) {
+            double diffP = h1 - h0, diffM = l0 - l1;
+            is_long = !(diffM > 0.0 && diffP < diffM);
+            if (is_long) { ep = h1; sar = l0; } else { ep = l1; sar = h0; }
+        } else if (startvalue > 0.0) { is_long = true; ep = h1; sar = startvalue; }
+        else { is_long = false; ep = l1; sar = fabs(startvalue); }
+        new_low = l1; new_high = h1;
+    }
+    __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
+        y[0] = pq_null();
+        if (r.len < 2 || t == 0) return;
+        double prev_low = new_low, prev_high = new_high;
+        new_high = n0(x[0]); new_low = n0(x[1]);
+        if (is_long) {
+            if (new_low <= sar) {
+                is_long = false; sar = ep;
+                if (sar < prev_high) sar = prev_high;
+                if (sar < new_high) sar = new_high;
+                if (ext && offset != 0.0) sar += sar * offset;
+                y[0] = ext ? -sar : sar;
+                af_short = ai_short; ep = new_low;
+                sar = sar + af_short * (ep - sar);
+                if (sar < prev_high) sar = prev_high;
+                if (sar < new_high) sar = new_high;
+            } else {
+                y[0] = sar;
+                if (new_high > ep) { ep = new_high; af_long += a_long; if (af_long > am_long) af_long = am_long; }
+                sar = sar + af_long * (ep - sar);
+                if (sar > prev_low) sar = prev_low;
+                if (sar > new_low) sar = new_low;
+            }
+        } else {
+            if (new_high >= sar) {
+                is_long = true; sar = ep;
+                if (sar > prev_low) sar = prev_low;
+                if (sar > new_low) sar = new_low;
+                if (ext && offset != 0.0) sar -= sar * offset;
+                y[0] = sar;
+                af_long = ai_long; ep = new_high;
+                sar = sar + af_long * (ep - sar);
+                if (sar > prev_low) sar = prev_low;
+                if (sar > new_low) sar = new_low;
+            } else {
+                y[0] = ext ? -sar : sar;
+                if (new_low < ep) { ep = new_low; af_short += a_short; if (af_short > am_short) af_short = am_short; }
+                sar = sar + af_short * (ep - sar);
+                if (sar < prev_high) sar = prev_high;
+                if (sar < new_high) sar = new_high;
+            }
+        }
+    }
+};
+
+// MAVP (decision D-4) as independent jobs, one per candidate period P: run the reference MA for period P over
+// the whole series and write only the rows whose clamped period is P (every row is written by exactly one job).
+template <class Inner>
+struct MavpSelOp {
+    static constexpr int NIN = 2, NOUT = 1; // real (nulls already -> 0.0), periods
+    static constexpr int SEQ_ID = 100 + Inner::SEQ_ID;
+    static constexpr bool MASKED = true;
+    int64_t P, minp, maxp;
+    Inner inner;
+    __device__ void init(const Row<2> &r) {
+        Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
+        inner.init(r1);
+    }
+    __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
+        Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
+        double xi[1] = {x[0]}, yi[1];
+        inner.step(r1, t, xi, yi);
+        int64_t pi = (int64_t)n0(x[1]);
+        if (pi < minp) pi = minp;
+        if (pi > maxp) pi = maxp;
+        y[0] = (pi != P) ? pq_skip() : ((t >= maxp - 1) ? yi[0] : pq_null());
+    }
+};
+// select rows of a materialised MA(P) column (used for matypes that are not a single SEQ op)
+struct MavpPickOp {
+    static constexpr int NIN = 2, NOUT = 1; // ma(P), periods
+    static constexpr int SEQ_ID = 12;
+    static constexpr bool MASKED = true;
+    int64_t P, minp, maxp;
+    __device__ void init(const Row<2> &) {}
+    __device__ void step(const Row<2> &, int64_t t, const double (&x)[2], double (&y)[1]) {
+        int64_t pi = (int64_t)n0(x[1]);
+        if (pi < minp) pi = minp;
+        if (pi > maxp) pi = maxp;
+        y[0] = (pi != P) ? pq_skip() : ((t >= maxp - 1) ? x[0] : pq_null());
+    }
+};
+static inline void t3_coeffs(T3Op &op, double vf) { // overlap.rs:949-952
+    op.c1 = -(vf * vf * vf);
+    op.c2 = 3.0 * (vf * vf) - 3.0 * op.c1;
+    op.c3 = -2.0 * op.c2 - 3.0 * op.c1 - 3.0 * vf;
+    op.c4 = 1.0 - op.c1 - op.c2 - op.c3;
+}
+struct FillNullOp {
+    static constexpr int NIN = 0, NOUT = 1;
+    typedef double OutT;
+    __device__ void eval(const Row<0> &, int64_t, double (&y)[1]) { y[0] = pq_null(); }
+};
+struct ReplaceNullOp { // nulls -> 0.0 (N-0 families)
+    static constexpr int NIN = 1, NOUT = 1;
+    typedef double OutT;
+    __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) { y[0] = n0(r.in[0][t]); }
+};
+

@@ -268,8 +268,35 @@ int32_t pq_pattern_id(const char *name) {
     return -1;
 }
 
+struct CdlBlob {
+    CdlArgs args;
+    int id;
+    pq_batch b;
+};
+static void cdl_launch_blob(const void *blob, hipStream_t stream);
 static pq_status cdl_launch(pq_ctx *ctx, const pq_batch *b, const CdlArgs &args, int id) {
     if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    CdlBlob cb{args, id, *b};
+    if (ctx->rec) {
+        static_assert(sizeof(CdlBlob) <= sizeof(RowThunk::blob), "CdlBlob too large");
+        RowThunk t;
+        t.launch = &cdl_launch_blob;
+        memcpy(t.blob, &cb, sizeof cb);
+        t.n_reads = 4;
+        t.reads[0] = args.o; t.reads[1] = args.h; t.reads[2] = args.l; t.reads[3] = args.c;
+        t.n_writes = 0;
+        for (int i = 0; i < PQ_N_PATTERNS; i++) if (args.out[i]) t.writes[t.n_writes++] = args.out[i];
+        return rec_add_row(ctx, t);
+    }
+    cdl_launch_blob(&cb, ctx->stream);
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+static void cdl_launch_blob(const void *blob, hipStream_t stream) {
+    const CdlBlob &cb = *reinterpret_cast<const CdlBlob *>(blob);
+    const pq_batch *b = &cb.b;
+    const CdlArgs &args = cb.args;
+    const int id = cb.id;
     for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
         int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
         CdlArgs a2 = args;
@@ -278,11 +305,9 @@ static pq_status cdl_launch(pq_ctx *ctx, const pq_batch *b, const CdlArgs &args,
         for (int i = 0; i < PQ_N_PATTERNS; i++) if (a2.out[i]) a2.out[i] += off;
         dim3 grid((unsigned)((b->len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns);
         Dims d{ns, b->len, b->stride};
-        if (id < 0) hipLaunchKernelGGL(cdl_all_kernel, grid, dim3(ROW_BLOCK), 0, ctx->stream, a2, d);
-        else hipLaunchKernelGGL(cdl_one_kernel, grid, dim3(ROW_BLOCK), 0, ctx->stream, a2, id, d);
-        PQ_HIP_TRY(hipGetLastError());
+        if (id < 0) hipLaunchKernelGGL(cdl_all_kernel, grid, dim3(ROW_BLOCK), 0, stream, a2, d);
+        else hipLaunchKernelGGL(cdl_one_kernel, grid, dim3(ROW_BLOCK), 0, stream, a2, id, d);
     }
-    return PQ_OK;
 }
 
 pq_status pq_cdl(pq_ctx *ctx, const pq_batch *b, int32_t id, const double *o, const double *h, const double *l,

@@ -7,12 +7,18 @@
 //          recurrence), outputs are pushed the same way.
 //   ROW  : one (series, row) per thread, row index fastest => fully coalesced; used for everything
 //          whose value is a pure function of a bounded look-back window (exact, order-free).
+// A SEQ launch of one function has only n_series/64 wavefronts (79 for 5000 symbols), far too few to
+// fill 256 CUs, so the library can also RECORD calls instead of launching them (pq_suite_*, suite.hip):
+// recorded SEQ jobs of all functions run as ONE grid (blockIdx.y = job) that does fill the chip.
 // All arithmetic is compiled with -ffp-contract=off; fma() appears only where the reference
 // calls f64::mul_add.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/pq_hip.h"
+
+struct Recorder; // suite.hip
 
 struct pq_ctx {
     int device;
@@ -21,14 +27,14 @@ struct pq_ctx {
     void *ws;        // scratch workspace (device)
     size_t ws_bytes;
     int64_t *d_flag; // 1 x int64 device scalar for reductions
+    Recorder *rec;   // non-null while a suite is being recorded
 };
 
 void pq_set_error(const char *fmt, ...);
 pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes);
-// n-th scratch column ([n_series][stride] doubles) of the workspace; reserve first
-static inline double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k) {
-    return reinterpret_cast<double *>(ctx->ws) + (size_t)k * (size_t)(b->n_series * b->stride);
-}
+// k-th scratch column ([n_series][stride] doubles).  While recording, every request returns a fresh
+// column owned by the suite (recorded jobs run concurrently, so scratch cannot be shared).
+double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k);
 pq_status pq_check(pq_ctx *ctx, const pq_batch *b);
 
 #define PQ_HIP_TRY(expr)                                                                         \
@@ -53,9 +59,14 @@ pq_status pq_check(pq_ctx *ctx, const pq_batch *b);
     } while (0)
 
 // ---------------------------------------------------------------- device helpers
+#define PQ_SKIP_BITS 0x7FF80000534B4950ULL // "SKIP": a SEQ op with MASKED = true returns this to leave a row unwritten
 __device__ __forceinline__ double pq_null() { return __longlong_as_double((long long)PQ_NULL_BITS); }
 __device__ __forceinline__ bool pq_isnull(double x) {
     return (unsigned long long)__double_as_longlong(x) == PQ_NULL_BITS;
+}
+__device__ __forceinline__ double pq_skip() { return __longlong_as_double((long long)PQ_SKIP_BITS); }
+__device__ __forceinline__ bool pq_isskip(double x) {
+    return (unsigned long long)__double_as_longlong(x) == PQ_SKIP_BITS;
 }
 
 struct Dims {
@@ -80,30 +91,35 @@ struct Row {
 };
 
 constexpr int SEQ_BLOCK = 64; // one wavefront per workgroup: more workgroups to spread over 256 CUs
-constexpr int SEQ_CH = 8;     // rows per register chunk
+template <int NIN>
+struct SeqChunk { // rows per register chunk: 64 B per lane and column, fewer for wide ops (VGPR budget)
+    static constexpr int value = NIN <= 2 ? 8 : 4;
+};
+template <class Op, class = void>
+struct IsMasked { static constexpr bool value = false; };
+template <class Op>
+struct IsMasked<Op, decltype((void)Op::MASKED)> { static constexpr bool value = Op::MASKED; };
 
-// SEQ driver.  Op contract:
-//   static constexpr int NIN, NOUT;
+// SEQ body for one lane.  Op contract:
+//   static constexpr int NIN, NOUT;   [static constexpr bool MASKED = true;  outputs may be pq_skip()]
 //   __device__ void init(const Row<NIN>& r);                       // once per series
 //   __device__ void step(const Row<NIN>& r, int64_t t, const double (&x)[NIN], double (&y)[NOUT]);
 template <class Op>
-__global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
-    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, CH = SEQ_CH;
-    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
-    if (s >= d.n) return;
+__device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double *const *outp, const Dims &d, int64_t s) {
+    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, CH = SeqChunk<NIN>::value;
+    constexpr bool MASKED = IsMasked<Op>::value;
     Row<NIN> r;
     r.len = d.len;
 #pragma unroll
-    for (int k = 0; k < NIN; k++) r.in[k] = in.p[k] + s * d.stride;
+    for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + s * d.stride;
     double *o[NOUT];
 #pragma unroll
-    for (int k = 0; k < NOUT; k++) o[k] = out.p[k] + s * d.stride;
+    for (int k = 0; k < NOUT; k++) o[k] = outp[k] + s * d.stride;
     op.init(r);
     const int64_t T = d.len;
     int64_t t0 = 0;
     double xb[NIN][CH];
-    // prologue: first chunk
-    if (T >= CH) {
+    if (T >= CH) { // prologue: first chunk
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
@@ -115,8 +131,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> i
         for (int k = 0; k < NIN; k++)
 #pragma unroll
             for (int j = 0; j < CH; j++) xc[k][j] = xb[k][j];
-        // issue the next chunk's loads before the dependent recurrence of this one
-        if (t0 + 2 * CH <= T) {
+        if (t0 + 2 * CH <= T) { // issue the next chunk's loads before the dependent recurrence of this one
 #pragma unroll
             for (int k = 0; k < NIN; k++)
 #pragma unroll
@@ -135,7 +150,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> i
 #pragma unroll
         for (int k = 0; k < NOUT; k++)
 #pragma unroll
-            for (int j = 0; j < CH; j++) o[k][t0 + j] = yb[k][j];
+            for (int j = 0; j < CH; j++)
+                if (!MASKED || !pq_isskip(yb[k][j])) o[k][t0 + j] = yb[k][j];
     }
     for (; t0 < T; t0++) { // tail
         double x[NIN], y[NOUT];
@@ -143,14 +159,60 @@ __global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> i
         for (int k = 0; k < NIN; k++) x[k] = r.in[k][t0];
         op.step(r, t0, x, y);
 #pragma unroll
-        for (int k = 0; k < NOUT; k++) o[k][t0] = y[k];
+        for (int k = 0; k < NOUT; k++)
+            if (!MASKED || !pq_isskip(y[k])) o[k][t0] = y[k];
     }
 }
+
+template <class Op>
+__global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
+    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (s >= d.n) return;
+    run_seq(op, in.p, out.p, d, s);
+}
+
+// ---- recording hooks (implemented in suite.hip)
+// a recordable SEQ op carries `static constexpr int SEQ_ID` = its switch case in the job grid (suite.hip)
+pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
+                      int nin, double *const *out, int nout);
+struct RowThunk { // type-erased ROW launch for replay
+    void (*launch)(const void *blob, hipStream_t stream);
+    unsigned char blob[1200];
+    const void *reads[8];
+    int n_reads;
+    void *writes[64];
+    int n_writes;
+};
+pq_status rec_add_row(pq_ctx *ctx, const RowThunk &t);
+void rec_set_shared_out(pq_ctx *ctx, bool on); // jobs recorded while on may write disjoint rows of one column
+// Records the enclosed calls into a suite and runs it once at finish(); a no-op inside an outer recording.
+struct SuiteScope {
+    pq_ctx *ctx;
+    bool owner;
+    pq_status status;
+    SuiteScope(pq_ctx *ctx, const pq_batch *b);
+    ~SuiteScope();
+    pq_status finish();
+};
+
+template <class Op, class = void>
+struct HasSeqId { static constexpr bool value = false; };
+template <class Op>
+struct HasSeqId<Op, decltype((void)Op::SEQ_ID)> { static constexpr bool value = true; };
 
 template <class Op>
 static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in,
                                    const OutCols<Op::NOUT> &out) {
     if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    if (ctx->rec) {
+        if constexpr (HasSeqId<Op>::value) {
+            static_assert(sizeof(Op) <= 512, "SEQ op too large for a job slot");
+            return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT);
+        } else {
+            pq_set_error("this SEQ op cannot be recorded into a suite");
+            return PQ_ERR_UNSUPPORTED;
+        }
+    }
     dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
     hipLaunchKernelGGL(seq_kernel<Op>, grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b));
     PQ_HIP_TRY(hipGetLastError());
@@ -180,20 +242,44 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> i
     for (int k = 0; k < Op::NOUT; k++) out.p[k][s * d.stride + t] = y[k];
 }
 template <class Op>
-static inline pq_status launch_row(pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in,
-                                   const OutColsT<Op, typename Op::OutT> &out) {
-    if (b->n_series == 0 || b->len == 0) return PQ_OK;
-    // grid.y is limited to 65535: slice the series axis
-    for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
+struct RowBlob {
+    Op op;
+    InCols<Op::NIN> in;
+    OutColsT<Op, typename Op::OutT> out;
+    pq_batch b;
+};
+template <class Op>
+static void row_launch_blob(const void *blob, hipStream_t stream) {
+    const RowBlob<Op> &rb = *reinterpret_cast<const RowBlob<Op> *>(blob);
+    const pq_batch *b = &rb.b;
+    for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) { // grid.y is limited to 65535: slice the series axis
         int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
-        InCols<Op::NIN> in2 = in;
-        OutColsT<Op, typename Op::OutT> out2 = out;
+        InCols<Op::NIN> in2 = rb.in;
+        OutColsT<Op, typename Op::OutT> out2 = rb.out;
         for (int k = 0; k < Op::NIN; k++) in2.p[k] += s0 * b->stride;
         for (int k = 0; k < Op::NOUT; k++) out2.p[k] += s0 * b->stride;
         dim3 grid((unsigned)((b->len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns);
         Dims d{ns, b->len, b->stride};
-        hipLaunchKernelGGL(row_kernel<Op>, grid, dim3(ROW_BLOCK), 0, ctx->stream, op, in2, out2, d);
-        PQ_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(row_kernel<Op>, grid, dim3(ROW_BLOCK), 0, stream, rb.op, in2, out2, d);
     }
+}
+template <class Op>
+static inline pq_status launch_row(pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in,
+                                   const OutColsT<Op, typename Op::OutT> &out) {
+    if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    RowBlob<Op> rb{op, in, out, *b};
+    if (ctx->rec) {
+        static_assert(sizeof(RowBlob<Op>) <= sizeof(RowThunk::blob), "ROW blob too large");
+        RowThunk t;
+        t.launch = &row_launch_blob<Op>;
+        memcpy(t.blob, &rb, sizeof rb);
+        t.n_reads = Op::NIN;
+        for (int k = 0; k < Op::NIN; k++) t.reads[k] = in.p[k];
+        t.n_writes = Op::NOUT;
+        for (int k = 0; k < Op::NOUT; k++) t.writes[k] = out.p[k];
+        return rec_add_row(ctx, t);
+    }
+    row_launch_blob<Op>(&rb, ctx->stream);
+    PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }

@@ -94,6 +94,7 @@ pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out) {
     c->ws = nullptr;
     c->ws_bytes = 0;
     c->d_flag = nullptr;
+    c->rec = nullptr;
     c->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
     c->own_stream = false;
     hipError_t e = hipMalloc((void **)&c->d_flag, sizeof(int64_t));

@@ -1,0 +1,282 @@
+// suite.hip -- record many pq_* calls, replay them as a few chip-filling grids.
+//
+// Why: a SEQ launch of one indicator has n_series/64 wavefronts (79 for 5000 symbols) -- 256 CUs cannot be
+// filled, each wave is latency-bound on its own loads and the launch runs at a few hundred GB/s.  The symbols
+// are the only parallel axis of one indicator (the time axis is a strict recurrence), but a DataFrame query
+// asks for MANY indicators at once.  pq_suite_begin()/pq_suite_end() therefore turn the enclosed pq_* calls into
+// a dependency-ordered list of phases; all SEQ jobs of a phase execute as ONE grid (blockIdx.y = job,
+// blockIdx.x = 64-symbol tile), ROW launches replay as recorded.  pq_suite_run() replays with no host work
+// besides the launches.  Composite functions (MAVP = one job per candidate period) use the same machinery
+// internally through SuiteScope.
+#include "ops_backtest.h"
+#include "ops_misc.h"
+#include "ops_momentum.h"
+#include "ops_overlap.h"
+#include <algorithm>
+#include <map>
+#include <vector>
+
+struct SeqJob { // device-visible
+    int kind, nin, nout, cost;
+    const double *in[5];
+    double *out[3];
+    alignas(8) unsigned char op[512];
+};
+static_assert(sizeof(BtArgs) <= 512, "BtArgs must fit a job slot");
+
+struct Phase {
+    std::vector<SeqJob> seq;
+    std::vector<RowThunk> rows;
+    SeqJob *d_seq = nullptr;
+};
+struct Recorder {
+    pq_batch b;
+    std::vector<Phase> phases;
+    std::map<const void *, int> writer_phase, reader_phase;
+    std::vector<void *> scratch;
+    bool shared_out = false;
+};
+struct pq_suite {
+    Recorder rec;
+};
+
+// every recordable SEQ op: X(Type)
+#define SEQ_OPS(X)                                                                                                   \
+    X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
+    X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
+    X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
+    X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
+    X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
+    X(AtrOp<false>) X(AtrOp<true>) X(AdOp<false>) X(AdOp<true>) X(ObvOp) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>)
+
+__global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
+    const SeqJob &job = jobs[blockIdx.y];
+    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (s >= d.n) return;
+    switch (job.kind) { // wave-uniform
+#define X(OP)                                                        \
+    case OP::SEQ_ID: {                                               \
+        OP op;                                                       \
+        __builtin_memcpy(&op, job.op, sizeof(OP));                   \
+        run_seq(op, job.in, job.out, d, s);                          \
+    } break;
+        SEQ_OPS(X)
+#undef X
+    case SEQ_ID_BACKTEST: {
+        BtArgs a;
+        __builtin_memcpy(&a, job.op, sizeof(BtArgs));
+        backtest_body<false, false>(a, d, s);
+    } break;
+    case SEQ_ID_BACKTEST + 1: {
+        BtArgs a;
+        __builtin_memcpy(&a, job.op, sizeof(BtArgs));
+        backtest_body<true, false>(a, d, s);
+    } break;
+    default: break;
+    }
+}
+
+// rough relative cost per row, used to start the longest jobs first
+static int job_cost(int kind) {
+    if (kind >= 45 && kind <= 49) return 30;      // Hilbert pipeline
+    if (kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1) return 25;
+    if (kind == 24 || kind == 25) return 20;      // ultosc, mfi: lagged recomputation
+    if (kind == 9 || kind == 10) return 20;       // rolling extrema
+    if (kind >= 26 && kind <= 28) return 15;      // DM family
+    if (kind == 6 || kind == 8) return 12;
+    return 8;
+}
+
+static int phase_for(Recorder &r, const void *const *reads, int nr, void *const *writes, int nw) {
+    int ph = 0;
+    for (int i = 0; i < nr; i++) {
+        auto it = r.writer_phase.find(reads[i]);
+        if (it != r.writer_phase.end()) ph = std::max(ph, it->second + 1);
+    }
+    for (int i = 0; i < nw; i++) {
+        if (!writes[i]) continue;
+        auto it = r.writer_phase.find(writes[i]);
+        if (it != r.writer_phase.end()) ph = std::max(ph, r.shared_out ? it->second : it->second + 1);
+        auto ir = r.reader_phase.find(writes[i]);
+        if (ir != r.reader_phase.end()) ph = std::max(ph, ir->second + 1);
+    }
+    if ((int)r.phases.size() <= ph) r.phases.resize(ph + 1);
+    for (int i = 0; i < nr; i++) {
+        int &rp = r.reader_phase[reads[i]];
+        rp = std::max(rp, ph);
+    }
+    for (int i = 0; i < nw; i++)
+        if (writes[i]) {
+            auto it = r.writer_phase.find(writes[i]);
+            r.writer_phase[writes[i]] = (it == r.writer_phase.end()) ? ph : std::max(it->second, ph);
+        }
+    return ph;
+}
+
+static pq_status same_batch(Recorder &r, const pq_batch *b) {
+    if (b->n_series != r.b.n_series || b->len != r.b.len || b->stride != r.b.stride) {
+        pq_set_error("every call recorded into one suite must use the same batch shape");
+        return PQ_ERR_ARG;
+    }
+    return PQ_OK;
+}
+
+pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
+                      int nin, double *const *out, int nout) {
+    Recorder &r = *ctx->rec;
+    PQ_TRY(same_batch(r, b));
+    SeqJob j;
+    memset(&j, 0, sizeof j);
+    j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind);
+    for (int k = 0; k < nin; k++) j.in[k] = in[k];
+    for (int k = 0; k < nout; k++) j.out[k] = out[k];
+    memcpy(j.op, op, op_bytes);
+    int ph = phase_for(r, (const void *const *)in, nin, (void *const *)out, nout);
+    r.phases[ph].seq.push_back(j);
+    return PQ_OK;
+}
+pq_status rec_add_backtest(pq_ctx *ctx, const pq_batch *b, int kind, const BtArgs &a) {
+    Recorder &r = *ctx->rec;
+    PQ_TRY(same_batch(r, b));
+    SeqJob j;
+    memset(&j, 0, sizeof j);
+    j.kind = kind; j.cost = job_cost(kind);
+    memcpy(j.op, &a, sizeof a);
+    const void *reads[4] = {a.price, a.buy, a.sell, a.bench};
+    void *writes[4] = {a.position, a.cash, a.equity, a.summary};
+    const void *rd[4]; int nr = 0;
+    for (int i = 0; i < 4; i++) if (reads[i]) rd[nr++] = reads[i];
+    int ph = phase_for(r, rd, nr, writes, 4);
+    r.phases[ph].seq.push_back(j);
+    return PQ_OK;
+}
+pq_status rec_add_row(pq_ctx *ctx, const RowThunk &t) {
+    Recorder &r = *ctx->rec;
+    int ph = phase_for(r, t.reads, t.n_reads, t.writes, t.n_writes);
+    r.phases[ph].rows.push_back(t);
+    return PQ_OK;
+}
+void rec_set_shared_out(pq_ctx *ctx, bool on) {
+    if (ctx->rec) ctx->rec->shared_out = on;
+}
+
+static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
+    for (Phase &p : r.phases) {
+        if (p.seq.empty()) continue;
+        std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cost > b.cost; });
+        PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
+        PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); // the host vectors are pageable
+    return PQ_OK;
+}
+static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
+    Dims d = dims_of(&r.b);
+    for (Phase &p : r.phases) {
+        if (!p.seq.empty()) {
+            dim3 grid((unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK), (unsigned)p.seq.size());
+            hipLaunchKernelGGL(seq_jobs_kernel, grid, dim3(SEQ_BLOCK), 0, ctx->stream, p.d_seq, d);
+        }
+        for (const RowThunk &t : p.rows) t.launch(t.blob, ctx->stream);
+    }
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+static void suite_free(pq_ctx *ctx, Recorder &r) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (Phase &p : r.phases) if (p.d_seq) (void)hipFree(p.d_seq);
+    for (void *s : r.scratch) (void)hipFree(s);
+    r.phases.clear();
+    r.scratch.clear();
+}
+
+double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k) {
+    size_t col = (size_t)(b->n_series * b->stride);
+    if (ctx->rec) { // fresh column per request, owned by the suite
+        void *p = nullptr;
+        if (hipMalloc(&p, col * sizeof(double)) != hipSuccess) return nullptr;
+        ctx->rec->scratch.push_back(p);
+        return (double *)p;
+    }
+    return reinterpret_cast<double *>(ctx->ws) + (size_t)k * col;
+}
+
+SuiteScope::SuiteScope(pq_ctx *c, const pq_batch *b) : ctx(c), owner(false), status(PQ_OK) {
+    if (ctx->rec) return;
+    pq_suite *s = new pq_suite();
+    s->rec.b = *b;
+    ctx->rec = &s->rec;
+    owner = true;
+}
+SuiteScope::~SuiteScope() {
+    if (owner && ctx->rec) { // error path: drop whatever was recorded
+        Recorder *r = ctx->rec;
+        ctx->rec = nullptr;
+        suite_free(ctx, *r);
+        delete reinterpret_cast<pq_suite *>(r);
+    }
+}
+pq_status SuiteScope::finish() {
+    if (!owner) return PQ_OK;
+    Recorder *r = ctx->rec;
+    ctx->rec = nullptr;
+    owner = false;
+    pq_status st = suite_finalize(ctx, *r);
+    if (st == PQ_OK) st = suite_launch(ctx, *r);
+    suite_free(ctx, *r); // drains the stream first
+    delete reinterpret_cast<pq_suite *>(r);
+    return st;
+}
+
+extern "C" {
+
+pq_status pq_suite_begin(pq_ctx *ctx, const pq_batch *b) {
+    PQ_TRY(pq_check(ctx, b));
+    PQ_REQUIRE(!ctx->rec, "pq_suite_begin: a suite is already being recorded on this context");
+    pq_suite *s = new pq_suite();
+    s->rec.b = *b;
+    ctx->rec = &s->rec;
+    return PQ_OK;
+}
+pq_status pq_suite_end(pq_ctx *ctx, pq_suite **out) {
+    PQ_REQUIRE(ctx && out, "pq_suite_end: null pointer");
+    PQ_REQUIRE(ctx->rec, "pq_suite_end: no suite is being recorded");
+    pq_suite *s = reinterpret_cast<pq_suite *>(ctx->rec);
+    ctx->rec = nullptr;
+    pq_status st = suite_finalize(ctx, s->rec);
+    if (st != PQ_OK) { suite_free(ctx, s->rec); delete s; return st; }
+    *out = s;
+    return PQ_OK;
+}
+pq_status pq_suite_abort(pq_ctx *ctx) {
+    PQ_REQUIRE(ctx, "pq_suite_abort: null pointer");
+    if (!ctx->rec) return PQ_OK;
+    pq_suite *s = reinterpret_cast<pq_suite *>(ctx->rec);
+    ctx->rec = nullptr;
+    suite_free(ctx, s->rec);
+    delete s;
+    return PQ_OK;
+}
+pq_status pq_suite_run(pq_ctx *ctx, pq_suite *s) {
+    PQ_REQUIRE(ctx && s, "pq_suite_run: null pointer");
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    return suite_launch(ctx, s->rec);
+}
+pq_status pq_suite_destroy(pq_ctx *ctx, pq_suite *s) {
+    PQ_REQUIRE(ctx, "pq_suite_destroy: null pointer");
+    if (!s) return PQ_OK;
+    suite_free(ctx, s->rec);
+    delete s;
+    return PQ_OK;
+}
+pq_status pq_suite_info(const pq_suite *s, int32_t *n_phases, int32_t *n_seq_jobs, int32_t *n_row_launches) {
+    PQ_REQUIRE(s, "pq_suite_info: null pointer");
+    int32_t nj = 0, nr = 0;
+    for (const Phase &p : s->rec.phases) { nj += (int32_t)p.seq.size(); nr += (int32_t)p.rows.size(); }
+    if (n_phases) *n_phases = (int32_t)s->rec.phases.size();
+    if (n_seq_jobs) *n_seq_jobs = nj;
+    if (n_row_launches) *n_row_launches = nr;
+    return PQ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,118 @@
+"""The benchmark workload as a reusable object: the full indicator suite (every function of SURVEY 8(a)
+with the reference's Python-wrapper default parameters) + the fused MACD-cross per-symbol backtest over
+one symbol-major [N, T] OHLCV block resident in HBM.  Outputs are allocated once.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import Batch, BtParams, check, lib
+from ._spec import BT_DEFAULTS, I, PATTERN_NAMES, PATTERN_PEN_DEFAULT, SPEC
+from .api import ctx
+
+COLMAP = {"real": "close"}
+
+
+def algorithmic_bytes_per_row() -> dict:
+    """8*(#f64 in + #f64 out) + 4*(#i32 out) per (symbol, day) row, per call."""
+    per = {}
+    for name, (cols, _p, outs, _f) in SPEC.items():
+        per[name] = 8 * len(cols) + sum(8 if dt == "f8" else 4 for _, dt in outs)
+    per["cdl_all"] = 8 * 4 + 4 * len(PATTERN_NAMES)          # fused: OHLC read once, 61 int32 written
+    per["backtest_macd_cross"] = 8 + 24                       # close in; position, cash, equity out
+    return per
+
+
+class Suite:
+    def __init__(self, n_series: int, T: int, device="cuda"):
+        self.n, self.T = n_series, T
+        self.dev = torch.device(device)
+        self.batch = Batch(n_series, T, T)
+        f64 = lambda: torch.empty((n_series, T), dtype=torch.float64, device=self.dev)
+        i32 = lambda: torch.empty((n_series, T), dtype=torch.int32, device=self.dev)
+        self.out = {name: [f64() if dt == "f8" else i32() for _, dt in outs] for name, (_c, _p, outs, _f) in SPEC.items()}
+        self.pat = {nm: i32() for nm in PATTERN_NAMES}
+        self.bt = [f64(), f64(), f64()]
+        self.summary = torch.empty((n_series, 8), dtype=torch.float64, device=self.dev)
+        self.periods = torch.from_numpy(np.tile((2 + np.arange(T) % 29).astype(np.float64), (n_series, 1))).to(self.dev)
+        self._pens = (C.c_double * 61)(*[PATTERN_PEN_DEFAULT[nm] for nm in PATTERN_NAMES])
+        self._pat_ptrs = (C.c_void_p * 61)(*[self.pat[nm].data_ptr() for nm in PATTERN_NAMES])
+        self._prm = BtParams(**BT_DEFAULTS)
+        self._defaults = {name: [C.c_int64(int(d)) if k == I else C.c_double(float(d)) for _, k, d in p]
+                          for name, (_c, p, _o, _f) in SPEC.items()}
+        self.bytes_per_row = algorithmic_bytes_per_row()
+
+    def out_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for ts in self.out.values() for t in ts) + \
+            sum(t.numel() * 4 for t in self.pat.values()) + sum(t.numel() * 8 for t in self.bt)
+
+    def _col(self, ohlcv, c):
+        return self.periods if c == "periods" else ohlcv[COLMAP.get(c, c)]
+
+    def run_one(self, name: str, ohlcv: dict) -> None:
+        L, h, b = lib(), ctx(self.dev.index), self.batch
+        if name == "cdl_all":
+            check(L.pq_cdl_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("open", "high", "low", "close")],
+                               self._pens, self._pat_ptrs))
+        elif name == "backtest_macd_cross":
+            check(L.pq_backtest_macd_cross(h, C.byref(b), C.c_void_p(ohlcv["close"].data_ptr()), 12, 26, 9, C.byref(self._prm),
+                                           *[C.c_void_p(t.data_ptr()) for t in self.bt], C.c_void_p(self.summary.data_ptr())))
+        else:
+            cols = SPEC[name][0]
+            check(getattr(L, "pq_" + name)(h, C.byref(b), *[C.c_void_p(self._col(ohlcv, c).data_ptr()) for c in cols],
+                                           *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in self.out[name]]))
+
+    def tasks(self):
+        return list(SPEC) + ["cdl_all", "backtest_macd_cross"]
+
+    def run_eager(self, ohlcv: dict) -> None:
+        """one step as ~90 separate launches (one per C-ABI call), enqueued on the current stream"""
+        with torch.cuda.device(self.dev):
+            for name in self.tasks():
+                self.run_one(name, ohlcv)
+
+    def record(self, ohlcv: dict, tasks=None) -> None:
+        """record the step once (pq_suite_begin/end): the sequential jobs of all functions become one grid per phase"""
+        self.close()
+        L, h = lib(), ctx(self.dev.index)
+        self._ohlcv = ohlcv  # keep the inputs alive: the suite holds raw device pointers
+        with torch.cuda.device(self.dev):
+            check(L.pq_suite_begin(h, C.byref(self.batch)))
+            try:
+                for name in (tasks or self.tasks()):
+                    self.run_one(name, ohlcv)
+            except Exception:
+                L.pq_suite_abort(h)
+                raise
+            out = C.c_void_p()
+            check(L.pq_suite_end(h, C.byref(out)))
+        self._suite = out
+
+    def info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().pq_suite_info(self._suite, C.byref(a), C.byref(b), C.byref(c)))
+        return {"phases": a.value, "seq_jobs": b.value, "row_launches": c.value}
+
+    def run(self, ohlcv: dict | None = None) -> None:
+        """one step: every indicator + all 61 patterns + the MACD-cross backtest, enqueued on the current stream"""
+        if getattr(self, "_suite", None) is None:
+            self.record(ohlcv)
+        with torch.cuda.device(self.dev):
+            check(lib().pq_suite_run(ctx(self.dev.index), self._suite))
+
+    def close(self):
+        if getattr(self, "_suite", None) is not None:
+            check(lib().pq_suite_destroy(ctx(self.dev.index), self._suite))
+            self._suite = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def suite_bytes_per_row(self) -> int:
+        return sum(self.bytes_per_row[t] for t in self.tasks())

@@ -290,3 +290,33 @@ def test_numpy_and_arrow_roundtrip(pq, oracle, data):
         pq.RSI(arr, 14)            # N-B family rejects nulls like the reference (momentum.rs:12-13)
     up, mid, lo = pq.BBANDS(x)
     assert up.shape == x.shape
+
+
+def test_suite_replay_matches_direct_calls_and_oracle(pq, oracle, data):
+    """pq_suite_*: the recorded job grid must reproduce the direct calls (and therefore the oracle) bit for bit"""
+    from polars_quant_amd.suite import Suite
+    g = {k: torch.from_numpy(v).cuda() for k, v in data.items() if k in ("open", "high", "low", "close", "volume")}
+    st = Suite(N_SYM, T, "cuda")
+    st.record(g)
+    info = st.info()
+    assert info["seq_jobs"] >= 60 and info["phases"] >= 2
+    for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
+        t.fill_(-7)                      # poison: every row must be produced by the replay
+    st.run()
+    st.run()                             # replays are idempotent
+    torch.cuda.synchronize()
+    d = dict(data)
+    d["periods"] = st.periods.cpu().numpy()
+    for name in sorted(pq.SPEC):
+        cols = pq.SPEC[name][0]
+        exp = oracle.call(name, *[d[c] for c in cols])
+        for (oname, _), got, e in zip(pq.SPEC[name][2], st.out[name], exp):
+            assert_same(f"suite:{name}.{oname}", got.cpu().numpy(), e, exact=name not in TRANSCENDENTAL)
+    for nm in pq.PATTERN_NAMES:
+        exp = oracle.pattern(nm, data["open"], data["high"], data["low"], data["close"])
+        assert (st.pat[nm].cpu().numpy() == exp).all(), nm
+    ebuy, esell = oracle.macd_cross_signals(data["close"])
+    epos, ecash, eeq, es = oracle.backtest(data["close"], ebuy, esell)
+    assert (bits(st.bt[2].cpu().numpy()) == bits(eeq)).all()
+    np.testing.assert_allclose(st.summary.cpu().numpy(), es, rtol=1e-12, atol=1e-13)
+    st.close()
