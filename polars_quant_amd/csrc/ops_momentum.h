@@ -135,15 +135,18 @@ struct BinOp {
 struct CmoOp { // momentum.rs:181-223: rolling SUMS of up/down moves; the lagged terms are recomputed
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 20;
+    static constexpr int NTAP = 2;
+    static constexpr int TAP_COL[2] = {0, 0};
     int64_t p;
     double su, sd, prev;
     __device__ void init(const Row<1> &) { su = sd = 0.0; prev = 0.0; }
+    __device__ void tap_lags(int64_t (&lag)[2]) const { lag[0] = p > 0 ? p : 0; lag[1] = p > 0 ? p + 1 : 0; }
     __device__ static void updown(double curr, double prv, double &u, double &d) {
         double diff = curr - prv;
         u = 0.0; d = 0.0;
         if (diff > 0.0) u = diff; else d = -diff;
     }
-    __device__ void step(const Row<1> &r, int64_t i, const double (&x)[1], double (&y)[1]) {
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], const double (&tp)[2], double (&y)[1]) {
         y[0] = pq_null();
         if (p <= 0) return;
         double u = 0.0, d = 0.0;
@@ -152,7 +155,7 @@ struct CmoOp { // momentum.rs:181-223: rolling SUMS of up/down moves; the lagged
         su += u; sd += d;
         if (i >= p) {
             double ou = 0.0, od = 0.0;
-            if (i - p >= 1) updown(r.in[0][i - p], r.in[0][i - p - 1], ou, od);
+            if (i - p >= 1) updown(tp[0], tp[1], ou, od);
             su -= ou; sd -= od;
         }
         if (i >= p - 1) {
@@ -215,14 +218,24 @@ struct TrixOp { // momentum.rs:544-569 (quirk Q-TRIX)
 struct UltoscOp { // momentum.rs:572-627
     static constexpr int NIN = 3, NOUT = 1; // high, low, close
     static constexpr int SEQ_ID = 24;
+    static constexpr int NTAP = 12; // per window: high, low, close at i-p and close at i-p-1
+    static constexpr int TAP_COL[12] = {0, 1, 2, 2, 0, 1, 2, 2, 0, 1, 2, 2};
     int64_t p1, p2, p3;
     double sb[3], st[3], prev_c;
     __device__ void init(const Row<3> &) { for (int k = 0; k < 3; k++) sb[k] = st[k] = 0.0; prev_c = 0.0; }
+    __device__ void tap_lags(int64_t (&lag)[12]) const {
+        const int64_t ps[3] = {p1, p2, p3};
+        bool ok = p1 > 0 && p2 > 0 && p3 > 0;
+        for (int k = 0; k < 3; k++) {
+            lag[4 * k] = lag[4 * k + 1] = lag[4 * k + 2] = ok ? ps[k] : 0;
+            lag[4 * k + 3] = ok ? ps[k] + 1 : 0;
+        }
+    }
     __device__ static void bptr(double h, double l, double c, double pc, double &bp, double &tr) {
         double min_l_pc = fmin(l, pc), max_h_pc = fmax(h, pc);
         bp = c - min_l_pc; tr = max_h_pc - min_l_pc;
     }
-    __device__ void step(const Row<3> &r, int64_t i, const double (&x)[3], double (&y)[1]) {
+    __device__ void step(const Row<3> &, int64_t i, const double (&x)[3], const double (&tp)[12], double (&y)[1]) {
         y[0] = pq_null();
         if (p1 <= 0 || p2 <= 0 || p3 <= 0) return;
         double bp = 0.0, tr = 0.0;
@@ -238,7 +251,7 @@ struct UltoscOp { // momentum.rs:572-627
             if (i >= p) {
                 double obp = 0.0, otr = 0.0;
                 int64_t q = i - p;
-                if (q >= 1) bptr(r.in[0][q], r.in[1][q], r.in[2][q], r.in[2][q - 1], obp, otr);
+                if (q >= 1) bptr(tp[4 * k], tp[4 * k + 1], tp[4 * k + 2], tp[4 * k + 3], obp, otr);
                 sb[k] -= obp; st[k] -= otr;
             }
             if (i >= p - 1 && st[k] != 0.0) a[k] = sb[k] / st[k]; else ok = false;
@@ -250,10 +263,16 @@ struct UltoscOp { // momentum.rs:572-627
 struct MfiOp { // momentum.rs:286-342
     static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume
     static constexpr int SEQ_ID = 25;
+    static constexpr int NTAP = 7; // high, low, close, volume at i-p; high, low, close at i-p-1
+    static constexpr int TAP_COL[7] = {0, 1, 2, 3, 0, 1, 2};
     int64_t p;
     double pos, neg, prev_tp;
     __device__ void init(const Row<4> &) { pos = neg = 0.0; prev_tp = 0.0; }
-    __device__ void step(const Row<4> &r, int64_t i, const double (&x)[4], double (&y)[1]) {
+    __device__ void tap_lags(int64_t (&lag)[7]) const {
+        for (int k = 0; k < 4; k++) lag[k] = p > 0 ? p : 0;
+        for (int k = 4; k < 7; k++) lag[k] = p > 0 ? p + 1 : 0;
+    }
+    __device__ void step(const Row<4> &, int64_t i, const double (&x)[4], const double (&lagv)[7], double (&y)[1]) {
         y[0] = pq_null();
         double tp = (x[0] + x[1] + x[2]) / 3.0;
         double mf = tp * x[3];
@@ -263,9 +282,9 @@ struct MfiOp { // momentum.rs:286-342
             if (i >= p) {
                 int64_t q = i - p;
                 if (q > 0) {
-                    double tq = (r.in[0][q] + r.in[1][q] + r.in[2][q]) / 3.0;
-                    double tq1 = (r.in[0][q - 1] + r.in[1][q - 1] + r.in[2][q - 1]) / 3.0;
-                    double mq = tq * r.in[3][q];
+                    double tq = (lagv[0] + lagv[1] + lagv[2]) / 3.0;
+                    double tq1 = (lagv[4] + lagv[5] + lagv[6]) / 3.0;
+                    double mq = tq * lagv[3];
                     if (tq > tq1) pos -= mq;
                     else if (tq < tq1) neg -= mq;
                 }
@@ -333,16 +352,19 @@ struct DmRawOp {
 struct SmaTpOp { // momentum.rs:148-158: calc_sma(tp) on a null-free slice; the lagged tp is recomputed
     static constexpr int NIN = 3, NOUT = 1;
     static constexpr int SEQ_ID = 31;
+    static constexpr int NTAP = 3;
+    static constexpr int TAP_COL[3] = {0, 1, 2};
     int64_t p;
     double sum, denom;
     bool dead;
     __device__ void init(const Row<3> &r) { dead = (p <= 0 || r.len < p); sum = 0.0; denom = 1.0 / (double)p; }
-    __device__ void step(const Row<3> &r, int64_t i, const double (&x)[3], double (&y)[1]) {
+    __device__ void tap_lags(int64_t (&lag)[3]) const { lag[0] = lag[1] = lag[2] = dead ? 0 : p; }
+    __device__ void step(const Row<3> &, int64_t i, const double (&x)[3], const double (&tp)[3], double (&y)[1]) {
         y[0] = pq_null();
         if (dead) return;
         sum += (x[0] + x[1] + x[2]) / 3.0;
         if (i < p - 1) return;
-        if (i >= p) { int64_t q = i - p; sum -= (r.in[0][q] + r.in[1][q] + r.in[2][q]) / 3.0; }
+        if (i >= p) sum -= (tp[0] + tp[1] + tp[2]) / 3.0;
         y[0] = sum * denom;
     }
 };

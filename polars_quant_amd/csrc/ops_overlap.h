@@ -7,10 +7,15 @@
 struct SmaOp { // overlap.rs:871-937
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 1;
+    static constexpr int NTAP = 1;
+    static constexpr int TAP_COL[1] = {0};
     int64_t p;
     SmaCore c;
     __device__ void init(const Row<1> &r) { c.init(p, r.len); }
-    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) { y[0] = c.step(r.in[0], t, x[0]); }
+    __device__ void tap_lags(int64_t (&lag)[1]) const { lag[0] = c.dead ? 0 : p; }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], const double (&tp)[1], double (&y)[1]) {
+        y[0] = c.step(r.in[0], t, x[0], tp[0]);
+    }
 };
 
 struct EmaOp { // overlap.rs:660-730
@@ -25,25 +30,31 @@ struct EmaOp { // overlap.rs:660-730
 struct BbandsOp { // overlap.rs:47-116
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int SEQ_ID = 3;
+    static constexpr int NTAP = 1;
+    static constexpr int TAP_COL[1] = {0};
     int64_t p;
     double up, dn;
     int64_t count;
     double sum, sum_sq;
-    bool dead, started;
+    bool dead;
+    Regular reg;
     ValidCursor tail;
     __device__ void init(const Row<1> &r) {
         dead = (p <= 0 || r.len < p);
-        count = 0; sum = 0.0; sum_sq = 0.0; started = false;
+        count = 0; sum = 0.0; sum_sq = 0.0; reg.init();
     }
-    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[3]) {
+    __device__ void tap_lags(int64_t (&lag)[1]) const { lag[0] = dead ? 0 : p; }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], const double (&tp)[1], double (&y)[3]) {
         y[0] = y[1] = y[2] = pq_null();
         double v = x[0];
         if (dead || pq_isnull(v)) return;
-        if (!started) { tail.start(t); started = true; }
+        if (reg.first < 0) tail.start(t);
+        bool regular = reg.push(t);
         count += 1; sum += v; sum_sq += v * v;
         if (count < p) return;
         if (count > p) {
-            double old = tail.pop(r.in[0]);
+            double old;
+            if (regular) { old = tp[0]; tail.idx = t - p + 1; } else old = tail.pop(r.in[0]);
             sum -= old; sum_sq -= old * old; count -= 1;
         }
         double mean = sum / (double)p;
@@ -152,25 +163,31 @@ struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e
 struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 7;
+    static constexpr int NTAP = 1;
+    static constexpr int TAP_COL[1] = {0};
     int64_t p, count;
     double denominator, numerator;
-    bool dead, started;
+    bool dead;
+    Regular reg;
     ValidCursor tail;
     __device__ void init(const Row<1> &r) {
         dead = (p <= 0 || r.len < p);
         denominator = (double)(p * (p + 1) / 2);
-        numerator = 0.0; count = 0; started = false;
+        numerator = 0.0; count = 0; reg.init();
     }
-    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
+    __device__ void tap_lags(int64_t (&lag)[1]) const { lag[0] = dead ? 0 : p; }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], const double (&tp)[1], double (&y)[1]) {
         y[0] = pq_null();
         double v = x[0];
         if (dead || pq_isnull(v)) return;
-        if (!started) { tail.start(t); started = true; }
+        if (reg.first < 0) tail.start(t);
+        bool regular = reg.push(t);
         count += 1;
         numerator += ((double)count) * v;
         if (count < p) return;
         if (count > p) {
-            double old = tail.pop(r.in[0]);
+            double old;
+            if (regular) { old = tp[0]; tail.idx = t - p + 1; } else old = tail.pop(r.in[0]);
             numerator -= ((double)p) * old;
             count -= 1;
         }
@@ -181,6 +198,8 @@ struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
 struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 8;
+    static constexpr int NTAP = 3;
+    static constexpr int TAP_COL[3] = {0, 0, 0};
     int64_t p;
     int64_t count;    // pass-1 count (saturates at p)
     int64_t j;        // number of valid values seen before the current one
@@ -188,22 +207,25 @@ struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
     int64_t c2;       // pass-2 count
     double kama, sum2;
     bool dead;
+    Regular reg;
     ValidCursor cur_a; // x[j-p]      : window.pop_front()
     ValidCursor cur_b; // x[j-p+1]    : newer end of the popped diff
     ValidCursor cur_c; // x[j-2p+1]   : older end of the popped diff (once that diff is a p-lag diff)
-    int64_t first_idx;
     __device__ void init(const Row<1> &r) {
         dead = (p <= 1 || r.len < p); // p == 1: the reference pops an empty VecDeque and aborts (:775)
-        count = 0; j = 0; sum = 0.0; x0 = 0.0; c2 = 0; kama = 0.0; sum2 = 0.0; first_idx = -1;
+        count = 0; j = 0; sum = 0.0; x0 = 0.0; c2 = 0; kama = 0.0; sum2 = 0.0; reg.init();
     }
-    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
+    __device__ void tap_lags(int64_t (&lag)[3]) const {
+        lag[0] = dead ? 0 : p; lag[1] = dead ? 0 : p - 1; lag[2] = dead ? 0 : 2 * p - 1;
+    }
+    __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], const double (&tp)[3], double (&y)[1]) {
         y[0] = pq_null();
         double v = x[0];
         if (dead || pq_isnull(v)) return;
         const double *col = r.in[0];
-        double er;
+        bool regular = reg.push(t);
         if (count == 0) { // :760-764
-            count = 1; x0 = v; first_idx = t; j = 1;
+            count = 1; x0 = v; j = 1;
             cur_a.start(t); cur_c.start(t);
             return;
         }
@@ -214,14 +236,22 @@ struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
             j += 1;
             return;
         }
-        // :773-779
-        double diff_abs = fabs(v - cur_a.pop(col));
-        // popped diff has compacted index k = j-p+1: |x_k - x_0| while k < p, else |x_k - x_{k-p}|
+        // :773-779; the popped diff has compacted index k = j-p+1: |x_k - x_0| while k < p, else |x_k - x_{k-p}|
         int64_t k = j - p + 1;
-        double xk = cur_b.pop(col);
-        double popped = (k < p) ? fabs(xk - x0) : fabs(xk - cur_c.pop(col));
+        double xa, xk, xc = 0.0;
+        if (regular) {
+            xa = tp[0]; cur_a.idx = t - p + 1;
+            xk = tp[1]; cur_b.idx = t - p + 2;
+            if (k >= p) { xc = tp[2]; cur_c.idx = t - 2 * p + 2; }
+        } else {
+            xa = cur_a.pop(col);
+            xk = cur_b.pop(col);
+            if (k >= p) xc = cur_c.pop(col);
+        }
+        double diff_abs = fabs(v - xa);
+        double popped = (k < p) ? fabs(xk - x0) : fabs(xk - xc);
         sum += diff_abs - popped;
-        er = diff_abs / sum;
+        double er = diff_abs / sum;
         j += 1;
         // pass 2 (:815-852)
         double sc_sqrt = er * (2.0 / 3.0 - 2.0 / 31.0) + 2.0 / 31.0;
@@ -344,20 +374,34 @@ struct MavpSelOp {
     static constexpr int NIN = 2, NOUT = 1; // real (nulls already -> 0.0), periods
     static constexpr int SEQ_ID = 100 + Inner::SEQ_ID;
     static constexpr bool MASKED = true;
+    static constexpr int NTAP = NTap<Inner>::value; // the inner MA's lag taps all read column 0
+    static constexpr int TAP_COL[3] = {0, 0, 0};
     int64_t P, minp, maxp;
     Inner inner;
     __device__ void init(const Row<2> &r) {
         Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
         inner.init(r1);
     }
+    __device__ void tap_lags(int64_t (&lag)[NTAP > 0 ? NTAP : 1]) const {
+        if constexpr (NTAP > 0) inner.tap_lags(lag);
+    }
+    __device__ double pick(int64_t t, double per, double ma) const {
+        int64_t pi = (int64_t)n0(per);
+        if (pi < minp) pi = minp;
+        if (pi > maxp) pi = maxp;
+        return (pi != P) ? pq_skip() : ((t >= maxp - 1) ? ma : pq_null());
+    }
     __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
         Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
         double xi[1] = {x[0]}, yi[1];
-        inner.step(r1, t, xi, yi);
-        int64_t pi = (int64_t)n0(x[1]);
-        if (pi < minp) pi = minp;
-        if (pi > maxp) pi = maxp;
-        y[0] = (pi != P) ? pq_skip() : ((t >= maxp - 1) ? yi[0] : pq_null());
+        if constexpr (NTAP == 0) inner.step(r1, t, xi, yi);
+        y[0] = pick(t, x[1], yi[0]);
+    }
+    __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], const double (&tp)[NTAP > 0 ? NTAP : 1], double (&y)[1]) {
+        Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
+        double xi[1] = {x[0]}, yi[1];
+        if constexpr (NTAP > 0) inner.step(r1, t, xi, tp, yi);
+        y[0] = pick(t, x[1], yi[0]);
     }
 };
 // select rows of a materialised MA(P) column (used for matypes that are not a single SEQ op)

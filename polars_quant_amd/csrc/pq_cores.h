@@ -45,11 +45,25 @@ struct ValidCursor {
     }
 };
 
+// Tracks whether every row since the first valid one has been valid.  While that holds ("regular"), the
+// oldest value of a p-window is simply row t-p and arrives through a prefetched lag tap; after the first
+// interior null the window is walked with ValidCursors instead (exact either way).
+struct Regular {
+    int64_t first, seen;
+    __device__ void init() { first = -1; seen = 0; }
+    __device__ bool push(int64_t t) { // call once per valid row; returns regular?
+        if (first < 0) first = t;
+        seen += 1;
+        return (t - first + 1) == seen;
+    }
+};
+
 // overlap.rs:871-937 calc_sma: running sum, +new then (count > p) -old, out = sum * (1/p).
 struct SmaCore {
     int64_t p, count;
     double denom, sum;
-    bool dead, started;
+    bool dead;
+    Regular reg;
     ValidCursor tail;
     __device__ void init(int64_t p_, int64_t n) {
         p = p_;
@@ -57,16 +71,20 @@ struct SmaCore {
         denom = 1.0 / (double)p;
         count = 0;
         sum = 0.0;
-        started = false;
+        reg.init();
     }
-    __device__ double step(const double *col, int64_t t, double v) {
+    // tap = col[t - p] (prefetched)
+    __device__ double step(const double *col, int64_t t, double v, double tap) {
         if (dead || pq_isnull(v)) return pq_null();
-        if (!started) { tail.start(t); started = true; }
+        if (reg.first < 0) tail.start(t);
+        bool regular = reg.push(t);
         count += 1;
         sum += v;
         if (count < p) return pq_null();
         if (count > p) {
-            sum -= tail.pop(col);
+            double old;
+            if (regular) { old = tap; tail.idx = t - p + 1; } else old = tail.pop(col);
+            sum -= old;
             count -= 1;
         }
         return sum * denom;
@@ -110,27 +128,46 @@ struct RollExt {
     int64_t p, j;      // j = number of valid values seen (1-based index of the newest)
     double best;
     int64_t best_j;    // 1-based valid-index of the current extremum
+    Regular reg;
     __device__ void init(int64_t p_) {
         p = p_;
         j = 0;
         best = 0.0;
         best_j = 0;
+        reg.init();
     }
     __device__ static bool beats(double a, double b) { return IS_MAX ? (a >= b) : (a <= b); }
     __device__ double step(const double *col, int64_t t, double v) {
+        bool regular = reg.push(t);
         j += 1;
         if (j == 1 || beats(v, best)) {
             best = v;
             best_j = j;
-        } else if (p > 0 && best_j == j - p) { // expired: rescan the last p valid values
+        } else if (p > 0 && best_j == j - p) { // expired: rescan the last p valid values, newest first
             best = v;
             best_j = j;
-            int64_t jj = j, i = t;
-            for (int64_t k = 1; k < p; k++) {
-                do { i--; } while (pq_isnull(col[i]));
-                jj--;
-                double w = col[i];
-                if (IS_MAX ? (w > best) : (w < best)) { best = w; best_j = jj; }
+            if (regular) { // rows t-1 .. t-p+1, independent loads in batches of 8
+                int64_t k = 1;
+                for (; k + 8 <= p; k += 8) {
+                    double w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) w[u] = col[t - k - u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (IS_MAX ? (w[u] > best) : (w[u] < best)) { best = w[u]; best_j = j - k - u; }
+                }
+                for (; k < p; k++) {
+                    double w = col[t - k];
+                    if (IS_MAX ? (w > best) : (w < best)) { best = w; best_j = j - k; }
+                }
+            } else {
+                int64_t jj = j, i = t;
+                for (int64_t k = 1; k < p; k++) {
+                    do { i--; } while (pq_isnull(col[i]));
+                    jj--;
+                    double w = col[i];
+                    if (IS_MAX ? (w > best) : (w < best)) { best = w; best_j = jj; }
+                }
             }
         }
         return best;

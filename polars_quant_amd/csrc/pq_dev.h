@@ -100,13 +100,24 @@ struct IsMasked { static constexpr bool value = false; };
 template <class Op>
 struct IsMasked<Op, decltype((void)Op::MASKED)> { static constexpr bool value = Op::MASKED; };
 
+template <class Op, class = void>
+struct NTap { static constexpr int value = 0; };
+template <class Op>
+struct NTap<Op, decltype((void)Op::NTAP)> { static constexpr int value = Op::NTAP; };
+
 // SEQ body for one lane.  Op contract:
 //   static constexpr int NIN, NOUT;   [static constexpr bool MASKED = true;  outputs may be pq_skip()]
 //   __device__ void init(const Row<NIN>& r);                       // once per series
 //   __device__ void step(const Row<NIN>& r, int64_t t, const double (&x)[NIN], double (&y)[NOUT]);
+// Lag taps (optional): an op that needs input column TAP_COL[i] at row t - lag_i declares
+//   static constexpr int NTAP;  static constexpr int TAP_COL[NTAP];
+//   __device__ void tap_lags(int64_t (&lag)[NTAP]) const;          // after init; lag <= 0 disables a tap
+//   __device__ void step(r, t, x, const double (&tap)[NTAP], y);
+// and gets the lagged values prefetched with the chunk instead of paying a dependent load per row.
 template <class Op>
 __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double *const *outp, const Dims &d, int64_t s) {
-    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, CH = SeqChunk<NIN>::value;
+    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, CH = SeqChunk<NIN>::value, NT = NTap<Op>::value;
+    constexpr int NTA = NT > 0 ? NT : 1;
     constexpr bool MASKED = IsMasked<Op>::value;
     Row<NIN> r;
     r.len = d.len;
@@ -116,34 +127,54 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
 #pragma unroll
     for (int k = 0; k < NOUT; k++) o[k] = outp[k] + s * d.stride;
     op.init(r);
+    int64_t lag[NTA];
+    if constexpr (NT > 0) op.tap_lags(lag);
     const int64_t T = d.len;
     int64_t t0 = 0;
-    double xb[NIN][CH];
-    if (T >= CH) { // prologue: first chunk
+    double xb[NIN][CH], tb[NTA][CH];
+    auto load_chunk = [&](int64_t base) {
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
-            for (int j = 0; j < CH; j++) xb[k][j] = r.in[k][j];
-    }
+            for (int j = 0; j < CH; j++) xb[k][j] = r.in[k][base + j];
+        if constexpr (NT > 0) {
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    int64_t q = base + j - lag[i];
+                    tb[i][j] = (lag[i] > 0 && q >= 0) ? r.in[Op::TAP_COL[i]][q] : 0.0;
+                }
+        }
+    };
+    if (T >= CH) load_chunk(0); // prologue: first chunk
     for (; t0 + CH <= T; t0 += CH) {
-        double xc[NIN][CH];
+        double xc[NIN][CH], tc[NTA][CH];
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
             for (int j = 0; j < CH; j++) xc[k][j] = xb[k][j];
-        if (t0 + 2 * CH <= T) { // issue the next chunk's loads before the dependent recurrence of this one
+        if constexpr (NT > 0) {
 #pragma unroll
-            for (int k = 0; k < NIN; k++)
+            for (int i = 0; i < NT; i++)
 #pragma unroll
-                for (int j = 0; j < CH; j++) xb[k][j] = r.in[k][t0 + CH + j];
+                for (int j = 0; j < CH; j++) tc[i][j] = tb[i][j];
         }
+        if (t0 + 2 * CH <= T) load_chunk(t0 + CH); // next chunk's loads go out before this chunk's dependent recurrence
         double yb[NOUT][CH];
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             double x[NIN], y[NOUT];
 #pragma unroll
             for (int k = 0; k < NIN; k++) x[k] = xc[k][j];
-            op.step(r, t0 + j, x, y);
+            if constexpr (NT > 0) {
+                double tp[NTA];
+#pragma unroll
+                for (int i = 0; i < NT; i++) tp[i] = tc[i][j];
+                op.step(r, t0 + j, x, tp, y);
+            } else {
+                op.step(r, t0 + j, x, y);
+            }
 #pragma unroll
             for (int k = 0; k < NOUT; k++) yb[k][j] = y[k];
         }
@@ -157,7 +188,17 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
         double x[NIN], y[NOUT];
 #pragma unroll
         for (int k = 0; k < NIN; k++) x[k] = r.in[k][t0];
-        op.step(r, t0, x, y);
+        if constexpr (NT > 0) {
+            double tp[NTA];
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                int64_t q = t0 - lag[i];
+                tp[i] = (lag[i] > 0 && q >= 0) ? r.in[Op::TAP_COL[i]][q] : 0.0;
+            }
+            op.step(r, t0, x, tp, y);
+        } else {
+            op.step(r, t0, x, y);
+        }
 #pragma unroll
         for (int k = 0; k < NOUT; k++)
             if (!MASKED || !pq_isskip(y[k])) o[k][t0] = y[k];
