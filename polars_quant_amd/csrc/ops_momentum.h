@@ -163,6 +163,27 @@ struct CmoOp { // momentum.rs:181-223: rolling SUMS of up/down moves; the lagged
             y[0] = (total == 0.0) ? 0.0 : 100.0 * (su - sd) / total;
         }
     }
+    Ring w; // last p+1 inputs
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p + 1 : 1; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); w = ra.make(p + 1); }
+    __device__ void step_lds(int64_t i, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0) return;
+        double u = 0.0, d = 0.0;
+        if (i >= 1) updown(x[0], prev, u, d);
+        prev = x[0];
+        su += u; sd += d;
+        if (i >= p) {
+            double ou = 0.0, od = 0.0;
+            if (i - p >= 1) updown(w.get((int)p), w.get((int)p + 1), ou, od);
+            su -= ou; sd -= od;
+        }
+        w.push(x[0]);
+        if (i >= p - 1) {
+            double total = su + sd;
+            y[0] = (total == 0.0) ? 0.0 : 100.0 * (su - sd) / total;
+        }
+    }
 };
 
 struct RsiOp { // momentum.rs:507-541
@@ -258,6 +279,29 @@ struct UltoscOp { // momentum.rs:572-627
         }
         if (ok) y[0] = 100.0 * (4.0 * a[0] + 2.0 * a[1] + a[2]) / 7.0;
     }
+    Ring wb, wt; // bp / tr of the last max(p1,p2,p3) rows
+    __host__ __device__ int64_t pmax() const { int64_t a = p1 > p2 ? p1 : p2; return a > p3 ? a : p3; }
+    __host__ __device__ int64_t ring_slots() const { return pmax() > 0 ? 2 * pmax() : 2; }
+    __device__ void init_lds(const Row<3> &r, RingAlloc &ra) { init(r); wb = ra.make(pmax()); wt = ra.make(pmax()); }
+    __device__ void step_lds(int64_t i, const double (&x)[3], double (&y)[1]) {
+        y[0] = pq_null();
+        if (p1 <= 0 || p2 <= 0 || p3 <= 0) return;
+        double bp = 0.0, tr = 0.0;
+        if (i >= 1) bptr(x[0], x[1], x[2], prev_c, bp, tr);
+        prev_c = x[2];
+        const int64_t ps[3] = {p1, p2, p3};
+        double a[3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            sb[k] += bp; st[k] += tr;
+            int64_t p = ps[k];
+            if (i >= p) { sb[k] -= wb.get((int)p); st[k] -= wt.get((int)p); } // bp/tr of row i-p (row 0 holds 0.0)
+            if (i >= p - 1 && st[k] != 0.0) a[k] = sb[k] / st[k]; else ok = false;
+        }
+        wb.push(bp); wt.push(tr);
+        if (ok) y[0] = 100.0 * (4.0 * a[0] + 2.0 * a[1] + a[2]) / 7.0;
+    }
 };
 
 struct MfiOp { // momentum.rs:286-342
@@ -285,6 +329,7 @@ struct MfiOp { // momentum.rs:286-342
                     double tq = (lagv[0] + lagv[1] + lagv[2]) / 3.0;
                     double tq1 = (lagv[4] + lagv[5] + lagv[6]) / 3.0;
                     double mq = tq * lagv[3];
+                    if (p == 0) { tq = tp; tq1 = prev_tp; mq = mf; } // the row just added is removed again
                     if (tq > tq1) pos -= mq;
                     else if (tq < tq1) neg -= mq;
                 }
@@ -293,6 +338,31 @@ struct MfiOp { // momentum.rs:286-342
             }
         }
         prev_tp = tp;
+    }
+    Ring wtp, wmf; // typical price / money flow of the last p+1 rows
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? 2 * (p + 1) : 2; }
+    __device__ void init_lds(const Row<4> &r, RingAlloc &ra) { init(r); wtp = ra.make(p + 1); wmf = ra.make(p + 1); }
+    __device__ void step_lds(int64_t i, const double (&x)[4], double (&y)[1]) {
+        y[0] = pq_null();
+        double tp = (x[0] + x[1] + x[2]) / 3.0;
+        double mf = tp * x[3];
+        if (i >= 1) {
+            if (tp > prev_tp) pos += mf;
+            else if (tp < prev_tp) neg += mf;
+            if (p >= 0 && i >= p) {
+                int64_t q = i - p;
+                if (q > 0) {
+                    double tq = tp, tq1 = prev_tp, mq = mf; // p == 0: the row just added is removed again
+                    if (p > 0) { tq = wtp.get((int)p); tq1 = wtp.get((int)p + 1); mq = wmf.get((int)p); }
+                    if (tq > tq1) pos -= mq;
+                    else if (tq < tq1) neg -= mq;
+                }
+                if (neg == 0.0) y[0] = 100.0;
+                else { double mr = pos / neg; y[0] = 100.0 - (100.0 / (1.0 + mr)); }
+            }
+        }
+        prev_tp = tp;
+        if (p > 0) { wtp.push(tp); wmf.push(mf); }
     }
 };
 
@@ -365,6 +435,19 @@ struct SmaTpOp { // momentum.rs:148-158: calc_sma(tp) on a null-free slice; the 
         sum += (x[0] + x[1] + x[2]) / 3.0;
         if (i < p - 1) return;
         if (i >= p) sum -= (tp[0] + tp[1] + tp[2]) / 3.0;
+        y[0] = sum * denom;
+    }
+    Ring w;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
+    __device__ void init_lds(const Row<3> &r, RingAlloc &ra) { init(r); w = ra.make(p); }
+    __device__ void step_lds(int64_t i, const double (&x)[3], double (&y)[1]) {
+        y[0] = pq_null();
+        if (dead) return;
+        double tp = (x[0] + x[1] + x[2]) / 3.0;
+        sum += tp;
+        double old = w.swap(tp);
+        if (i < p - 1) return;
+        if (i >= p) sum -= old;
         y[0] = sum * denom;
     }
 };

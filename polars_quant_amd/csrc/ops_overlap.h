@@ -16,6 +16,10 @@ struct SmaOp { // overlap.rs:871-937
     __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], const double (&tp)[1], double (&y)[1]) {
         y[0] = c.step(r.in[0], t, x[0], tp[0]);
     }
+    Ring w;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { c.init(p, r.len); w = ra.make(p); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.step_ring(w, x[0]); }
 };
 
 struct EmaOp { // overlap.rs:660-730
@@ -57,6 +61,22 @@ struct BbandsOp { // overlap.rs:47-116
             if (regular) { old = tp[0]; tail.idx = t - p + 1; } else old = tail.pop(r.in[0]);
             sum -= old; sum_sq -= old * old; count -= 1;
         }
+        double mean = sum / (double)p;
+        double variance = (sum_sq / (double)p) - mean * mean;
+        double sd = sqrt(fmax(variance, 0.0));
+        y[0] = mean + up * sd; y[1] = mean; y[2] = mean - dn * sd;
+    }
+    Ring w;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); w = ra.make(p); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[3]) {
+        y[0] = y[1] = y[2] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        count += 1; sum += v; sum_sq += v * v;
+        double old = w.swap(v);
+        if (count < p) return;
+        if (count > p) { sum -= old; sum_sq -= old * old; count -= 1; }
         double mean = sum / (double)p;
         double variance = (sum_sq / (double)p) - mean * mean;
         double sd = sqrt(fmax(variance, 0.0));
@@ -193,6 +213,20 @@ struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
         }
         y[0] = numerator / denominator;
     }
+    Ring w;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); w = ra.make(p); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        count += 1;
+        numerator += ((double)count) * v;
+        double old = w.swap(v);
+        if (count < p) return;
+        if (count > p) { numerator -= ((double)p) * old; count -= 1; }
+        y[0] = numerator / denominator;
+    }
 };
 
 struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
@@ -261,6 +295,30 @@ struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
         kama = fma(sc, v - kama, kama);
         y[0] = kama;
     }
+    Ring w; // last 2p valid values
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? 2 * p : 1; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); w = ra.make(2 * p); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
+        y[0] = pq_null();
+        double v = x[0];
+        if (dead || pq_isnull(v)) return;
+        if (count == 0) { count = 1; x0 = v; j = 1; w.push(v); return; }
+        if (count < p) { count += 1; sum += fabs(v - x0); j += 1; w.push(v); return; }
+        int64_t k = j - p + 1;
+        double xa = w.get((int)p), xk = w.get((int)p - 1);
+        double diff_abs = fabs(v - xa);
+        double popped = (k < p) ? fabs(xk - x0) : fabs(xk - w.get((int)(2 * p - 1)));
+        sum += diff_abs - popped;
+        double er = diff_abs / sum;
+        j += 1;
+        w.push(v);
+        double sc_sqrt = er * (2.0 / 3.0 - 2.0 / 31.0) + 2.0 / 31.0;
+        double sc = sc_sqrt * sc_sqrt;
+        if (c2 < p) { c2 += 1; sum2 += v; return; }
+        if (c2 == p) { c2 += 1; kama = sum2 / (double)p; y[0] = kama; return; }
+        kama = fma(sc, v - kama, kama);
+        y[0] = kama;
+    }
 };
 
 struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires => cumulative min)
@@ -278,6 +336,16 @@ struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires =
         if (!any || v <= mn) { mn = v; any = true; }
         y[0] = (m + mn) / 2.0;
     }
+    Ring w;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); w = ra.make(p); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
+        double v = x[0];
+        if (p <= 0 || pq_isnull(v)) { y[0] = pq_null(); return; }
+        double m = mx.step_ring(w, v);
+        if (!any || v <= mn) { mn = v; any = true; }
+        y[0] = (m + mn) / 2.0;
+    }
 };
 
 struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either input -> null (D-7)
@@ -292,6 +360,16 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
         if (p <= 0) { y[0] = pq_null(); return; } // decision D-7b
         if (!pq_isnull(x[0])) hm = mx.step(r.in[0], t, x[0]);
         if (!pq_isnull(x[1])) lm = mn.step(r.in[1], t, x[1]);
+        y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
+    }
+    Ring wh, wl;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? 2 * p : 2; }
+    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) { init(r); wh = ra.make(p); wl = ra.make(p); }
+    __device__ void step_lds(int64_t, const double (&x)[2], double (&y)[1]) {
+        if (p <= 0) { y[0] = pq_null(); return; }
+        double hm = pq_null(), lm = pq_null();
+        if (!pq_isnull(x[0])) hm = mx.step_ring(wh, x[0]);
+        if (!pq_isnull(x[1])) lm = mn.step_ring(wl, x[1]);
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
     }
 };
@@ -401,6 +479,20 @@ struct MavpSelOp {
         Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
         double xi[1] = {x[0]}, yi[1];
         if constexpr (NTAP > 0) inner.step(r1, t, xi, tp, yi);
+        y[0] = pick(t, x[1], yi[0]);
+    }
+    // LDS body: forward to the inner op's ring variant when it has one
+    __host__ __device__ int64_t ring_slots() const {
+        if constexpr (HasRings<Inner>::value) return inner.ring_slots(); else return 0;
+    }
+    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
+        Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
+        if constexpr (HasRings<Inner>::value) inner.init_lds(r1, ra); else inner.init(r1);
+    }
+    __device__ void step_lds(int64_t t, const double (&x)[2], double (&y)[1]) {
+        double xi[1] = {x[0]}, yi[1];
+        if constexpr (HasRings<Inner>::value) inner.step_lds(t, xi, yi);
+        else { Row<1> r1; r1.in[0] = nullptr; r1.len = 0; inner.step(r1, t, xi, yi); }
         y[0] = pick(t, x[1], yi[0]);
     }
 };

@@ -89,6 +89,19 @@ struct SmaCore {
         }
         return sum * denom;
     }
+    // LDS-ring variant: the ring holds the last p valid values, so the popped value is ring.swap(v)
+    __device__ double step_ring(Ring &w, double v) {
+        if (dead || pq_isnull(v)) return pq_null();
+        count += 1;
+        sum += v;
+        double old = w.swap(v);
+        if (count < p) return pq_null();
+        if (count > p) {
+            sum -= old;
+            count -= 1;
+        }
+        return sum * denom;
+    }
 };
 
 // D-1 calc_rma (Wilder) over a null-free slice: None for i < p-1, seed = mean(x[0..p)) at i = p-1,
@@ -170,6 +183,27 @@ struct RollExt {
                 }
             }
         }
+        return best;
+    }
+    // LDS-ring variant (ring depth >= p).  A lazy rescan is hopeless in SIMT -- with 64 lanes some lane's extremum
+    // expires on almost every row, so the whole wave would pay the dependent rescan loop each time; instead every row
+    // takes the extremum of the min(j, p) newest values straight from the ring: p independent LDS reads + p max/min.
+    // The result is the same value the reference's monotonic deque holds at its front.
+    __device__ double step_ring(Ring &w, double v) {
+        j += 1;
+        best = v;
+        if (p > 0) {
+            int n = (int)(j < p ? j : p);
+            int k = w.pos;
+            for (int u = 1; u < n; u++) {
+                k = (k == 0) ? w.depth - 1 : k - 1;
+                double x = w.base[k * 64];
+                best = IS_MAX ? fmax(best, x) : fmin(best, x);
+            }
+        } else { // p <= 0 never expires anything: running extremum (callers reject p <= 0 before this)
+            best = v;
+        }
+        w.push(v);
         return best;
     }
 };

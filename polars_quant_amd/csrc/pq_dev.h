@@ -205,17 +205,210 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SEQ body, LDS-staged (the fast path).  The per-lane gather above costs one L1 tag lookup per lane and
+// 8-byte element: a 64-lane load touches 64 different cache lines and the kernel becomes bound by the
+// texture-addresser / L1 rate, not by HBM.  Here the wavefront instead moves a whole tile
+// [64 series][K rows] per column with coalesced 16-byte accesses (K*8 contiguous bytes per series),
+// transposes it through LDS (row pitch K*8+8 bytes: conflict-free for the cooperative b128 writes and for
+// the per-lane b64 reads), and each lane then walks ITS OWN row of the tile in the reference's order.
+// Outputs take the same route back.  The next tile's global loads are in flight (in registers) while
+// the current tile is computed.  Rolling windows live in LDS rings ([slot][lane] layout), which also
+// makes them null-proof: only valid values are pushed.
+// One wavefront = one workgroup, so the barriers below only order this wave's own LDS traffic.
+struct Ring { // per-lane circular buffer in LDS; slot k of lane l at base + (k*64 + l)*8
+    double *base; // already offset by the lane
+    int depth, pos;
+    __device__ double get(int back) const { // value pushed `back` pushes ago (1 = newest); back <= depth
+        int k = pos - back;
+        if (k < 0) k += depth;
+        return base[k * 64];
+    }
+    __device__ void push(double v) {
+        base[pos * 64] = v;
+        pos = (pos + 1 == depth) ? 0 : pos + 1;
+    }
+    __device__ double swap(double v) { // store v, return the value pushed `depth` pushes ago
+        double old = base[pos * 64];
+        base[pos * 64] = v;
+        pos = (pos + 1 == depth) ? 0 : pos + 1;
+        return old;
+    }
+};
+struct RingAlloc {
+    double *next; // lane-offset base of the free region
+    __device__ Ring make(int64_t depth) {
+        Ring r;
+        r.base = next;
+        r.depth = depth > 0 ? (int)depth : 1;
+        r.pos = 0;
+        next += (size_t)r.depth * 64;
+        return r;
+    }
+};
+// ops with rolling windows add:   int64_t ring_slots() const;   void init_lds(const Row<NIN>&, RingAlloc&);
+//                                 void step_lds(int64_t t, const double (&x)[NIN], double (&y)[NOUT]);
+template <class Op, class = void>
+struct HasRings { static constexpr bool value = false; };
 template <class Op>
+struct HasRings<Op, decltype((void)&Op::ring_slots)> { static constexpr bool value = true; };
+
+template <class Op>
+struct SeqTile {
+    static constexpr int K = (Op::NIN == 1 && Op::NOUT == 1) ? 16 : 8;   // rows per tile
+    static constexpr int NT = IsMasked<Op>::value ? Op::NIN : (Op::NIN > Op::NOUT ? Op::NIN : Op::NOUT);
+    static constexpr int ROWB = K * 8 + 8;                                 // LDS row pitch in bytes
+    static constexpr int TILE_BYTES = 64 * ROWB;
+    static constexpr int BYTES = NT * TILE_BYTES;
+};
+template <class Op>
+static inline size_t seq_lds_bytes(const Op &op) {
+    size_t b = SeqTile<Op>::BYTES;
+    if constexpr (HasRings<Op>::value) b += (size_t)op.ring_slots() * 512;
+    return b;
+}
+constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to the gather body
+
+// One wavefront == one workgroup: cross-lane LDS hand-offs only need this wave's own LDS operations to have
+// completed (the LDS queue is in order per wave).  __syncthreads() would also drain vmcnt, i.e. wait for the
+// prefetched global loads and the output stores of the previous tile on every tile -- exactly the latency the
+// prefetch is there to hide -- so the hand-off is an LDS-only wait that the compiler may not move memory
+// operations across.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <class Op>
+__device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
+                                            int64_t tile_s0, unsigned char *lds) {
+    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
+    constexpr int TB = SeqTile<Op>::TILE_BYTES;
+    constexpr int CPL = K / 2;      // 16-byte chunks (lanes) per series segment
+    constexpr int SPI = 64 / CPL;   // series covered by one wave-wide access
+    constexpr int NI = 64 / SPI;    // accesses per column tile
+    constexpr bool MASKED = IsMasked<Op>::value;
+    static_assert(NTap<Op>::value == 0 || HasRings<Op>::value, "an op with lag taps needs a ring variant for the LDS body");
+    const int lane = threadIdx.x;
+    const int64_t s = tile_s0 + lane;
+    const bool live = s < d.n;
+    const int64_t srow = live ? s : d.n - 1; // dead lanes shadow the last series (never stored)
+    const int csym = lane / CPL, cchunk = lane % CPL;
+    int64_t crow[NI]; // global row offsets of the series this lane helps to move
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        int64_t cs = tile_s0 + i * SPI + csym;
+        crow[i] = (cs < d.n ? cs : d.n - 1) * d.stride + cchunk * 2;
+    }
+    Row<NIN> r;
+    r.len = d.len;
+#pragma unroll
+    for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + srow * d.stride;
+    if constexpr (HasRings<Op>::value) {
+        RingAlloc ra{reinterpret_cast<double *>(lds + SeqTile<Op>::BYTES) + lane};
+        op.init_lds(r, ra);
+    } else {
+        op.init(r);
+    }
+    const int64_t T = d.len, nt = T / K;
+    double2 pre[NIN][NI];
+    auto prefetch = [&](int64_t t0) {
+#pragma unroll
+        for (int k = 0; k < NIN; k++)
+#pragma unroll
+            for (int i = 0; i < NI; i++) pre[k][i] = *reinterpret_cast<const double2 *>(inp[k] + crow[i] + t0);
+    };
+    unsigned char *my_row = lds + lane * ROWB;
+    unsigned char *co_row[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) co_row[i] = lds + (i * SPI + csym) * ROWB + cchunk * 16;
+    if (nt > 0) prefetch(0);
+    for (int64_t it = 0; it < nt; it++) {
+        const int64_t t0 = it * K;
+#pragma unroll
+        for (int k = 0; k < NIN; k++)
+#pragma unroll
+            for (int i = 0; i < NI; i++) { // two b64 stores: LDS rows are only 8-byte aligned
+                double *q = reinterpret_cast<double *>(co_row[i] + k * TB);
+                q[0] = pre[k][i].x;
+                q[1] = pre[k][i].y;
+            }
+        if (it + 1 < nt) prefetch(t0 + K);
+        lds_fence();
+        // one row at a time, NOT unrolled: every job of a suite grid runs different code, and K copies of each
+        // op body would thrash the instruction cache; the next row's inputs are read from LDS ahead of the step
+        double xn[NIN];
+#pragma unroll
+        for (int k = 0; k < NIN; k++) xn[k] = *reinterpret_cast<const double *>(my_row + k * TB);
+#pragma unroll 1
+        for (int j = 0; j < K; j++) {
+            double x[NIN], y[NOUT];
+#pragma unroll
+            for (int k = 0; k < NIN; k++) x[k] = xn[k];
+            if (j + 1 < K) {
+#pragma unroll
+                for (int k = 0; k < NIN; k++) xn[k] = *reinterpret_cast<const double *>(my_row + k * TB + (j + 1) * 8);
+            }
+            if constexpr (HasRings<Op>::value) op.step_lds(t0 + j, x, y);
+            else op.step(r, t0 + j, x, y);
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int k = 0; k < NOUT; k++)
+                    if (live && !pq_isskip(y[k])) outp[k][s * d.stride + t0 + j] = y[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NOUT; k++) *reinterpret_cast<double *>(my_row + k * TB + j * 8) = y[k];
+            }
+        }
+        lds_fence();
+        if constexpr (!MASKED) {
+#pragma unroll
+            for (int k = 0; k < NOUT; k++)
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
+                    double2 v = make_double2(q[0], q[1]);
+                    if (tile_s0 + i * SPI + csym < d.n) *reinterpret_cast<double2 *>(outp[k] + crow[i] + t0) = v;
+                }
+            lds_fence();
+        }
+    }
+    if (live) { // ragged tail: fewer than K rows left
+        for (int64_t t = nt * K; t < T; t++) {
+            double x[NIN], y[NOUT];
+#pragma unroll
+            for (int k = 0; k < NIN; k++) x[k] = r.in[k][t];
+            if constexpr (HasRings<Op>::value) op.step_lds(t, x, y);
+            else op.step(r, t, x, y);
+#pragma unroll
+            for (int k = 0; k < NOUT; k++)
+                if (!MASKED || !pq_isskip(y[k])) outp[k][s * d.stride + t] = y[k];
+        }
+    }
+}
+
+// 16-byte accesses need 16-byte aligned rows
+template <int NIN, int NOUT>
+static inline bool seq_cols_aligned(const pq_batch *b, const double *const *in, double *const *out) {
+    if (b->stride % 2) return false;
+    for (int k = 0; k < NIN; k++) if (reinterpret_cast<uintptr_t>(in[k]) % 16) return false;
+    for (int k = 0; k < NOUT; k++) if (reinterpret_cast<uintptr_t>(out[k]) % 16) return false;
+    return true;
+}
+
+template <class Op, bool LDS>
 __global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
-    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
-    if (s >= d.n) return;
-    run_seq(op, in.p, out.p, d, s);
+    if constexpr (LDS) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
+        run_seq_lds(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
+    } else {
+        const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+        if (s >= d.n) return;
+        run_seq(op, in.p, out.p, d, s);
+    }
 }
 
 // ---- recording hooks (implemented in suite.hip)
 // a recordable SEQ op carries `static constexpr int SEQ_ID` = its switch case in the job grid (suite.hip)
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout);
+                      int nin, double *const *out, int nout, size_t lds_bytes);
 struct RowThunk { // type-erased ROW launch for replay
     void (*launch)(const void *blob, hipStream_t stream);
     unsigned char blob[1200];
@@ -245,17 +438,20 @@ template <class Op>
 static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in,
                                    const OutCols<Op::NOUT> &out) {
     if (b->n_series == 0 || b->len == 0) return PQ_OK;
+    size_t lds = seq_lds_bytes(op);
+    bool use_lds = lds <= SEQ_LDS_LIMIT && seq_cols_aligned<Op::NIN, Op::NOUT>(b, in.p, out.p);
     if (ctx->rec) {
         if constexpr (HasSeqId<Op>::value) {
             static_assert(sizeof(Op) <= 512, "SEQ op too large for a job slot");
-            return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT);
+            return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");
             return PQ_ERR_UNSUPPORTED;
         }
     }
     dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
-    hipLaunchKernelGGL(seq_kernel<Op>, grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b));
+    if (use_lds) hipLaunchKernelGGL((seq_kernel<Op, true>), grid, dim3(SEQ_BLOCK), lds, ctx->stream, op, in, out, dims_of(b));
+    else hipLaunchKernelGGL((seq_kernel<Op, false>), grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b));
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }

@@ -18,6 +18,7 @@
 
 struct SeqJob { // device-visible
     int kind, nin, nout, cost;
+    unsigned lds_bytes, pad_; // 0 = run the gather body
     const double *in[5];
     double *out[3];
     alignas(8) unsigned char op[512];
@@ -25,12 +26,17 @@ struct SeqJob { // device-visible
 static_assert(sizeof(BtArgs) <= 512, "BtArgs must fit a job slot");
 
 struct Phase {
-    std::vector<SeqJob> seq;
+    std::vector<SeqJob> seq;   // sorted at finalize: [0, n_small) need <= SMALL_LDS bytes of LDS, the rest more
     std::vector<RowThunk> rows;
     SeqJob *d_seq = nullptr;
+    int n_small = 0;
+    unsigned lds_small = 0, lds_large = 0;
 };
+constexpr unsigned SMALL_LDS = 26 * 1024; // 6 single-wave workgroups per CU
 struct Recorder {
     pq_batch b;
+    hipStream_t aux[2] = {nullptr, nullptr}; // large-LDS SEQ grid / ROW launches run beside the main SEQ grid
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::vector<Phase> phases;
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
@@ -50,27 +56,30 @@ struct pq_suite {
     X(AtrOp<false>) X(AtrOp<true>) X(AdOp<false>) X(AdOp<true>) X(ObvOp) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>)
 
 __global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char jobs_lds[];
     const SeqJob &job = jobs[blockIdx.y];
-    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
-    if (s >= d.n) return;
+    const int64_t s0 = (int64_t)blockIdx.x * SEQ_BLOCK;
+    const int64_t s = s0 + threadIdx.x;
+    if (job.lds_bytes == 0 && s >= d.n) return; // gather bodies are per-lane; LDS bodies need the whole wave
     switch (job.kind) { // wave-uniform
 #define X(OP)                                                        \
     case OP::SEQ_ID: {                                               \
         OP op;                                                       \
         __builtin_memcpy(&op, job.op, sizeof(OP));                   \
-        run_seq(op, job.in, job.out, d, s);                          \
+        if (job.lds_bytes) run_seq_lds(op, job.in, job.out, d, s0, jobs_lds); \
+        else run_seq(op, job.in, job.out, d, s);                     \
     } break;
         SEQ_OPS(X)
 #undef X
     case SEQ_ID_BACKTEST: {
         BtArgs a;
         __builtin_memcpy(&a, job.op, sizeof(BtArgs));
-        backtest_body<false, false>(a, d, s);
+        if (s < d.n) backtest_body<false, false>(a, d, s);
     } break;
     case SEQ_ID_BACKTEST + 1: {
         BtArgs a;
         __builtin_memcpy(&a, job.op, sizeof(BtArgs));
-        backtest_body<true, false>(a, d, s);
+        if (s < d.n) backtest_body<true, false>(a, d, s);
     } break;
     default: break;
     }
@@ -122,12 +131,12 @@ static pq_status same_batch(Recorder &r, const pq_batch *b) {
 }
 
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout) {
+                      int nin, double *const *out, int nout, size_t lds_bytes) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
     SeqJob j;
     memset(&j, 0, sizeof j);
-    j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind);
+    j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind); j.lds_bytes = (unsigned)lds_bytes;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
     memcpy(j.op, op, op_bytes);
@@ -163,7 +172,17 @@ void rec_set_shared_out(pq_ctx *ctx, bool on) {
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
     for (Phase &p : r.phases) {
         if (p.seq.empty()) continue;
-        std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cost > b.cost; });
+        // small-LDS jobs first (one grid at 6 workgroups/CU), large-LDS jobs second; longest jobs lead each grid
+        std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) {
+            bool la = a.lds_bytes > SMALL_LDS, lb = b.lds_bytes > SMALL_LDS;
+            if (la != lb) return lb;
+            return a.cost > b.cost;
+        });
+        p.n_small = 0; p.lds_small = 0; p.lds_large = 0;
+        for (const SeqJob &j : p.seq) {
+            if (j.lds_bytes <= SMALL_LDS) { p.n_small++; p.lds_small = std::max(p.lds_small, j.lds_bytes); }
+            else p.lds_large = std::max(p.lds_large, j.lds_bytes);
+        }
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
     }
@@ -172,18 +191,46 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
 }
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     Dims d = dims_of(&r.b);
-    for (Phase &p : r.phases) {
-        if (!p.seq.empty()) {
-            dim3 grid((unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK), (unsigned)p.seq.size());
-            hipLaunchKernelGGL(seq_jobs_kernel, grid, dim3(SEQ_BLOCK), 0, ctx->stream, p.d_seq, d);
+    if (!r.aux[0]) { // lazily create the side streams (they live as long as the suite)
+        for (int i = 0; i < 2; i++) {
+            PQ_HIP_TRY(hipStreamCreateWithFlags(&r.aux[i], hipStreamNonBlocking));
+            PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
-        for (const RowThunk &t : p.rows) t.launch(t.blob, ctx->stream);
+        PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
+    }
+    const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
+    for (Phase &p : r.phases) {
+        // the launches of one phase are independent of each other: the small-LDS SEQ grid runs on the caller's
+        // stream, the large-LDS SEQ grid and the ROW launches beside it on two side streams
+        const bool has_large = (int)p.seq.size() > p.n_small, has_rows = !p.rows.empty();
+        if (has_large || has_rows) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
+        if (p.n_small > 0)
+            hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)p.n_small), dim3(SEQ_BLOCK), p.lds_small, ctx->stream,
+                               p.d_seq, d);
+        if (has_large) {
+            PQ_HIP_TRY(hipStreamWaitEvent(r.aux[0], r.ev_fork, 0));
+            hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)(p.seq.size() - p.n_small)), dim3(SEQ_BLOCK),
+                               p.lds_large, r.aux[0], p.d_seq + p.n_small, d);
+            PQ_HIP_TRY(hipEventRecord(r.ev_join[0], r.aux[0]));
+        }
+        if (has_rows) {
+            PQ_HIP_TRY(hipStreamWaitEvent(r.aux[1], r.ev_fork, 0));
+            for (const RowThunk &t : p.rows) t.launch(t.blob, r.aux[1]);
+            PQ_HIP_TRY(hipEventRecord(r.ev_join[1], r.aux[1]));
+        }
+        if (has_large) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[0], 0));
+        if (has_rows) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[1], 0));
     }
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }
 static void suite_free(pq_ctx *ctx, Recorder &r) {
     (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) {
+        if (r.aux[i]) { (void)hipStreamSynchronize(r.aux[i]); (void)hipStreamDestroy(r.aux[i]); r.aux[i] = nullptr; }
+        if (r.ev_join[i]) { (void)hipEventDestroy(r.ev_join[i]); r.ev_join[i] = nullptr; }
+    }
+    if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     for (Phase &p : r.phases) if (p.d_seq) (void)hipFree(p.d_seq);
     for (void *s : r.scratch) (void)hipFree(s);
     r.phases.clear();
