@@ -36,7 +36,8 @@ def make_inputs(n_sym: int, T: int, seed: int, device):
 def cpu_baseline(sample_syms: int, T: int):
     from oracle import pq_oracle as oracle
     d = oracle.gen_ohlcv(SEED, sample_syms, T, 0)
-    cores = len(os.sched_getaffinity(0))
+    # the GPU box allots 16 host cores per GPU (and caps worker pools there); use at most that many
+    cores = min(len(os.sched_getaffinity(0)), 16)
     oracle.suite_bench({k: v[:8] for k, v in d.items()}, cores)  # spin up the OpenMP team
     t0 = time.perf_counter(); oracle.suite_bench(d, cores); t_all = time.perf_counter() - t0
     small = {k: v[: max(8, sample_syms // 8)] for k, v in d.items()}
@@ -75,12 +76,12 @@ def main():
     n_local, T = args.symbols, args.days
     ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
     suite = Suite(n_local, T, dev)
-    gathered = torch.empty((world * n_local, 8), dtype=torch.float64, device=dev) if world > 1 else None
+    from polars_quant_amd.distributed import gather_summaries
 
     def step():
         suite.run(ohlcv)
         if world > 1:   # the one exchange of the path: per-symbol summary rows to every rank (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, suite.summary)
+            gather_summaries(suite.summary, world * n_local)
 
     for _ in range(args.warmup):
         step()
@@ -138,7 +139,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_task[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(1024, T)
+            line["cpu_baseline"] = cpu_baseline(4096, T)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,57 @@
+"""not-gpu, world_size 2 over gloo: the symbol sharding + the one summary gather of the multi-GPU path.
+
+On CPU the product cannot compute (no HIP device), so each rank produces its shard's summary rows with the
+oracle; what is under test is polars_quant_amd.distributed (static split, ragged gather, symbol order)."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, n_sym, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pq_oracle as oracle
+    from polars_quant_amd.distributed import gather_summaries, shard_range
+    T = 300
+    d = oracle.gen_ohlcv(0x5EED0003, n_sym, T, 0)          # every rank can regenerate any symbol deterministically
+    lo, hi = shard_range(n_sym, rank, world)
+    close = d["close"][lo:hi]
+    buy, sell = oracle.macd_cross_signals(close)
+    _, _, _, summ = oracle.backtest(close, buy, sell)
+    full = gather_summaries(torch.from_numpy(summ.reshape(hi - lo, 8)), n_sym)
+    if rank == 0:
+        q.put(full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_sym", [10, 7])      # even split and ragged split
+def test_two_rank_symbol_sharding(n_sym, oracle):
+    from polars_quant_amd.distributed import shard_range
+    assert shard_range(10, 0, 2) == (0, 5) and shard_range(10, 1, 2) == (5, 10)
+    assert shard_range(7, 0, 2) == (0, 3) and shard_range(7, 1, 2) == (3, 7)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_sym
+    procs = [ctx.Process(target=_worker, args=(r, 2, n_sym, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    d = oracle.gen_ohlcv(0x5EED0003, n_sym, 300, 0)
+    buy, sell = oracle.macd_cross_signals(d["close"])
+    _, _, _, exp = oracle.backtest(d["close"], buy, sell)
+    assert got.shape == (n_sym, 8)
+    assert (got.view(np.uint64) == exp.view(np.uint64)).all()
