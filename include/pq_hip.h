@@ -152,6 +152,13 @@ pq_status pq_stochf(pq_ctx *, const pq_batch *, const double *high, const double
 pq_status pq_stochrsi(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, int64_t fastk_period,
                       int64_t fastd_period, int64_t fastd_matype, double *fastk, double *fastd); /* momentum.py:197 */
 
+/* fused multi-output forms: the shared core is evaluated once (bit-identical to the single-output calls) */
+pq_status pq_dmi_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
+                     int64_t timeperiod, double *dx, double *plus_di, double *minus_di, double *adx,
+                     double *adxr);                                                    /* momentum.rs:668-727 calc_dm */
+pq_status pq_ht_all(pq_ctx *, const pq_batch *, const double *real, double *ht_dcperiod, double *ht_dcphase,
+                    double *inphase, double *quadrature, double *sine, double *leadsine);    /* cycle.rs:27-63 */
+
 /* ---- volatility / volume / price (src/talib/{volatility,volume,price}.rs) ---- */
 pq_status pq_trange(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
                     double *out);                                                              /* volatility.rs:51 */

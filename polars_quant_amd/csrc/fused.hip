@@ -1,0 +1,114 @@
+// fused.hip -- C ABI of the composite functions: one sequential job when the LDS body applies (ops_fused.h),
+// the chained launches through scratch columns otherwise (very long windows, unaligned columns, MA types that are
+// themselves multi-pass).  Both forms are bit-identical.
+#include "ops_fused.h"
+
+extern "C" {
+pq_status pq_trima_chain(pq_ctx *, const pq_batch *, const double *, int64_t, double *);
+pq_status pq_cci_chain(pq_ctx *, const pq_batch *, const double *, const double *, const double *, int64_t, double *);
+pq_status pq_adxr_chain(pq_ctx *, const pq_batch *, const double *, const double *, const double *, int64_t, double *);
+pq_status pq_apo_chain(pq_ctx *, const pq_batch *, const double *, int64_t, int64_t, int64_t, double *);
+pq_status pq_ppo_chain(pq_ctx *, const pq_batch *, const double *, int64_t, int64_t, int64_t, double *);
+pq_status pq_macdext_chain(pq_ctx *, const pq_batch *, const double *, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                           double *, double *, double *);
+pq_status pq_stoch_chain(pq_ctx *, const pq_batch *, const double *, const double *, const double *, int64_t, int64_t,
+                         int64_t, int64_t, int64_t, double *, double *);
+pq_status pq_stochf_chain(pq_ctx *, const pq_batch *, const double *, const double *, const double *, int64_t, int64_t,
+                          int64_t, double *, double *);
+pq_status pq_stochrsi_chain(pq_ctx *, const pq_batch *, const double *, int64_t, int64_t, int64_t, int64_t, double *, double *);
+}
+
+#define CHK(name, cond) PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(cond, name ": null pointer")
+
+extern "C" {
+
+pq_status pq_trima(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
+    CHK("pq_trima", real && out);
+    TrimaOp op{};
+    if (p % 2 == 1) { op.k1 = p / 2 + 1; op.k2 = op.k1; } else { op.k1 = p / 2; op.k2 = op.k1 + 1; } // overlap.rs:1313-1326
+    InCols<1> in{{real}}; OutCols<1> o{{out}};
+    if (p > 0 && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_trima_chain(ctx, b, real, p, out);
+}
+pq_status pq_apo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype, double *out) {
+    CHK("pq_apo", real && out);
+    MaDiffOp<0> op{}; op.fast = fast; op.slow = slow; op.matype = matype;
+    InCols<1> in{{real}}; OutCols<1> o{{out}};
+    if (Ma2::supports(matype) && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_apo_chain(ctx, b, real, fast, slow, matype, out);
+}
+pq_status pq_ppo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype, double *out) {
+    CHK("pq_ppo", real && out);
+    MaDiffOp<1> op{}; op.fast = fast; op.slow = slow; op.matype = matype;
+    InCols<1> in{{real}}; OutCols<1> o{{out}};
+    if (Ma2::supports(matype) && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_ppo_chain(ctx, b, real, fast, slow, matype, out);
+}
+pq_status pq_macdext(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t fastmt, int64_t slow,
+                     int64_t slowmt, int64_t sig, int64_t sigmt, double *macd, double *signal, double *hist) {
+    CHK("pq_macdext", real && macd && signal && hist);
+    MacdextOp op{}; op.fast = fast; op.fastmt = fastmt; op.slow = slow; op.slowmt = slowmt; op.sig = sig; op.sigmt = sigmt;
+    InCols<1> in{{real}}; OutCols<3> o{{macd, signal, hist}};
+    if (Ma2::supports(fastmt) && Ma2::supports(slowmt) && Ma2::supports(sigmt) && seq_can_lds(b, op, in, o))
+        return launch_seq(ctx, b, op, in, o);
+    return pq_macdext_chain(ctx, b, real, fast, fastmt, slow, slowmt, sig, sigmt, macd, signal, hist);
+}
+pq_status pq_stoch(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
+                   int64_t slowk, int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, double *outk, double *outd) {
+    CHK("pq_stoch", h && l && c && outk && outd);
+    StochOp<0> op{}; op.fastk = fastk; op.p1 = slowk; op.mt1 = slowk_mt; op.p2 = slowd; op.mt2 = slowd_mt;
+    InCols<3> in{{h, l, c}}; OutCols<2> o{{outk, outd}};
+    if (Ma2::supports(slowk_mt) && Ma2::supports(slowd_mt) && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_stoch_chain(ctx, b, h, l, c, fastk, slowk, slowk_mt, slowd, slowd_mt, outk, outd);
+}
+pq_status pq_stochf(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
+                    int64_t fastd, int64_t fastd_mt, double *outk, double *outd) {
+    CHK("pq_stochf", h && l && c && outk && outd);
+    StochOp<1> op{}; op.fastk = fastk; op.p1 = fastd; op.mt1 = fastd_mt; op.p2 = 0; op.mt2 = 0;
+    InCols<3> in{{h, l, c}}; OutCols<2> o{{outk, outd}};
+    if (Ma2::supports(fastd_mt) && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_stochf_chain(ctx, b, h, l, c, fastk, fastd, fastd_mt, outk, outd);
+}
+pq_status pq_stochrsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, int64_t fastk, int64_t fastd,
+                      int64_t fastd_mt, double *outk, double *outd) {
+    CHK("pq_stochrsi", real && outk && outd);
+    StochRsiOp op{}; op.p = p; op.fastk = fastk; op.fastd = fastd; op.fastd_mt = fastd_mt;
+    InCols<1> in{{real}}; OutCols<2> o{{outk, outd}};
+    if (Ma2::supports(fastd_mt) && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_stochrsi_chain(ctx, b, real, p, fastk, fastd, fastd_mt, outk, outd);
+}
+pq_status pq_cci(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *out) {
+    CHK("pq_cci", h && l && c && out);
+    CciOp op{}; op.p = p;
+    InCols<3> in{{h, l, c}}; OutCols<1> o{{out}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_cci_chain(ctx, b, h, l, c, p, out);
+}
+pq_status pq_adxr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *out) {
+    CHK("pq_adxr", h && l && c && out);
+    DmAllOp<false> op{}; op.p = p;
+    InCols<3> in{{h, l, c}}; OutCols<1> o{{out}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    return pq_adxr_chain(ctx, b, h, l, c, p, out);
+}
+// calc_dm (momentum.rs:668-727) evaluated once for all five of its users
+pq_status pq_dmi_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
+                     double *dx, double *plus_di, double *minus_di, double *adx, double *adxr) {
+    CHK("pq_dmi_all", h && l && c && dx && plus_di && minus_di && adx && adxr);
+    DmAllOp<true> op{}; op.p = p;
+    InCols<3> in{{h, l, c}}; OutCols<5> o{{dx, plus_di, minus_di, adx, adxr}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_dx(ctx, b, h, l, c, p, dx));
+    PQ_TRY(pq_plus_di(ctx, b, h, l, c, p, plus_di));
+    PQ_TRY(pq_minus_di(ctx, b, h, l, c, p, minus_di));
+    PQ_TRY(pq_adx(ctx, b, h, l, c, p, adx));
+    return pq_adxr_chain(ctx, b, h, l, c, p, adxr);
+}
+// the shared Hilbert pipeline (cycle.rs:27-63) evaluated once for ht_dcperiod / ht_dcphase / ht_phasor / ht_sine
+pq_status pq_ht_all(pq_ctx *ctx, const pq_batch *b, const double *real, double *dcperiod, double *dcphase, double *inphase,
+                    double *quadrature, double *sine, double *leadsine) {
+    CHK("pq_ht_all", real && dcperiod && dcphase && inphase && quadrature && sine && leadsine);
+    return launch_seq(ctx, b, HtAllOp{}, InCols<1>{{real}}, OutCols<6>{{dcperiod, dcphase, inphase, quadrature, sine, leadsine}});
+}
+
+} // extern "C"

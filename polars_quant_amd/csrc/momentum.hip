@@ -43,7 +43,7 @@ pq_status pq_willr(pq_ctx *ctx, const pq_batch *b, const double *h, const double
     WillrOp op; op.p = p;
     return launch_row(ctx, b, op, InCols<3>{{h, l, c}}, OutColsT<WillrOp, double>{{out}});
 }
-pq_status pq_cci(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
+pq_status pq_cci_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                  double *out) {
     CHK("pq_cci", h && l && c && out);
     WS(8);
@@ -101,7 +101,7 @@ DMFN(pq_dx, 0)
 DMFN(pq_plus_di, 0) /* momentum.rs:409 returns calc_dm().0 == DX (quirk Q-PDI, decision D-5: literal) */
 DMFN(pq_minus_di, 1)
 DMFN(pq_adx, 2)
-pq_status pq_adxr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
+pq_status pq_adxr_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                   double *out) {
     CHK("pq_adxr", h && l && c && out);
     WS(8);
@@ -121,7 +121,7 @@ pq_status pq_minus_dm(pq_ctx *ctx, const pq_batch *b, const double *h, const dou
     return launch_seq(ctx, b, op, InCols<2>{{h, l}}, OutCols<1>{{out}});
 }
 // D-6: APO = MA(fast) - MA(slow); PPO = (MA(fast)-MA(slow))/MA(slow)*100 on the reference's calc_ma
-pq_status pq_apo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype,
+pq_status pq_apo_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype,
                  double *out) {
     CHK("pq_apo", real && out);
     WS(8);
@@ -130,7 +130,7 @@ pq_status pq_apo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fas
     PQ_TRY(pq_ma(ctx, b, real, slow, matype, s));
     return launch_row(ctx, b, BinOp<0>{}, InCols<2>{{f, s}}, OutColsT<BinOp<0>, double>{{out}});
 }
-pq_status pq_ppo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype,
+pq_status pq_ppo_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype,
                  double *out) {
     CHK("pq_ppo", real && out);
     WS(8);
@@ -139,7 +139,7 @@ pq_status pq_ppo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fas
     PQ_TRY(pq_ma(ctx, b, real, slow, matype, s));
     return launch_row(ctx, b, BinOp<1>{}, InCols<2>{{f, s}}, OutColsT<BinOp<1>, double>{{out}});
 }
-pq_status pq_macdext(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t fastmt, int64_t slow,
+pq_status pq_macdext_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t fastmt, int64_t slow,
                      int64_t slowmt, int64_t sig, int64_t sigmt, double *macd, double *signal, double *hist) {
     CHK("pq_macdext", real && macd && signal && hist); // momentum.py:83-88
     WS(8);
@@ -150,14 +150,14 @@ pq_status pq_macdext(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
     PQ_TRY(pq_ma(ctx, b, macd, sig, sigmt, signal));
     return launch_row(ctx, b, BinOp<0>{}, InCols<2>{{macd, signal}}, OutColsT<BinOp<0>, double>{{hist}});
 }
-pq_status pq_stochf(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
+pq_status pq_stochf_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
                     int64_t fastd, int64_t fastd_mt, double *outk, double *outd) {
     CHK("pq_stochf", h && l && c && outk && outd); // momentum.py:188-195
     FastkOp op; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{h, l, c}}, OutColsT<FastkOp, double>{{outk}}));
     return pq_ma(ctx, b, outk, fastd, fastd_mt, outd);
 }
-pq_status pq_stoch(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
+pq_status pq_stoch_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
                    int64_t slowk, int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, double *outk, double *outd) {
     CHK("pq_stoch", h && l && c && outk && outd); // momentum.py:178-186
     WS(8);
@@ -167,7 +167,7 @@ pq_status pq_stoch(pq_ctx *ctx, const pq_batch *b, const double *h, const double
     PQ_TRY(pq_ma(ctx, b, fk, slowk, slowk_mt, outk));
     return pq_ma(ctx, b, outk, slowd, slowd_mt, outd);
 }
-pq_status pq_stochrsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, int64_t fastk, int64_t fastd,
+pq_status pq_stochrsi_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, int64_t fastk, int64_t fastd,
                       int64_t fastd_mt, double *outk, double *outd) {
     CHK("pq_stochrsi", real && outk && outd); // momentum.py:197-205
     WS(8);

@@ -1,0 +1,242 @@
+// ops_fused.h -- single-walk versions of the functions the reference builds from several passes.
+// Each op keeps every intermediate series in registers / LDS rings, so a composite is ONE sequential job (one
+// phase of a suite grid) instead of a chain of launches through scratch columns.  Arithmetic and null rules are
+// those of the chained form (bit-identical; tests compare both against the oracle).  These ops exist only for
+// the LDS body; the C ABI falls back to the chained launches when the LDS body cannot be used.
+#pragma once
+#include "ops_misc.h"
+#include "ops_momentum.h"
+#include "ops_overlap.h"
+
+// calc_ma (overlap.rs:857-869) restricted to the types that are a single core: SMA (0, 7, default) and EMA (1)
+struct Ma2 {
+    int kind;
+    SmaCore s;
+    EmaCore e;
+    Ring w;
+    __host__ __device__ static bool supports(int64_t matype) { return !(matype >= 2 && matype <= 6) && matype != 8; }
+    __host__ __device__ static int64_t slots(int64_t matype, int64_t p) { return matype == 1 ? 0 : (p > 0 ? p : 1); }
+    __device__ void init(int64_t matype, int64_t p, int64_t n, RingAlloc &ra) {
+        kind = matype == 1 ? 1 : 0;
+        if (kind) e.init(p, n);
+        else { s.init(p, n); w = ra.make(p); }
+    }
+    __device__ double step(double v) { return kind ? e.step(v) : s.step_ring(w, v); }
+};
+
+struct TrimaOp {
+    static constexpr bool LDS_ONLY = true; // overlap.rs:1313-1326: sma(sma(x, k1), k2)
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 70;
+    int64_t k1, k2;
+    SmaCore a, b;
+    Ring wa, wb;
+    __host__ __device__ int64_t ring_slots() const { return (k1 > 0 ? k1 : 1) + (k2 > 0 ? k2 : 1); }
+    __device__ void init(const Row<1> &) {}
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { a.init(k1, r.len); b.init(k2, r.len); wa = ra.make(k1); wb = ra.make(k2); }
+    __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[1]) { y[0] = pq_null(); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = b.step_ring(wb, a.step_ring(wa, x[0])); }
+};
+
+template <int MODE> // 0 APO, 1 PPO (decision D-6)
+struct MaDiffOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int SEQ_ID = 71 + MODE;
+    int64_t fast, slow, matype;
+    Ma2 f, s;
+    __host__ __device__ int64_t ring_slots() const { return Ma2::slots(matype, fast) + Ma2::slots(matype, slow); }
+    __device__ void init(const Row<1> &) {}
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { f.init(matype, fast, r.len, ra); s.init(matype, slow, r.len, ra); }
+    __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[1]) { y[0] = pq_null(); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
+        double a = f.step(x[0]), b = s.step(x[0]);
+        if (pq_isnull(a) || pq_isnull(b)) { y[0] = pq_null(); return; }
+        if (MODE == 0) y[0] = a - b;
+        else y[0] = (b == 0.0) ? pq_null() : (a - b) / b * 100.0;
+    }
+};
+
+struct MacdextOp {
+    static constexpr bool LDS_ONLY = true; // momentum.py:83-88
+    static constexpr int NIN = 1, NOUT = 3;
+    static constexpr int SEQ_ID = 73;
+    int64_t fast, fastmt, slow, slowmt, sig, sigmt;
+    Ma2 f, s, g;
+    __host__ __device__ int64_t ring_slots() const { return Ma2::slots(fastmt, fast) + Ma2::slots(slowmt, slow) + Ma2::slots(sigmt, sig); }
+    __device__ void init(const Row<1> &) {}
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) {
+        f.init(fastmt, fast, r.len, ra); s.init(slowmt, slow, r.len, ra); g.init(sigmt, sig, r.len, ra);
+    }
+    __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[3]) { y[0] = y[1] = y[2] = pq_null(); }
+    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[3]) {
+        double a = f.step(x[0]), b = s.step(x[0]);
+        double m = (pq_isnull(a) || pq_isnull(b)) ? pq_null() : a - b;
+        double d = g.step(m); // N-A: a null macd row is skipped by the signal MA
+        y[0] = m; y[1] = d;
+        y[2] = (pq_isnull(m) || pq_isnull(d)) ? pq_null() : m - d;
+    }
+};
+
+// Polars rolling_min/rolling_max(window=k) + fastk (momentum.py:181-183): the frame is the last k ROWS; the result is
+// null until the frame holds k non-null rows, i.e. whenever any of its rows is null.
+struct FastkCore {
+    int64_t k, rows, nulls_h, nulls_l;
+    Ring wh, wl;
+    __device__ void init(int64_t k_, RingAlloc &ra) { k = k_; rows = 0; nulls_h = nulls_l = 0; wh = ra.make(k); wl = ra.make(k); }
+    __device__ double step(double h, double l, double c) {
+        if (k <= 0) return pq_null();
+        double oh = wh.swap(h), ol = wl.swap(l);
+        if (rows >= k) { nulls_h -= pq_isnull(oh) ? 1 : 0; nulls_l -= pq_isnull(ol) ? 1 : 0; }
+        nulls_h += pq_isnull(h) ? 1 : 0; nulls_l += pq_isnull(l) ? 1 : 0;
+        rows += 1;
+        if (rows < k || nulls_h || nulls_l || pq_isnull(c)) return pq_null();
+        double hn = h, ln = l;
+        int q = wh.pos;
+        for (int u = 0; u < (int)k; u++) {
+            q = (q == 0) ? wh.depth - 1 : q - 1;
+            double a = wh.base[q * 64], b = wl.base[q * 64];
+            hn = a > hn ? a : hn;
+            ln = b < ln ? b : ln;
+        }
+        return (c - ln) * 100.0 / (hn - ln);
+    }
+};
+
+template <int MODE> // 0 STOCH -> (slowk, slowd); 1 STOCHF -> (fastk, fastd)     momentum.py:178-195
+struct StochOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int NIN = 3, NOUT = 2; // high, low, close
+    static constexpr int SEQ_ID = 74 + MODE;
+    int64_t fastk, p1, mt1, p2, mt2; // STOCH: slowk/slowd MA params; STOCHF: (p1, mt1) = fastd, second MA unused
+    FastkCore fk;
+    Ma2 m1, m2;
+    __host__ __device__ int64_t ring_slots() const {
+        return 2 * (fastk > 0 ? fastk : 1) + Ma2::slots(mt1, p1) + (MODE == 0 ? Ma2::slots(mt2, p2) : 0);
+    }
+    __device__ void init(const Row<3> &) {}
+    __device__ void init_lds(const Row<3> &r, RingAlloc &ra) {
+        fk.init(fastk, ra);
+        m1.init(mt1, p1, r.len, ra);
+        if (MODE == 0) m2.init(mt2, p2, r.len, ra);
+    }
+    __device__ void step(const Row<3> &, int64_t, const double (&)[3], double (&y)[2]) { y[0] = y[1] = pq_null(); }
+    __device__ void step_lds(int64_t, const double (&x)[3], double (&y)[2]) {
+        double k = fk.step(x[0], x[1], x[2]);
+        double a = m1.step(k);
+        if (MODE == 0) { y[0] = a; y[1] = m2.step(a); }
+        else { y[0] = k; y[1] = a; }
+    }
+};
+
+struct StochRsiOp {
+    static constexpr bool LDS_ONLY = true; // momentum.py:197-205
+    static constexpr int NIN = 1, NOUT = 2;
+    static constexpr int SEQ_ID = 76;
+    int64_t p, fastk, fastd, fastd_mt;
+    RsiOp rsi;
+    FastkCore fk;
+    Ma2 m;
+    __host__ __device__ int64_t ring_slots() const { return 2 * (fastk > 0 ? fastk : 1) + Ma2::slots(fastd_mt, fastd); }
+    __device__ void init(const Row<1> &) {}
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { rsi.p = p; rsi.init(r); fk.init(fastk, ra); m.init(fastd_mt, fastd, r.len, ra); }
+    __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[2]) { y[0] = y[1] = pq_null(); }
+    __device__ void step_lds(int64_t i, const double (&x)[1], double (&y)[2]) {
+        double rv[1];
+        Row<1> dummy; dummy.in[0] = nullptr; dummy.len = 0;
+        rsi.step(dummy, i, x, rv);
+        double k = fk.step(rv[0], rv[0], rv[0]);
+        y[0] = k;
+        y[1] = m.step(k);
+    }
+};
+
+struct CciOp {
+    static constexpr bool LDS_ONLY = true; // momentum.rs:138-178 in one walk: sma(tp) + mean absolute deviation over the same window (oldest first)
+    static constexpr int NIN = 3, NOUT = 1;
+    static constexpr int SEQ_ID = 77;
+    int64_t p;
+    double sum, denom;
+    bool dead;
+    Ring w;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
+    __device__ void init(const Row<3> &) {}
+    __device__ void init_lds(const Row<3> &r, RingAlloc &ra) {
+        dead = (p <= 0 || r.len < p); sum = 0.0; denom = 1.0 / (double)p; w = ra.make(p);
+    }
+    __device__ void step(const Row<3> &, int64_t, const double (&)[3], double (&y)[1]) { y[0] = pq_null(); }
+    __device__ void step_lds(int64_t i, const double (&x)[3], double (&y)[1]) {
+        y[0] = pq_null();
+        if (dead) return;
+        double tp = (x[0] + x[1] + x[2]) / 3.0;
+        sum += tp;
+        double old = w.swap(tp);
+        if (i < p - 1) return;
+        if (i >= p) sum -= old;
+        double avg = sum * denom;
+        double mean_dev = 0.0;
+        int q = w.pos; // oldest slot (the ring is full: it holds rows i-p+1 .. i)
+        for (int u = 0; u < (int)p; u++) {
+            mean_dev += fabs(w.base[q * 64] - avg);
+            q = (q + 1 == w.depth) ? 0 : q + 1;
+        }
+        if (mean_dev != 0.0) {
+            mean_dev /= (double)p;
+            y[0] = (tp - avg) / (0.015 * mean_dev);
+        }
+    }
+};
+
+// momentum.rs:668-727 calc_dm once for all five of its users: dx, plus_di (= dx, quirk Q-PDI), minus_di, adx, adxr
+template <bool ALL> // ALL: the five columns; else adxr alone
+struct DmAllOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int NIN = 3, NOUT = ALL ? 5 : 1;
+    static constexpr int SEQ_ID = ALL ? 78 : 80;
+    int64_t p;
+    DmOp<2> core; // carries the three RMAs + the ADX RMA
+    Ring wadx;
+    __host__ __device__ int64_t ring_slots() const { return p > 1 ? p - 1 : 1; }
+    __device__ void init(const Row<3> &) {}
+    __device__ void init_lds(const Row<3> &r, RingAlloc &ra) { core.p = p; core.init(r); wadx = ra.make(p - 1); }
+    __device__ void step(const Row<3> &, int64_t, const double (&)[3], double (&y)[NOUT]) { for (int k = 0; k < NOUT; k++) y[k] = pq_null(); }
+    __device__ void step_lds(int64_t i, const double (&x)[3], double (&y)[NOUT]) {
+        double dx, mdi;
+        double adx = core.step_all(i, x, dx, mdi);
+        if (ALL) { y[0] = dx; y[1 % NOUT] = dx; y[2 % NOUT] = mdi; y[3 % NOUT] = adx; }
+        // momentum.rs:50-59: (adx[i] + adx[i-(p-1)]) * 0.5 for i >= p-1
+        double adxr = pq_null();
+        if (p > 0 && i >= p - 1) {
+            double prev = (p == 1) ? adx : wadx.get((int)(p - 1));
+            if (!pq_isnull(adx) && !pq_isnull(prev)) adxr = (adx + prev) * 0.5;
+        }
+        if (p > 1) wadx.push(adx);
+        y[NOUT - 1] = adxr;
+    }
+};
+
+// cycle.rs: the shared Hilbert pipeline once for ht_dcperiod, ht_dcphase, ht_phasor and ht_sine
+struct HtAllOp {
+    static constexpr int NIN = 1, NOUT = 6; // dcperiod, dcphase, inphase, quadrature, sine, leadsine
+    static constexpr int SEQ_ID = 79;
+    HtOp<0> core;
+    __device__ void init(const Row<1> &r) { core.init(r); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[6]) {
+        double yp[1];
+        Row<1> dummy; dummy.in[0] = nullptr; dummy.len = 0;
+        core.step(dummy, i, x, yp); // advances the pipeline, emits the smoothed period
+        y[0] = yp[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) y[k] = pq_null();
+        if (core.dead || i < 31) return;
+        const double i1 = core.i1[0], q1 = core.q1[0];
+        double ph = (i1 != 0.0) ? atan(q1 / i1) * 180.0 / PQ_PI : 0.0; // cycle.rs:130-134 == :294-298
+        double dc_phase = ph + 90.0;
+        if (i1 < 0.0) dc_phase += 180.0;
+        if (dc_phase > 315.0) dc_phase -= 360.0;
+        y[1] = dc_phase;
+        y[2] = i1; y[3] = q1;
+        y[4] = sin(ph * PQ_PI / 180.0);
+        y[5] = sin((ph + 45.0) * PQ_PI / 180.0);
+    }
+};

@@ -378,7 +378,8 @@ struct DmOp {
         rp.init(p, r.len); rm.init(p, r.len); rt.init(p, r.len); radx.init(p, r.len);
         ph = pl = pc = 0.0;
     }
-    __device__ void step(const Row<3> &, int64_t i, const double (&x)[3], double (&y)[1]) {
+    // one row of calc_dm: returns adx (MODE 2 semantics), dx and minus_di through the references
+    __device__ double step_all(int64_t i, const double (&x)[3], double &dx, double &mdi) {
         double p_dm = 0.0, m_dm = 0.0, tr = 0.0;
         if (i >= 1) {
             double up_move = x[0] - ph, down_move = pl - x[1];
@@ -388,16 +389,22 @@ struct DmOp {
         }
         ph = x[0]; pl = x[1]; pc = x[2];
         double sp = rp.step(i, p_dm), sm = rm.step(i, m_dm), st = rt.step(i, tr);
-        double pdi = pq_null(), mdi = pq_null(), dx = pq_null();
+        double pdi = pq_null();
+        mdi = pq_null(); dx = pq_null();
         if (!pq_isnull(sp) && !pq_isnull(sm) && !pq_isnull(st) && st != 0.0) {
             pdi = 100.0 * sp / st;
             mdi = 100.0 * sm / st;
             double diff = fabs(pdi - mdi), sum = pdi + mdi;
             dx = (sum == 0.0) ? 0.0 : 100.0 * diff / sum;
         }
+        return (MODE == 2) ? radx.step(i, z0(dx)) : pq_null(); // momentum.rs:21-27
+    }
+    __device__ void step(const Row<3> &, int64_t i, const double (&x)[3], double (&y)[1]) {
+        double dx, mdi;
+        double adx = step_all(i, x, dx, mdi);
         if (MODE == 0) y[0] = dx;
         else if (MODE == 1) y[0] = mdi;
-        else y[0] = radx.step(i, z0(dx)); // momentum.rs:21-27
+        else y[0] = adx;
     }
 };
 template <bool PLUS> // momentum.rs:414-436 / :359-381

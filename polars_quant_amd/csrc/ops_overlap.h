@@ -449,7 +449,7 @@ struct SarextOp {
 // the whole series and write only the rows whose clamped period is P (every row is written by exactly one job).
 template <class Inner>
 struct MavpSelOp {
-    static constexpr int NIN = 2, NOUT = 1; // real (nulls already -> 0.0), periods
+    static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0 here, overlap.rs:416-424), periods
     static constexpr int SEQ_ID = 100 + Inner::SEQ_ID;
     static constexpr bool MASKED = true;
     static constexpr int NTAP = NTap<Inner>::value; // the inner MA's lag taps all read column 0
@@ -471,14 +471,19 @@ struct MavpSelOp {
     }
     __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
         Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
-        double xi[1] = {x[0]}, yi[1];
+        double xi[1] = {n0(x[0])}, yi[1];
         if constexpr (NTAP == 0) inner.step(r1, t, xi, yi);
         y[0] = pick(t, x[1], yi[0]);
     }
     __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], const double (&tp)[NTAP > 0 ? NTAP : 1], double (&y)[1]) {
         Row<1> r1; r1.in[0] = r.in[0]; r1.len = r.len;
-        double xi[1] = {x[0]}, yi[1];
-        if constexpr (NTAP > 0) inner.step(r1, t, xi, tp, yi);
+        double xi[1] = {n0(x[0])}, yi[1];
+        if constexpr (NTAP > 0) {
+            double tz[NTAP > 0 ? NTAP : 1];
+#pragma unroll
+            for (int k = 0; k < NTAP; k++) tz[k] = n0(tp[k]);
+            inner.step(r1, t, xi, tz, yi);
+        }
         y[0] = pick(t, x[1], yi[0]);
     }
     // LDS body: forward to the inner op's ring variant when it has one
@@ -490,7 +495,7 @@ struct MavpSelOp {
         if constexpr (HasRings<Inner>::value) inner.init_lds(r1, ra); else inner.init(r1);
     }
     __device__ void step_lds(int64_t t, const double (&x)[2], double (&y)[1]) {
-        double xi[1] = {x[0]}, yi[1];
+        double xi[1] = {n0(x[0])}, yi[1];
         if constexpr (HasRings<Inner>::value) inner.step_lds(t, xi, yi);
         else { Row<1> r1; r1.in[0] = nullptr; r1.len = 0; inner.step(r1, t, xi, yi); }
         y[0] = pick(t, x[1], yi[0]);

@@ -51,7 +51,7 @@ pq_status pq_t3(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, d
     t3_coeffs(op, vf);
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
-pq_status pq_trima(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
+pq_status pq_trima_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_trima: null pointer");
     PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
     double *tmp = pq_ws_col(ctx, b, 7); // scratch column 7 is reserved for trima (see pq_ma users)
@@ -119,9 +119,7 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     // of them run as ONE grid
     SuiteScope scope(ctx, b);
     PQ_TRY(scope.status);
-    PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
-    double *r0 = pq_ws_col(ctx, b, 5);
-    PQ_TRY(launch_row(ctx, b, ReplaceNullOp{}, IN1(real), OutColsT<ReplaceNullOp, double>{{r0}}));
+    const double *r0 = real; // the select jobs map nulls to 0.0 themselves (overlap.rs:416-424)
     rec_set_shared_out(ctx, true); // the jobs write disjoint rows of `out`
     pq_status st;
     switch (matype) { // overlap.rs:857-869
@@ -133,7 +131,11 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     case 8: { T3Op t3{}; t3_coeffs(t3, 0.0);
               st = mavp_jobs(ctx, b, r0, periods, minp, maxp, t3, out); break; }
     case 5: { // TRIMA is two chained SMAs: select from a materialised MA column per period
-        double *ma = pq_ws_col(ctx, b, 6);
+        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
+        double *rz = pq_ws_col(ctx, b, 5), *ma = pq_ws_col(ctx, b, 6);
+        rec_set_shared_out(ctx, false);
+        PQ_TRY(launch_row(ctx, b, ReplaceNullOp{}, IN1(real), OutColsT<ReplaceNullOp, double>{{rz}}));
+        r0 = rz;
         st = PQ_OK;
         for (int64_t P = minp; P <= maxp && st == PQ_OK; P++) {
             rec_set_shared_out(ctx, false);

@@ -430,6 +430,15 @@ struct SuiteScope {
 };
 
 template <class Op, class = void>
+struct IsLdsOnly { static constexpr bool value = false; };
+template <class Op>
+struct IsLdsOnly<Op, decltype((void)Op::LDS_ONLY)> { static constexpr bool value = Op::LDS_ONLY; };
+// can this op instance run in the LDS body on these columns?  (fused ops have no gather body: callers check first)
+template <class Op>
+static inline bool seq_can_lds(const pq_batch *b, const Op &op, const InCols<Op::NIN> &in, const OutCols<Op::NOUT> &out) {
+    return seq_lds_bytes(op) <= SEQ_LDS_LIMIT && seq_cols_aligned<Op::NIN, Op::NOUT>(b, in.p, out.p);
+}
+template <class Op, class = void>
 struct HasSeqId { static constexpr bool value = false; };
 template <class Op>
 struct HasSeqId<Op, decltype((void)Op::SEQ_ID)> { static constexpr bool value = true; };
@@ -440,6 +449,10 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     if (b->n_series == 0 || b->len == 0) return PQ_OK;
     size_t lds = seq_lds_bytes(op);
     bool use_lds = lds <= SEQ_LDS_LIMIT && seq_cols_aligned<Op::NIN, Op::NOUT>(b, in.p, out.p);
+    if (IsLdsOnly<Op>::value && !use_lds) {
+        pq_set_error("internal: fused op launched without checking seq_can_lds");
+        return PQ_ERR_UNSUPPORTED;
+    }
     if (ctx->rec) {
         if constexpr (HasSeqId<Op>::value) {
             static_assert(sizeof(Op) <= 512, "SEQ op too large for a job slot");

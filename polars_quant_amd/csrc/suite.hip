@@ -9,9 +9,7 @@
 // besides the launches.  Composite functions (MAVP = one job per candidate period) use the same machinery
 // internally through SuiteScope.
 #include "ops_backtest.h"
-#include "ops_misc.h"
-#include "ops_momentum.h"
-#include "ops_overlap.h"
+#include "ops_fused.h"
 #include <algorithm>
 #include <map>
 #include <vector>
@@ -19,8 +17,8 @@
 struct SeqJob { // device-visible
     int kind, nin, nout, cost;
     unsigned lds_bytes, pad_; // 0 = run the gather body
-    const double *in[5];
-    double *out[3];
+    const double *in[6];
+    double *out[8];
     alignas(8) unsigned char op[512];
 };
 static_assert(sizeof(BtArgs) <= 512, "BtArgs must fit a job slot");
@@ -53,6 +51,8 @@ struct pq_suite {
     X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
+    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(HtAllOp)                                                                   \
     X(AtrOp<false>) X(AtrOp<true>) X(AdOp<false>) X(AdOp<true>) X(ObvOp) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>)
 
 __global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
@@ -87,11 +87,12 @@ __global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs,
 
 // rough relative cost per row, used to start the longest jobs first
 static int job_cost(int kind) {
-    if (kind >= 45 && kind <= 49) return 30;      // Hilbert pipeline
+    if ((kind >= 45 && kind <= 49) || kind == 79) return 30; // Hilbert pipeline
     if (kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1) return 25;
     if (kind == 24 || kind == 25) return 20;      // ultosc, mfi: lagged recomputation
     if (kind == 9 || kind == 10) return 20;       // rolling extrema
-    if (kind >= 26 && kind <= 28) return 15;      // DM family
+    if ((kind >= 26 && kind <= 28) || kind == 78 || kind == 80) return 15; // DM family
+    if (kind >= 74 && kind <= 77) return 14;      // stochastics, cci
     if (kind == 6 || kind == 8) return 12;
     return 8;
 }
@@ -134,6 +135,7 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, 
                       int nin, double *const *out, int nout, size_t lds_bytes) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
+    if (nin > 6 || nout > 8) { pq_set_error("internal: SEQ job has too many columns"); return PQ_ERR_UNSUPPORTED; }
     SeqJob j;
     memset(&j, 0, sizeof j);
     j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind); j.lds_bytes = (unsigned)lds_bytes;

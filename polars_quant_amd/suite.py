@@ -60,13 +60,29 @@ class Suite:
         elif name == "backtest_macd_cross":
             check(L.pq_backtest_macd_cross(h, C.byref(b), C.c_void_p(ohlcv["close"].data_ptr()), 12, 26, 9, C.byref(self._prm),
                                            *[C.c_void_p(t.data_ptr()) for t in self.bt], C.c_void_p(self.summary.data_ptr())))
+        elif name == "dmi_all":   # calc_dm evaluated once for its five users (all timeperiod=14 by default)
+            o = self.out
+            check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
+                               *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
+        elif name == "ht_all":    # the Hilbert pipeline evaluated once for dcperiod / dcphase / phasor / sine
+            o = self.out
+            outs = [o["ht_dcperiod"][0], o["ht_dcphase"][0], o["ht_phasor"][0], o["ht_phasor"][1], o["ht_sine"][0], o["ht_sine"][1]]
+            check(L.pq_ht_all(h, C.byref(b), C.c_void_p(ohlcv["close"].data_ptr()), *[C.c_void_p(t.data_ptr()) for t in outs]))
         else:
             cols = SPEC[name][0]
             check(getattr(L, "pq_" + name)(h, C.byref(b), *[C.c_void_p(self._col(ohlcv, c).data_ptr()) for c in cols],
                                            *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in self.out[name]]))
 
-    def tasks(self):
-        return list(SPEC) + ["cdl_all", "backtest_macd_cross"]
+    FUSED = {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"),
+             "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine")}
+
+    def tasks(self, fused: bool = False):
+        """every function of the suite; fused=True replaces the users of a shared core by the multi-output call"""
+        names = list(SPEC)
+        if fused:
+            covered = {n for v in self.FUSED.values() for n in v}
+            names = [n for n in names if n not in covered] + list(self.FUSED)
+        return names + ["cdl_all", "backtest_macd_cross"]
 
     def run_eager(self, ohlcv: dict) -> None:
         """one step as ~90 separate launches (one per C-ABI call), enqueued on the current stream"""
@@ -82,7 +98,7 @@ class Suite:
         with torch.cuda.device(self.dev):
             check(L.pq_suite_begin(h, C.byref(self.batch)))
             try:
-                for name in (tasks or self.tasks()):
+                for name in (tasks or self.tasks(fused=True)):
                     self.run_one(name, ohlcv)
             except Exception:
                 L.pq_suite_abort(h)
@@ -115,4 +131,5 @@ class Suite:
             pass
 
     def suite_bytes_per_row(self) -> int:
+        """per-call algorithmic bytes of the whole suite (SURVEY 8d accounting, independent of how calls are fused)"""
         return sum(self.bytes_per_row[t] for t in self.tasks())

@@ -320,3 +320,25 @@ def test_suite_replay_matches_direct_calls_and_oracle(pq, oracle, data):
     assert (bits(st.bt[2].cpu().numpy()) == bits(eeq)).all()
     np.testing.assert_allclose(st.summary.cpu().numpy(), es, rtol=1e-12, atol=1e-13)
     st.close()
+
+
+def test_fused_multi_output_calls(pq, oracle, data):
+    """pq_dmi_all / pq_ht_all evaluate a shared core once; every column must equal the single-output function"""
+    import ctypes as C
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import Batch, check, lib
+    g = {k: torch.from_numpy(data[k]).cuda() for k in ("high", "low", "close")}
+    b = Batch(N_SYM, T, T)
+    outs = [torch.empty((N_SYM, T), dtype=torch.float64, device="cuda") for _ in range(5)]
+    for p in (14, 1, 5):
+        check(lib().pq_dmi_all(api.ctx(0), C.byref(b), *[C.c_void_p(g[k].data_ptr()) for k in ("high", "low", "close")], p,
+                               *[C.c_void_p(t.data_ptr()) for t in outs]))
+        for nm, t in zip(("dx", "plus_di", "minus_di", "adx", "adxr"), outs):
+            (exp,) = oracle.call(nm, data["high"], data["low"], data["close"], timeperiod=p)
+            assert_same(f"dmi_all.{nm}(p={p})", t.cpu().numpy(), exp)
+    outs = [torch.empty((N_SYM, T), dtype=torch.float64, device="cuda") for _ in range(6)]
+    check(lib().pq_ht_all(api.ctx(0), C.byref(b), C.c_void_p(g["close"].data_ptr()), *[C.c_void_p(t.data_ptr()) for t in outs]))
+    exp = (oracle.call("ht_dcperiod", data["close"]) + oracle.call("ht_dcphase", data["close"]) +
+           oracle.call("ht_phasor", data["close"]) + oracle.call("ht_sine", data["close"]))
+    for i, (t, e) in enumerate(zip(outs, exp)):
+        assert_same(f"ht_all[{i}]", t.cpu().numpy(), e, exact=False)
