@@ -79,27 +79,33 @@ struct MacdextOp {
 };
 
 // Polars rolling_min/rolling_max(window=k) + fastk (momentum.py:181-183): the frame is the last k ROWS; the result is
-// null until the frame holds k non-null rows, i.e. whenever any of its rows is null.
+// null until the frame holds k non-null rows, i.e. whenever any of its rows is null.  Extrema by block decomposition
+// (see RollExt::step_ring2); nulls are counted per frame and entered as neutral elements.
 struct FastkCore {
     int64_t k, rows, nulls_h, nulls_l;
-    Ring wh, wl;
-    __device__ void init(int64_t k_, RingAlloc &ra) { k = k_; rows = 0; nulls_h = nulls_l = 0; wh = ra.make(k); wl = ra.make(k); }
+    Ring nh, nl;          // null flags of the frame rows (1.0 / 0.0)
+    RollExt<true> mx;
+    RollExt<false> mn;
+    Ring hc, hs, lc, ls;
+    __host__ __device__ static int64_t slots(int64_t k) { return 6 * (k > 0 ? k : 1); }
+    __device__ void init(int64_t k_, RingAlloc &ra) {
+        k = k_; rows = 0; nulls_h = nulls_l = 0;
+        nh = ra.make(k); nl = ra.make(k);
+        mx.init(k); mn.init(k); mx.init_ring(); mn.init_ring();
+        hc = ra.make(k); hs = ra.make(k); lc = ra.make(k); ls = ra.make(k);
+    }
     __device__ double step(double h, double l, double c) {
         if (k <= 0) return pq_null();
-        double oh = wh.swap(h), ol = wl.swap(l);
-        if (rows >= k) { nulls_h -= pq_isnull(oh) ? 1 : 0; nulls_l -= pq_isnull(ol) ? 1 : 0; }
-        nulls_h += pq_isnull(h) ? 1 : 0; nulls_l += pq_isnull(l) ? 1 : 0;
+        const bool hn_ = pq_isnull(h), ln_ = pq_isnull(l);
+        double oh = nh.swap(hn_ ? 1.0 : 0.0), ol = nl.swap(ln_ ? 1.0 : 0.0);
+        if (rows >= k) { nulls_h -= (oh != 0.0) ? 1 : 0; nulls_l -= (ol != 0.0) ? 1 : 0; }
+        nulls_h += hn_ ? 1 : 0; nulls_l += ln_ ? 1 : 0;
         rows += 1;
+        // a null enters the window structures as the neutral element (it can only matter in frames that are null anyway)
+        double hmax = mx.step_ring2(hc, hs, hn_ ? -1.7976931348623157e308 : h);
+        double lmin = mn.step_ring2(lc, ls, ln_ ? 1.7976931348623157e308 : l);
         if (rows < k || nulls_h || nulls_l || pq_isnull(c)) return pq_null();
-        double hn = h, ln = l;
-        int q = wh.pos;
-        for (int u = 0; u < (int)k; u++) {
-            q = (q == 0) ? wh.depth - 1 : q - 1;
-            double a = wh.base[q * 64], b = wl.base[q * 64];
-            hn = a > hn ? a : hn;
-            ln = b < ln ? b : ln;
-        }
-        return (c - ln) * 100.0 / (hn - ln);
+        return (c - lmin) * 100.0 / (hmax - lmin);
     }
 };
 
@@ -112,7 +118,7 @@ struct StochOp {
     FastkCore fk;
     Ma2 m1, m2;
     __host__ __device__ int64_t ring_slots() const {
-        return 2 * (fastk > 0 ? fastk : 1) + Ma2::slots(mt1, p1) + (MODE == 0 ? Ma2::slots(mt2, p2) : 0);
+        return FastkCore::slots(fastk) + Ma2::slots(mt1, p1) + (MODE == 0 ? Ma2::slots(mt2, p2) : 0);
     }
     __device__ void init(const Row<3> &) {}
     __device__ void init_lds(const Row<3> &r, RingAlloc &ra) {
@@ -137,7 +143,7 @@ struct StochRsiOp {
     RsiOp rsi;
     FastkCore fk;
     Ma2 m;
-    __host__ __device__ int64_t ring_slots() const { return 2 * (fastk > 0 ? fastk : 1) + Ma2::slots(fastd_mt, fastd); }
+    __host__ __device__ int64_t ring_slots() const { return FastkCore::slots(fastk) + Ma2::slots(fastd_mt, fastd); }
     __device__ void init(const Row<1> &) {}
     __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { rsi.p = p; rsi.init(r); fk.init(fastk, ra); m.init(fastd_mt, fastd, r.len, ra); }
     __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[2]) { y[0] = y[1] = pq_null(); }
@@ -175,10 +181,12 @@ struct CciOp {
         if (i >= p) sum -= old;
         double avg = sum * denom;
         double mean_dev = 0.0;
-        int q = w.pos; // oldest slot (the ring is full: it holds rows i-p+1 .. i)
-        for (int u = 0; u < (int)p; u++) {
-            mean_dev += fabs(w.base[q * 64] - avg);
-            q = (q + 1 == w.depth) ? 0 : q + 1;
+        for (int b0 = (int)p; b0 >= 1; b0 -= 8) { // oldest (p pushes ago) to newest, in the reference's summation order
+            double v8[8];
+            w.get8<-1>(b0, v8);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (b0 - u >= 1) mean_dev += fabs(v8[u] - avg);
         }
         if (mean_dev != 0.0) {
             mean_dev /= (double)p;
@@ -238,5 +246,72 @@ struct HtAllOp {
         y[2] = i1; y[3] = q1;
         y[4] = sin(ph * PQ_PI / 180.0);
         y[5] = sin((ph + 45.0) * PQ_PI / 180.0);
+    }
+};
+
+// MAVP for the single-core MA types (SMA: matype 0/7/other, EMA: matype 1): a job advances up to EIGHT candidate
+// periods [lo, hi] together from one shared input ring (their running states live in an LDS array [period][lane]) and
+// writes the rows whose clamped period falls in its range.  Same arithmetic per period as MavpSelOp<SmaOp/EmaOp>; the
+// inputs are read once per 8 periods instead of once per period.
+template <int KIND>
+struct MavpBlockOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr bool MASKED = true;
+    static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0), periods
+    static constexpr int SEQ_ID = 81 + KIND;
+    int lo, hi, minp, maxp, n;
+    Ring w, st;
+    const double *tab; // SMA: 1/P ; EMA: 2/(P+1)
+    __host__ __device__ int64_t ring_slots() const { return (KIND == 0 ? (hi > 0 ? hi : 1) : 0) + 8 + 1; }
+    __device__ void init(const Row<2> &) {}
+    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
+        n = (int)(r.len < 0x7fffffff ? r.len : 0x7fffffff);
+        if (KIND == 0) w = ra.make(hi);
+        st = ra.make(8);
+        double *t = ra.make_shared(8);
+        int k = threadIdx.x & 63;
+        if (k < 8) {
+            double P = (double)(lo + k);
+            t[k] = (KIND == 0) ? 1.0 / P : 2.0 / (P + 1.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) st.base[u * 64] = 0.0;
+        tab = t;
+        lds_fence();
+    }
+    __device__ void step(const Row<2> &, int64_t, const double (&)[2], double (&y)[1]) { y[0] = pq_skip(); }
+    __device__ void step_lds(int64_t t64, const double (&x)[2], double (&y)[1]) {
+        const double v = n0(x[0]);
+        const int t = (int)t64;
+        double pd = n0(x[1]);
+        int64_t p64 = (int64_t)pd;
+        int pi = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
+        const int c = t + 1; // every row is valid after nulls -> 0.0
+        double s[8], old[8], tb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s[u] = st.base[u * 64]; tb[u] = tab[u]; }
+        if (KIND == 0) w.get8<1>(lo, old); // x[t - P] for P = lo .. lo+7
+        double sel = pq_skip();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int P = lo + u;
+            double res = pq_null();
+            double a = s[u];
+            if (P <= hi && P > 0 && n >= P) {
+                if (KIND == 0) { // overlap.rs:897-910
+                    a += v;
+                    if (c > P) a -= old[u];
+                    if (c >= P) res = a * tb[u];
+                } else {         // overlap.rs:687-700
+                    if (c < P) a += v;
+                    else if (c == P) { a += v; a = a / (double)P; res = a; }
+                    else { a = fma(tb[u], v - a, a); res = a; }
+                }
+            }
+            st.base[u * 64] = a;
+            if (P == pi && P <= hi) sel = (t >= maxp - 1) ? res : pq_null();
+        }
+        if (KIND == 0) w.push(v);
+        y[0] = sel;
     }
 };

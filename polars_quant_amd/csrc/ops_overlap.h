@@ -336,13 +336,13 @@ struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires =
         if (!any || v <= mn) { mn = v; any = true; }
         y[0] = (m + mn) / 2.0;
     }
-    Ring w;
-    __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
-    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); w = ra.make(p); }
+    Ring wc, ws;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? 2 * p : 2; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); mx.init_ring(); wc = ra.make(p); ws = ra.make(p); }
     __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
         double v = x[0];
         if (p <= 0 || pq_isnull(v)) { y[0] = pq_null(); return; }
-        double m = mx.step_ring(w, v);
+        double m = mx.step_ring2(wc, ws, v);
         if (!any || v <= mn) { mn = v; any = true; }
         y[0] = (m + mn) / 2.0;
     }
@@ -362,14 +362,17 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
         if (!pq_isnull(x[1])) lm = mn.step(r.in[1], t, x[1]);
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
     }
-    Ring wh, wl;
-    __host__ __device__ int64_t ring_slots() const { return p > 0 ? 2 * p : 2; }
-    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) { init(r); wh = ra.make(p); wl = ra.make(p); }
+    Ring whc, whs, wlc, wls;
+    __host__ __device__ int64_t ring_slots() const { return p > 0 ? 4 * p : 4; }
+    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
+        init(r); mx.init_ring(); mn.init_ring();
+        whc = ra.make(p); whs = ra.make(p); wlc = ra.make(p); wls = ra.make(p);
+    }
     __device__ void step_lds(int64_t, const double (&x)[2], double (&y)[1]) {
         if (p <= 0) { y[0] = pq_null(); return; }
         double hm = pq_null(), lm = pq_null();
-        if (!pq_isnull(x[0])) hm = mx.step_ring(wh, x[0]);
-        if (!pq_isnull(x[1])) lm = mn.step_ring(wl, x[1]);
+        if (!pq_isnull(x[0])) hm = mx.step_ring2(whc, whs, x[0]);
+        if (!pq_isnull(x[1])) lm = mn.step_ring2(wlc, wls, x[1]);
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
     }
 };

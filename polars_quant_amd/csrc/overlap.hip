@@ -1,6 +1,6 @@
 // overlap.hip -- SEQ kernels + C ABI for the overlap studies (reference: src/talib/overlap.rs).
 // One series per lane, reference operation order, null-transparent streaming (N-A).
-#include "ops_overlap.h"
+#include "ops_fused.h"
 
 // ---------------------------------------------------------------- C ABI
 #define IN1(a) InCols<1>{{a}}
@@ -115,14 +115,33 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && periods && out, "pq_mavp: null pointer");
     if (minp > maxp || minp < 0)
         return launch_row(ctx, b, FillNullOp{}, InCols<0>{}, OutColsT<FillNullOp, double>{{out}});
-    // one masked-select job per candidate period; recorded into a (possibly temporary) suite so that all
+    // otherwise one masked-select job per candidate period; recorded into a (possibly temporary) suite so that all
     // of them run as ONE grid
     SuiteScope scope(ctx, b);
     PQ_TRY(scope.status);
     const double *r0 = real; // the select jobs map nulls to 0.0 themselves (overlap.rs:416-424)
     rec_set_shared_out(ctx, true); // the jobs write disjoint rows of `out`
-    pq_status st;
-    switch (matype) { // overlap.rs:857-869
+    pq_status st = PQ_OK;
+    bool blocked = false;
+    if (matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8 && maxp < (1 << 30)) {
+        // SMA / EMA: eight candidate periods per job
+        blocked = true;
+        st = PQ_OK;
+        for (int64_t lo = minp; lo <= maxp && st == PQ_OK; lo += 8) {
+            int64_t hi = lo + 7 < maxp ? lo + 7 : maxp;
+            InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
+            if (matype == 1) {
+                MavpBlockOp<1> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
+                if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
+                st = launch_seq(ctx, b, op, in, o1);
+            } else {
+                MavpBlockOp<0> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
+                if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
+                st = launch_seq(ctx, b, op, in, o1);
+            }
+        }
+    }
+    if (!blocked && st == PQ_OK) switch (matype) { // overlap.rs:857-869
     case 1: st = mavp_jobs(ctx, b, r0, periods, minp, maxp, EmaOp{}, out); break;
     case 2: st = mavp_jobs(ctx, b, r0, periods, minp, maxp, WmaOp{}, out); break;
     case 3: st = mavp_jobs(ctx, b, r0, periods, minp, maxp, DemaOp{}, out); break;
@@ -148,6 +167,7 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
         break; }
     default: st = mavp_jobs(ctx, b, r0, periods, minp, maxp, SmaOp{}, out); break;
     }
+    (void)0;
     rec_set_shared_out(ctx, false);
     PQ_TRY(st);
     return scope.finish();

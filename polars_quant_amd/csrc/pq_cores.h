@@ -185,25 +185,39 @@ struct RollExt {
         }
         return best;
     }
-    // LDS-ring variant (ring depth >= p).  A lazy rescan is hopeless in SIMT -- with 64 lanes some lane's extremum
-    // expires on almost every row, so the whole wave would pay the dependent rescan loop each time; instead every row
-    // takes the extremum of the min(j, p) newest values straight from the ring: p independent LDS reads + p max/min.
-    // The result is the same value the reference's monotonic deque holds at its front.
-    __device__ double step_ring(Ring &w, double v) {
-        j += 1;
-        best = v;
-        if (p > 0) {
-            int n = (int)(j < p ? j : p);
-            int k = w.pos;
-            for (int u = 1; u < n; u++) {
-                k = (k == 0) ? w.depth - 1 : k - 1;
-                double x = w.base[k * 64];
-                best = IS_MAX ? fmax(best, x) : fmin(best, x);
-            }
-        } else { // p <= 0 never expires anything: running extremum (callers reject p <= 0 before this)
-            best = v;
+    // LDS variant: block-decomposed sliding extremum (van Herk / Gil-Werman), O(1) LDS traffic per row and no
+    // data-dependent branches.  Valid values are cut into blocks of p; `cur` holds the running block, `suf` the suffix
+    // extrema of the previous block.  Window(last p values) = prefix of the current block + suffix of the previous one,
+    // so its extremum is ext(prefix, suf[m+1]).  A lazy rescan is hopeless in SIMT (some lane expires on nearly every
+    // row and the whole wave pays the rescan); here the only burst -- turning a finished block into its suffix extrema --
+    // falls on the same row for every lane unless nulls have shifted a lane.  max/min are exact in any order, so the
+    // value is the one at the front of the reference's monotonic deque.
+    int64_t m;        // values in the current block
+    bool has_prev;
+    double prefix;
+    __device__ void init_ring() { m = 0; has_prev = false; prefix = 0.0; }
+    // cur, suf: rings used as plain arrays of depth >= p
+    __device__ double step_ring2(Ring &cur, Ring &suf, double v) {
+        if (p <= 0) return v;
+        prefix = (m == 0) ? v : (IS_MAX ? fmax(prefix, v) : fmin(prefix, v));
+        cur.base[m * 64] = v;
+        m += 1;
+        double out = prefix;
+        if (has_prev && m < p) {
+            double s = suf.base[m * 64]; // extremum of previous-block entries m .. p-1
+            out = IS_MAX ? fmax(out, s) : fmin(out, s);
         }
-        w.push(v);
-        return best;
+        if (m == p) { // block complete: suffix extrema become the next block's `suf`
+            double run = cur.base[(p - 1) * 64];
+            suf.base[(p - 1) * 64] = run;
+            for (int64_t k = p - 2; k >= 0; k--) {
+                double x = cur.base[k * 64];
+                run = IS_MAX ? fmax(run, x) : fmin(run, x);
+                suf.base[k * 64] = run;
+            }
+            m = 0;
+            has_prev = true;
+        }
+        return out;
     }
 };

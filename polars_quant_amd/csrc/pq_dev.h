@@ -209,13 +209,22 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
 // SEQ body, LDS-staged (the fast path).  The per-lane gather above costs one L1 tag lookup per lane and
 // 8-byte element: a 64-lane load touches 64 different cache lines and the kernel becomes bound by the
 // texture-addresser / L1 rate, not by HBM.  Here the wavefront instead moves a whole tile
-// [64 series][K rows] per column with coalesced 16-byte accesses (K*8 contiguous bytes per series),
+// [64 series][K rows] per column with coalesced 16-byte accesses (K*8 contiguous bytes per series; K = 16 for
+// 1-in/1-out ops, 8 otherwise.  Measured: K = 32/16 moves ~25 % more bytes/s when the grid is bandwidth-bound, but
+// the doubled LDS footprint costs occupancy and the full suite runs slower, so the smaller tiles are the default),
 // transposes it through LDS (row pitch K*8+8 bytes: conflict-free for the cooperative b128 writes and for
 // the per-lane b64 reads), and each lane then walks ITS OWN row of the tile in the reference's order.
 // Outputs take the same route back.  The next tile's global loads are in flight (in registers) while
 // the current tile is computed.  Rolling windows live in LDS rings ([slot][lane] layout), which also
 // makes them null-proof: only valid values are pushed.
 // One wavefront = one workgroup, so the barriers below only order this wave's own LDS traffic.
+// One wavefront == one workgroup: cross-lane LDS hand-offs only need this wave's own LDS operations to have
+// completed (the LDS queue is in order per wave).  __syncthreads() would also drain vmcnt, i.e. wait for the
+// prefetched global loads and the output stores of the previous tile on every tile -- exactly the latency the
+// prefetch is there to hide -- so the hand-off is an LDS-only wait that the compiler may not move memory
+// operations across.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 struct Ring { // per-lane circular buffer in LDS; slot k of lane l at base + (k*64 + l)*8
     double *base; // already offset by the lane
     int depth, pos;
@@ -223,6 +232,19 @@ struct Ring { // per-lane circular buffer in LDS; slot k of lane l at base + (k*
         int k = pos - back;
         if (k < 0) k += depth;
         return base[k * 64];
+    }
+    // eight window values at once: out[u] = value pushed (back0 + DIR*u) pushes ago.  The addresses are plain selects
+    // (no branches), so the eight LDS reads go out back to back and are waited for once.  Backs outside [1, depth] read
+    // an arbitrary valid slot; the caller masks them.
+    template <int DIR>
+    __device__ void get8(int back0, double (&out)[8]) const {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int k = pos - (back0 + DIR * u);
+            k += (k < 0) ? depth : 0;
+            k = ((unsigned)k < (unsigned)depth) ? k : 0;
+            out[u] = base[k * 64];
+        }
     }
     __device__ void push(double v) {
         base[pos * 64] = v;
@@ -237,6 +259,12 @@ struct Ring { // per-lane circular buffer in LDS; slot k of lane l at base + (k*
 };
 struct RingAlloc {
     double *next; // lane-offset base of the free region
+    // n doubles shared by all lanes of the wave (returns the un-offset pointer); costs ceil(n/64) slots
+    __device__ double *make_shared(int64_t n) {
+        double *p = next - (threadIdx.x & 63);
+        next += (size_t)((n + 63) / 64) * 64;
+        return p;
+    }
     __device__ Ring make(int64_t depth) {
         Ring r;
         r.base = next;
@@ -253,9 +281,15 @@ struct HasRings { static constexpr bool value = false; };
 template <class Op>
 struct HasRings<Op, decltype((void)&Op::ring_slots)> { static constexpr bool value = true; };
 
+#ifndef PQ_K11
+#define PQ_K11 16
+#endif
+#ifndef PQ_KXX
+#define PQ_KXX 8
+#endif
 template <class Op>
 struct SeqTile {
-    static constexpr int K = (Op::NIN == 1 && Op::NOUT == 1) ? 16 : 8;   // rows per tile
+    static constexpr int K = (Op::NIN == 1 && Op::NOUT == 1) ? PQ_K11 : PQ_KXX;   // rows per tile
     static constexpr int NT = IsMasked<Op>::value ? Op::NIN : (Op::NIN > Op::NOUT ? Op::NIN : Op::NOUT);
     static constexpr int ROWB = K * 8 + 8;                                 // LDS row pitch in bytes
     static constexpr int TILE_BYTES = 64 * ROWB;
@@ -268,13 +302,6 @@ static inline size_t seq_lds_bytes(const Op &op) {
     return b;
 }
 constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to the gather body
-
-// One wavefront == one workgroup: cross-lane LDS hand-offs only need this wave's own LDS operations to have
-// completed (the LDS queue is in order per wave).  __syncthreads() would also drain vmcnt, i.e. wait for the
-// prefetched global loads and the output stores of the previous tile on every tile -- exactly the latency the
-// prefetch is there to hide -- so the hand-off is an LDS-only wait that the compiler may not move memory
-// operations across.
-__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
@@ -455,7 +482,7 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     }
     if (ctx->rec) {
         if constexpr (HasSeqId<Op>::value) {
-            static_assert(sizeof(Op) <= 512, "SEQ op too large for a job slot");
+            static_assert(sizeof(Op) <= 1024, "SEQ op too large for a job slot");
             return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");

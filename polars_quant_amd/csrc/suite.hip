@@ -19,9 +19,9 @@ struct SeqJob { // device-visible
     unsigned lds_bytes, pad_; // 0 = run the gather body
     const double *in[6];
     double *out[8];
-    alignas(8) unsigned char op[512];
+    alignas(8) unsigned char op[1024];
 };
-static_assert(sizeof(BtArgs) <= 512, "BtArgs must fit a job slot");
+static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
 
 struct Phase {
     std::vector<SeqJob> seq;   // sorted at finalize: [0, n_small) need <= SMALL_LDS bytes of LDS, the rest more
@@ -30,7 +30,7 @@ struct Phase {
     int n_small = 0;
     unsigned lds_small = 0, lds_large = 0;
 };
-constexpr unsigned SMALL_LDS = 26 * 1024; // 6 single-wave workgroups per CU
+constexpr unsigned SMALL_LDS = 26 * 1024; // <= 26 KB: 6 single-wave workgroups per CU; the rest (<= 64 KB) runs as a second grid
 struct Recorder {
     pq_batch b;
     hipStream_t aux[2] = {nullptr, nullptr}; // large-LDS SEQ grid / ROW launches run beside the main SEQ grid
@@ -52,7 +52,7 @@ struct pq_suite {
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(HtAllOp)                                                                   \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(HtAllOp) X(MavpBlockOp<0>) X(MavpBlockOp<1>)                                                                   \
     X(AtrOp<false>) X(AtrOp<true>) X(AdOp<false>) X(AdOp<true>) X(ObvOp) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>)
 
 __global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
@@ -93,6 +93,7 @@ static int job_cost(int kind) {
     if (kind == 9 || kind == 10) return 20;       // rolling extrema
     if ((kind >= 26 && kind <= 28) || kind == 78 || kind == 80) return 15; // DM family
     if (kind >= 74 && kind <= 77) return 14;      // stochastics, cci
+    if (kind == 81 || kind == 82) return 16;      // eight MAVP periods per walk
     if (kind == 6 || kind == 8) return 12;
     return 8;
 }
