@@ -232,6 +232,10 @@ pq_status pq_suite_abort(pq_ctx *ctx);
 pq_status pq_suite_run(pq_ctx *ctx, pq_suite *suite);
 pq_status pq_suite_destroy(pq_ctx *ctx, pq_suite *suite);
 pq_status pq_suite_info(const pq_suite *suite, int32_t *n_phases, int32_t *n_seq_jobs, int32_t *n_row_launches);
+/* measurement: HIP events around every sequential-job grid, on the stream it is launched on */
+pq_status pq_suite_set_timing(pq_suite *suite, int32_t on);
+pq_status pq_suite_grid_stats(pq_suite *suite, int32_t grid, double *avg_ms, double *algorithmic_bytes, int32_t *n_jobs,
+                              int32_t *lds_bytes, int32_t *runs);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,15 @@ struct SeqJob { // device-visible
 };
 static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
 
+struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-event timing
+    double alg_bytes = 0;
+    int n_jobs = 0;
+    unsigned lds = 0;
+    std::vector<hipEvent_t> ev; // start/stop pairs, one pair per timed run
+    int runs = 0;
+};
 struct Phase {
+    GridStat gs[2];            // [0] small-LDS grid, [1] large-LDS grid
     std::vector<SeqJob> seq;   // sorted at finalize: [0, n_small) need <= SMALL_LDS bytes of LDS, the rest more
     std::vector<RowThunk> rows;
     SeqJob *d_seq = nullptr;
@@ -39,6 +47,8 @@ struct Recorder {
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
     bool shared_out = false;
+    bool timing = false;
+    static constexpr int MAX_TIMED_RUNS = 64;
 };
 struct pq_suite {
     Recorder rec;
@@ -182,10 +192,25 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             return a.cost > b.cost;
         });
         p.n_small = 0; p.lds_small = 0; p.lds_large = 0;
+        const double rows = (double)r.b.n_series * (double)r.b.len;
+        std::map<const void *, int> masked_seen[2];
         for (const SeqJob &j : p.seq) {
-            if (j.lds_bytes <= SMALL_LDS) { p.n_small++; p.lds_small = std::max(p.lds_small, j.lds_bytes); }
+            const int g = j.lds_bytes <= SMALL_LDS ? 0 : 1;
+            if (g == 0) { p.n_small++; p.lds_small = std::max(p.lds_small, j.lds_bytes); }
             else p.lds_large = std::max(p.lds_large, j.lds_bytes);
+            // algorithmic bytes: 8 B per f64 column and row; a column written row-disjointly by several masked
+            // jobs counts once; the backtest job reads price and writes position/cash/equity (+ 64 B/symbol summary)
+            GridStat &st = p.gs[g];
+            st.n_jobs++;
+            if (j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1) { st.alg_bytes += 32.0 * rows + 64.0 * r.b.n_series; continue; }
+            st.alg_bytes += 8.0 * rows * j.nin;
+            const bool masked = (j.kind == 12) || (j.kind >= 100) || j.kind == 81 || j.kind == 82;
+            for (int k = 0; k < j.nout; k++) {
+                if (masked) { if (masked_seen[g][j.out[k]]++) continue; }
+                st.alg_bytes += 8.0 * rows;
+            }
         }
+        p.gs[0].lds = p.lds_small; p.gs[1].lds = p.lds_large;
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
     }
@@ -207,13 +232,31 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         // stream, the large-LDS SEQ grid and the ROW launches beside it on two side streams
         const bool has_large = (int)p.seq.size() > p.n_small, has_rows = !p.rows.empty();
         if (has_large || has_rows) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
-        if (p.n_small > 0)
+        auto timed = [&](GridStat &g, hipStream_t st, bool begin) -> hipError_t { // HIP events on the launch stream
+            if (!r.timing || g.runs >= Recorder::MAX_TIMED_RUNS) return hipSuccess;
+            size_t idx = (size_t)g.runs * 2 + (begin ? 0 : 1);
+            while (g.ev.size() <= idx) {
+                hipEvent_t e;
+                hipError_t er = hipEventCreate(&e);
+                if (er != hipSuccess) return er;
+                g.ev.push_back(e);
+            }
+            hipError_t er = hipEventRecord(g.ev[idx], st);
+            if (!begin) g.runs++;
+            return er;
+        };
+        if (p.n_small > 0) {
+            PQ_HIP_TRY(timed(p.gs[0], ctx->stream, true));
             hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)p.n_small), dim3(SEQ_BLOCK), p.lds_small, ctx->stream,
                                p.d_seq, d);
+            PQ_HIP_TRY(timed(p.gs[0], ctx->stream, false));
+        }
         if (has_large) {
             PQ_HIP_TRY(hipStreamWaitEvent(r.aux[0], r.ev_fork, 0));
+            PQ_HIP_TRY(timed(p.gs[1], r.aux[0], true));
             hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)(p.seq.size() - p.n_small)), dim3(SEQ_BLOCK),
                                p.lds_large, r.aux[0], p.d_seq + p.n_small, d);
+            PQ_HIP_TRY(timed(p.gs[1], r.aux[0], false));
             PQ_HIP_TRY(hipEventRecord(r.ev_join[0], r.aux[0]));
         }
         if (has_rows) {
@@ -234,7 +277,10 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
         if (r.ev_join[i]) { (void)hipEventDestroy(r.ev_join[i]); r.ev_join[i] = nullptr; }
     }
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
-    for (Phase &p : r.phases) if (p.d_seq) (void)hipFree(p.d_seq);
+    for (Phase &p : r.phases) {
+        if (p.d_seq) (void)hipFree(p.d_seq);
+        for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
+    }
     for (void *s : r.scratch) (void)hipFree(s);
     r.phases.clear();
     r.scratch.clear();
@@ -318,6 +364,38 @@ pq_status pq_suite_destroy(pq_ctx *ctx, pq_suite *s) {
     suite_free(ctx, s->rec);
     delete s;
     return PQ_OK;
+}
+pq_status pq_suite_set_timing(pq_suite *s, int32_t on) {
+    PQ_REQUIRE(s, "pq_suite_set_timing: null pointer");
+    s->rec.timing = on != 0;
+    for (Phase &p : s->rec.phases) for (GridStat &g : p.gs) g.runs = 0;
+    return PQ_OK;
+}
+// grid k (in launch order: phase 0 small-LDS, phase 0 large-LDS, phase 1 small, ...; empty grids skipped).
+// avg_ms = mean HIP-event time over the runs since pq_suite_set_timing(1) (0 if none); call after pq_ctx_sync.
+pq_status pq_suite_grid_stats(pq_suite *s, int32_t k, double *avg_ms, double *alg_bytes, int32_t *n_jobs, int32_t *lds_bytes,
+                              int32_t *runs) {
+    PQ_REQUIRE(s, "pq_suite_grid_stats: null pointer");
+    int idx = 0;
+    for (Phase &p : s->rec.phases)
+        for (GridStat &g : p.gs) {
+            if (g.n_jobs == 0) continue;
+            if (idx++ != k) continue;
+            double tot = 0;
+            for (int i = 0; i < g.runs; i++) {
+                float ms = 0;
+                PQ_HIP_TRY(hipEventElapsedTime(&ms, g.ev[2 * i], g.ev[2 * i + 1]));
+                tot += ms;
+            }
+            if (avg_ms) *avg_ms = g.runs ? tot / g.runs : 0.0;
+            if (alg_bytes) *alg_bytes = g.alg_bytes;
+            if (n_jobs) *n_jobs = g.n_jobs;
+            if (lds_bytes) *lds_bytes = (int32_t)g.lds;
+            if (runs) *runs = g.runs;
+            return PQ_OK;
+        }
+    pq_set_error("pq_suite_grid_stats: grid index out of range");
+    return PQ_ERR_ARG;
 }
 pq_status pq_suite_info(const pq_suite *s, int32_t *n_phases, int32_t *n_seq_jobs, int32_t *n_row_launches) {
     PQ_REQUIRE(s, "pq_suite_info: null pointer");

@@ -112,6 +112,22 @@ class Suite:
         check(lib().pq_suite_info(self._suite, C.byref(a), C.byref(b), C.byref(c)))
         return {"phases": a.value, "seq_jobs": b.value, "row_launches": c.value}
 
+    def set_timing(self, on: bool = True) -> None:
+        """HIP events around every sequential-job grid (on its launch stream) for the following runs"""
+        check(lib().pq_suite_set_timing(self._suite, 1 if on else 0))
+
+    def grid_stats(self):
+        """-> list of dicts per SEQ grid: avg_ms over the timed runs, algorithmic bytes per launch, jobs, LDS bytes"""
+        out, k = [], 0
+        while True:
+            ms, by, nj, lds, runs = C.c_double(), C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+            st = lib().pq_suite_grid_stats(self._suite, k, C.byref(ms), C.byref(by), C.byref(nj), C.byref(lds), C.byref(runs))
+            if st != 0:
+                break
+            out.append({"avg_ms": ms.value, "alg_bytes": by.value, "n_jobs": nj.value, "lds_bytes": lds.value, "runs": runs.value})
+            k += 1
+        return out
+
     def run(self, ohlcv: dict | None = None) -> None:
         """one step: every indicator + all 61 patterns + the MACD-cross backtest, enqueued on the current stream"""
         if getattr(self, "_suite", None) is None:
