@@ -30,19 +30,23 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
     std::vector<hipEvent_t> ev; // start/stop pairs, one pair per timed run
     int runs = 0;
 };
+// Jobs are grouped by LDS need: every workgroup of a launch gets the launch's (largest) dynamic LDS size, so one grid
+// for everything would pin all jobs to the occupancy of the hungriest one.  Three grids per phase, run concurrently.
+constexpr int NCLS = 3;
+constexpr unsigned CLS_LIMIT[NCLS] = {14 * 1024, 28 * 1024, 64 * 1024}; // ~11 / 5 / 2+ single-wave workgroups per CU
+static int lds_class(unsigned lds) { return lds <= CLS_LIMIT[0] ? 0 : (lds <= CLS_LIMIT[1] ? 1 : 2); }
 struct Phase {
-    GridStat gs[2];            // [0] small-LDS grid, [1] large-LDS grid
-    std::vector<SeqJob> seq;   // sorted at finalize: [0, n_small) need <= SMALL_LDS bytes of LDS, the rest more
+    GridStat gs[NCLS];
+    std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
     SeqJob *d_seq = nullptr;
-    int n_small = 0;
-    unsigned lds_small = 0, lds_large = 0;
+    int first[NCLS + 1] = {0, 0, 0, 0}; // job index range of each class
+    unsigned lds[NCLS] = {0, 0, 0};
 };
-constexpr unsigned SMALL_LDS = 26 * 1024; // <= 26 KB: 6 single-wave workgroups per CU; the rest (<= 64 KB) runs as a second grid
 struct Recorder {
     pq_batch b;
-    hipStream_t aux[2] = {nullptr, nullptr}; // large-LDS SEQ grid / ROW launches run beside the main SEQ grid
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux[NCLS] = {nullptr, nullptr, nullptr}; // classes 1.. of the SEQ grids + the ROW launches run beside class 0
+    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {nullptr, nullptr, nullptr};
     std::vector<Phase> phases;
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
@@ -185,19 +189,19 @@ void rec_set_shared_out(pq_ctx *ctx, bool on) {
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
     for (Phase &p : r.phases) {
         if (p.seq.empty()) continue;
-        // small-LDS jobs first (one grid at 6 workgroups/CU), large-LDS jobs second; longest jobs lead each grid
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) {
-            bool la = a.lds_bytes > SMALL_LDS, lb = b.lds_bytes > SMALL_LDS;
-            if (la != lb) return lb;
+            int ca = lds_class(a.lds_bytes), cb = lds_class(b.lds_bytes);
+            if (ca != cb) return ca < cb;
             return a.cost > b.cost;
         });
-        p.n_small = 0; p.lds_small = 0; p.lds_large = 0;
         const double rows = (double)r.b.n_series * (double)r.b.len;
-        std::map<const void *, int> masked_seen[2];
+        std::map<const void *, int> masked_seen[NCLS];
+        for (int c = 0; c <= NCLS; c++) p.first[c] = 0;
+        for (int c = 0; c < NCLS; c++) { p.lds[c] = 0; p.gs[c].alg_bytes = 0; p.gs[c].n_jobs = 0; }
         for (const SeqJob &j : p.seq) {
-            const int g = j.lds_bytes <= SMALL_LDS ? 0 : 1;
-            if (g == 0) { p.n_small++; p.lds_small = std::max(p.lds_small, j.lds_bytes); }
-            else p.lds_large = std::max(p.lds_large, j.lds_bytes);
+            const int g = lds_class(j.lds_bytes);
+            p.first[g + 1]++;
+            p.lds[g] = std::max(p.lds[g], j.lds_bytes);
             // algorithmic bytes: 8 B per f64 column and row; a column written row-disjointly by several masked
             // jobs counts once; the backtest job reads price and writes position/cash/equity (+ 64 B/symbol summary)
             GridStat &st = p.gs[g];
@@ -210,7 +214,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
                 st.alg_bytes += 8.0 * rows;
             }
         }
-        p.gs[0].lds = p.lds_small; p.gs[1].lds = p.lds_large;
+        for (int c = 0; c < NCLS; c++) { p.first[c + 1] += p.first[c]; p.gs[c].lds = p.lds[c]; }
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
     }
@@ -220,7 +224,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     Dims d = dims_of(&r.b);
     if (!r.aux[0]) { // lazily create the side streams (they live as long as the suite)
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < NCLS; i++) {
             PQ_HIP_TRY(hipStreamCreateWithFlags(&r.aux[i], hipStreamNonBlocking));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
@@ -228,10 +232,8 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     }
     const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
     for (Phase &p : r.phases) {
-        // the launches of one phase are independent of each other: the small-LDS SEQ grid runs on the caller's
-        // stream, the large-LDS SEQ grid and the ROW launches beside it on two side streams
-        const bool has_large = (int)p.seq.size() > p.n_small, has_rows = !p.rows.empty();
-        if (has_large || has_rows) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
+        // the launches of one phase are independent of each other: SEQ grid class 0 runs on the caller's stream, classes
+        // 1.. on side streams aux[0..], the ROW launches on the last side stream
         auto timed = [&](GridStat &g, hipStream_t st, bool begin) -> hipError_t { // HIP events on the launch stream
             if (!r.timing || g.runs >= Recorder::MAX_TIMED_RUNS) return hipSuccess;
             size_t idx = (size_t)g.runs * 2 + (begin ? 0 : 1);
@@ -245,34 +247,39 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             if (!begin) g.runs++;
             return er;
         };
-        if (p.n_small > 0) {
-            PQ_HIP_TRY(timed(p.gs[0], ctx->stream, true));
-            hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)p.n_small), dim3(SEQ_BLOCK), p.lds_small, ctx->stream,
-                               p.d_seq, d);
-            PQ_HIP_TRY(timed(p.gs[0], ctx->stream, false));
+        bool side[NCLS] = {false, false, false};
+        for (int c = 1; c < NCLS; c++) side[c - 1] = p.first[c + 1] > p.first[c];
+        side[NCLS - 1] = !p.rows.empty();
+        bool any_side = false;
+        for (int i = 0; i < NCLS; i++) any_side |= side[i];
+        if (any_side) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
+        // hungriest class first: its workgroups need a large contiguous LDS block each and would otherwise starve behind
+        // the steady stream of small allocations until the other grids drain
+        for (int c = NCLS - 1; c >= 0; c--) {
+            const int nj = p.first[c + 1] - p.first[c];
+            if (nj <= 0) continue;
+            hipStream_t st = c == 0 ? ctx->stream : r.aux[c - 1];
+            if (c > 0) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
+            PQ_HIP_TRY(timed(p.gs[c], st, true));
+            hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)nj), dim3(SEQ_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d);
+            PQ_HIP_TRY(timed(p.gs[c], st, false));
+            if (c > 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[c - 1], st));
         }
-        if (has_large) {
-            PQ_HIP_TRY(hipStreamWaitEvent(r.aux[0], r.ev_fork, 0));
-            PQ_HIP_TRY(timed(p.gs[1], r.aux[0], true));
-            hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)(p.seq.size() - p.n_small)), dim3(SEQ_BLOCK),
-                               p.lds_large, r.aux[0], p.d_seq + p.n_small, d);
-            PQ_HIP_TRY(timed(p.gs[1], r.aux[0], false));
-            PQ_HIP_TRY(hipEventRecord(r.ev_join[0], r.aux[0]));
+        if (side[NCLS - 1]) {
+            hipStream_t st = r.aux[NCLS - 1];
+            PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
+            for (const RowThunk &t : p.rows) t.launch(t.blob, st);
+            PQ_HIP_TRY(hipEventRecord(r.ev_join[NCLS - 1], st));
         }
-        if (has_rows) {
-            PQ_HIP_TRY(hipStreamWaitEvent(r.aux[1], r.ev_fork, 0));
-            for (const RowThunk &t : p.rows) t.launch(t.blob, r.aux[1]);
-            PQ_HIP_TRY(hipEventRecord(r.ev_join[1], r.aux[1]));
-        }
-        if (has_large) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[0], 0));
-        if (has_rows) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[1], 0));
+        for (int i = 0; i < NCLS; i++)
+            if (side[i]) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[i], 0));
     }
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }
 static void suite_free(pq_ctx *ctx, Recorder &r) {
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NCLS; i++) {
         if (r.aux[i]) { (void)hipStreamSynchronize(r.aux[i]); (void)hipStreamDestroy(r.aux[i]); r.aux[i] = nullptr; }
         if (r.ev_join[i]) { (void)hipEventDestroy(r.ev_join[i]); r.ev_join[i] = nullptr; }
     }
