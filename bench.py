@@ -83,6 +83,7 @@ def main():
         if world > 1:   # the one exchange of the path: per-symbol summary rows to every rank (RCCL over xGMI)
             gather_summaries(suite.summary, world * n_local)
 
+    suite.record(ohlcv)   # one-time: turn the step's calls into job grids (not part of the timed region)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -116,6 +117,13 @@ def main():
     achieved = mean_bytes / (mean_ms * 1e-3) / 1e9
     suite_bytes = suite.suite_bytes_per_row() * rows_local
     suite_gbs = suite_bytes / (elapsed / args.steps) / 1e9
+    # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    # command; summary committed by scripts/pmc_summary.py).  Only valid for the configuration it was collected on.
+    traffic = None
+    pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+    if pmc.exists() and n_local == N_SYM and T == T_DAYS:
+        k = json.loads(pmc.read_text())["kernels"].get("seq_jobs_kernel")
+        traffic = k["hbm_bytes_per_launch"] if k else None
 
     if rank == 0:
         rows_total = world * rows_local * args.steps
@@ -131,7 +139,7 @@ def main():
                        "algorithmic_bytes_per_row": suite.suite_bytes_per_row(),
                        "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "kernel": "seq_jobs_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": mean_bytes, "avg_launch_ms": mean_ms,
                          "launches_per_step": len(grids),
                          "grids": [{k: g[k] for k in ("avg_ms", "alg_bytes", "n_jobs", "lds_bytes")} for g in grids]},

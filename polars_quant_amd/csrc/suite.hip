@@ -11,6 +11,8 @@
 #include "ops_backtest.h"
 #include "ops_fused.h"
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
 #include <map>
 #include <vector>
 
@@ -215,6 +217,8 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         for (int c = 0; c < NCLS; c++) { p.first[c + 1] += p.first[c]; p.gs[c].lds = p.lds[c]; }
+        if (getenv("PQ_SUITE_DEBUG"))
+            for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost);
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
     }
