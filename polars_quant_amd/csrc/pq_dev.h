@@ -290,7 +290,12 @@ struct HasRings<Op, decltype((void)&Op::ring_slots)> { static constexpr bool val
 template <class Op>
 struct SeqTile {
     static constexpr int K = (Op::NIN == 1 && Op::NOUT == 1) ? PQ_K11 : PQ_KXX;   // rows per tile
-    static constexpr int NT = IsMasked<Op>::value ? Op::NIN : (Op::NIN > Op::NOUT ? Op::NIN : Op::NOUT);
+#ifdef PQ_DIRECT_STORES
+    static constexpr bool DIRECT = true;  // experiment: outputs by per-lane 8-byte stores, no output tiles
+#else
+    static constexpr bool DIRECT = IsMasked<Op>::value;
+#endif
+    static constexpr int NT = DIRECT ? Op::NIN : (Op::NIN > Op::NOUT ? Op::NIN : Op::NOUT);
     static constexpr int ROWB = K * 8 + 8;                                 // LDS row pitch in bytes
     static constexpr int TILE_BYTES = 64 * ROWB;
     static constexpr int BYTES = NT * TILE_BYTES;
@@ -303,15 +308,17 @@ static inline size_t seq_lds_bytes(const Op &op) {
 }
 constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to the gather body
 
+// ring_ws: nullptr = the rings live in LDS behind the tiles; else a global-memory region of this wave's own
+// ([slot][lane] exactly as in LDS) -- trades LDS footprint (occupancy) for L2 round trips
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
-                                            int64_t tile_s0, unsigned char *lds) {
+                                            int64_t tile_s0, unsigned char *lds, double *ring_ws = nullptr) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
     constexpr int TB = SeqTile<Op>::TILE_BYTES;
     constexpr int CPL = K / 2;      // 16-byte chunks (lanes) per series segment
     constexpr int SPI = 64 / CPL;   // series covered by one wave-wide access
     constexpr int NI = 64 / SPI;    // accesses per column tile
-    constexpr bool MASKED = IsMasked<Op>::value;
+    constexpr bool MASKED = SeqTile<Op>::DIRECT; // direct per-lane stores (masked ops must; others only in the experiment)
     static_assert(NTap<Op>::value == 0 || HasRings<Op>::value, "an op with lag taps needs a ring variant for the LDS body");
     const int lane = threadIdx.x;
     const int64_t s = tile_s0 + lane;
@@ -329,7 +336,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
     for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + srow * d.stride;
     if constexpr (HasRings<Op>::value) {
-        RingAlloc ra{reinterpret_cast<double *>(lds + SeqTile<Op>::BYTES) + lane};
+        RingAlloc ra{(ring_ws ? ring_ws : reinterpret_cast<double *>(lds + SeqTile<Op>::BYTES)) + lane};
         op.init_lds(r, ra);
     } else {
         op.init(r);
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> i
 // ---- recording hooks (implemented in suite.hip)
 // a recordable SEQ op carries `static constexpr int SEQ_ID` = its switch case in the job grid (suite.hip)
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes);
+                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes);
 struct RowThunk { // type-erased ROW launch for replay
     void (*launch)(const void *blob, hipStream_t stream);
     unsigned char blob[1200];
@@ -483,7 +490,8 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     if (ctx->rec) {
         if constexpr (HasSeqId<Op>::value) {
             static_assert(sizeof(Op) <= 1024, "SEQ op too large for a job slot");
-            return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0);
+            return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0,
+                               SeqTile<Op>::BYTES);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");
             return PQ_ERR_UNSUPPORTED;

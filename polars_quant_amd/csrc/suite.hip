@@ -18,7 +18,9 @@
 
 struct SeqJob { // device-visible
     int kind, nin, nout, cost;
-    unsigned lds_bytes, pad_; // 0 = run the gather body
+    unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
+    double *ring_ws;               // non-null: rings in global memory, [tile][slot][lane]
+    unsigned long long ring_stride; // doubles per 64-symbol tile
     const double *in[6];
     double *out[8];
     alignas(8) unsigned char op[1024];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs,
     case OP::SEQ_ID: {                                               \
         OP op;                                                       \
         __builtin_memcpy(&op, job.op, sizeof(OP));                   \
-        if (job.lds_bytes) run_seq_lds(op, job.in, job.out, d, s0, jobs_lds); \
+        if (job.lds_bytes) run_seq_lds(op, job.in, job.out, d, s0, jobs_lds, job.ring_ws ? job.ring_ws + blockIdx.x * job.ring_stride : nullptr); \
         else run_seq(op, job.in, job.out, d, s);                     \
     } break;
         SEQ_OPS(X)
@@ -149,13 +151,13 @@ static pq_status same_batch(Recorder &r, const pq_batch *b) {
 }
 
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes) {
+                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
     if (nin > 6 || nout > 8) { pq_set_error("internal: SEQ job has too many columns"); return PQ_ERR_UNSUPPORTED; }
     SeqJob j;
     memset(&j, 0, sizeof j);
-    j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind); j.lds_bytes = (unsigned)lds_bytes;
+    j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind); j.lds_bytes = (unsigned)lds_bytes; j.tile_bytes = (unsigned)tile_bytes;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
     memcpy(j.op, op, op_bytes);
@@ -189,8 +191,23 @@ void rec_set_shared_out(pq_ctx *ctx, bool on) {
 }
 
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
+    const char *gr = getenv("PQ_GLOBAL_RINGS");
+    const unsigned gr_min = gr ? (unsigned)atoi(gr) : 0; // experiment: jobs needing more LDS than this keep their rings in global memory
     for (Phase &p : r.phases) {
         if (p.seq.empty()) continue;
+        if (gr_min) {
+            const size_t tiles = (size_t)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
+            for (SeqJob &j : p.seq) {
+                if (j.lds_bytes <= gr_min || j.lds_bytes <= j.tile_bytes) continue;
+                size_t ring_bytes = j.lds_bytes - j.tile_bytes;
+                void *ws = nullptr;
+                PQ_HIP_TRY(hipMalloc(&ws, ring_bytes * tiles));
+                r.scratch.push_back(ws);
+                j.ring_ws = (double *)ws;
+                j.ring_stride = ring_bytes / 8;
+                j.lds_bytes = j.tile_bytes;
+            }
+        }
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) {
             int ca = lds_class(a.lds_bytes), cb = lds_class(b.lds_bytes);
             if (ca != cb) return ca < cb;
