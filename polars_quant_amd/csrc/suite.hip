@@ -245,8 +245,13 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     Dims d = dims_of(&r.b);
     if (!r.aux[0]) { // lazily create the side streams (they live as long as the suite)
+        int prio_lo = 0, prio_hi = 0;
+        PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)); // numerically lower = higher priority
         for (int i = 0; i < NCLS; i++) {
-            PQ_HIP_TRY(hipStreamCreateWithFlags(&r.aux[i], hipStreamNonBlocking));
+            // the LDS-hungry grids get dispatch priority: their workgroups need a large contiguous LDS block and lose every
+            // race for freed LDS against the small allocations of the other grids otherwise
+            int prio = (i < NCLS - 1 && !getenv("PQ_NO_PRIO")) ? prio_hi : prio_lo;
+            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, prio));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
         PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
