@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--symbols", type=int, default=N_SYM, help="symbols per GPU (weak scaling)")
     ap.add_argument("--days", type=int, default=T_DAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stride", type=int, default=0, help="elements between series starts in HBM (0 = dense = days)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +76,13 @@ def main():
     from polars_quant_amd.suite import Suite
     n_local, T = args.symbols, args.days
     ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
-    suite = Suite(n_local, T, dev)
+    stride = args.stride or T
+    if stride != T:  # re-house the inputs with the padded row pitch
+        for k in list(ohlcv):
+            buf = torch.zeros((n_local, stride), dtype=torch.float64, device=dev)
+            buf[:, :T] = ohlcv[k]
+            ohlcv[k] = buf[:, :T]
+    suite = Suite(n_local, T, dev, stride=stride)
     from polars_quant_amd.distributed import gather_summaries
 
     def step():

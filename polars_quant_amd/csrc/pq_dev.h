@@ -310,6 +310,14 @@ constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to th
 
 // ring_ws: nullptr = the rings live in LDS behind the tiles; else a global-memory region of this wave's own
 // ([slot][lane] exactly as in LDS) -- trades LDS footprint (occupancy) for L2 round trips
+// The LDS body runs in a 2-wavefront workgroup: wave 0 loads + computes, wave 1 only stores.  Reason: gfx950 counts loads
+// and stores in ONE counter (vmcnt), loads retire in order but stores do not, so a wave with stores in flight cannot wait
+// for a prefetched load without also waiting for every store it has issued (measured: a tile copy by one wave runs at
+// ~1 TB/s, split across a loading and a storing wave at ~2 TB/s, scripts/ubench/).  With the stores in another wave,
+// wave 0's counter holds loads only and the prefetch is waited for exactly; wave 1 never waits on vmcnt at all.
+// Hand-off per tile: wave 0 finishes the out tile in LDS -> barrier A -> wave 1 pulls it into registers -> barrier B ->
+// wave 1 issues the global stores while wave 0 already overwrites LDS with the next input tile.
+constexpr int SEQ_LDS_BLOCK = 128;
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
                                             int64_t tile_s0, unsigned char *lds, double *ring_ws = nullptr) {
@@ -318,12 +326,10 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     constexpr int CPL = K / 2;      // 16-byte chunks (lanes) per series segment
     constexpr int SPI = 64 / CPL;   // series covered by one wave-wide access
     constexpr int NI = 64 / SPI;    // accesses per column tile
-    constexpr bool MASKED = SeqTile<Op>::DIRECT; // direct per-lane stores (masked ops must; others only in the experiment)
+    constexpr bool MASKED = SeqTile<Op>::DIRECT; // per-lane stores by wave 0 (row-masked outputs)
     static_assert(NTap<Op>::value == 0 || HasRings<Op>::value, "an op with lag taps needs a ring variant for the LDS body");
-    const int lane = threadIdx.x;
-    const int64_t s = tile_s0 + lane;
-    const bool live = s < d.n;
-    const int64_t srow = live ? s : d.n - 1; // dead lanes shadow the last series (never stored)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t T = d.len, nt = T / K;
     const int csym = lane / CPL, cchunk = lane % CPL;
     int64_t crow[NI]; // global row offsets of the series this lane helps to move
 #pragma unroll
@@ -331,6 +337,39 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         int64_t cs = tile_s0 + i * SPI + csym;
         crow[i] = (cs < d.n ? cs : d.n - 1) * d.stride + cchunk * 2;
     }
+    unsigned char *co_row[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) co_row[i] = lds + (i * SPI + csym) * ROWB + cchunk * 16;
+
+    if (wave == 1) { // ---------------------------------------------------------------- storer
+        if constexpr (!MASKED) {
+            for (int64_t it = 0; it < nt; it++) {
+                __builtin_amdgcn_s_barrier(); // A: out tile `it` is complete
+                lds_fence();
+                double2 v[NOUT][NI];
+#pragma unroll
+                for (int k = 0; k < NOUT; k++)
+#pragma unroll
+                    for (int i = 0; i < NI; i++) { // two b64 reads: LDS rows are only 8-byte aligned
+                        const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
+                        v[k][i] = make_double2(q[0], q[1]);
+                    }
+                lds_fence();
+                __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
+                const int64_t t0 = it * K;
+#pragma unroll
+                for (int k = 0; k < NOUT; k++)
+#pragma unroll
+                    for (int i = 0; i < NI; i++)
+                        if (tile_s0 + i * SPI + csym < d.n) *reinterpret_cast<double2 *>(outp[k] + crow[i] + t0) = v[k][i];
+            }
+        }
+        return;
+    }
+    // -------------------------------------------------------------------------------- loader + compute
+    const int64_t s = tile_s0 + lane;
+    const bool live = s < d.n;
+    const int64_t srow = live ? s : d.n - 1; // dead lanes shadow the last series (never stored)
     Row<NIN> r;
     r.len = d.len;
 #pragma unroll
@@ -341,30 +380,27 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     } else {
         op.init(r);
     }
-    const int64_t T = d.len, nt = T / K;
-    double2 pre[NIN][NI];
-    auto prefetch = [&](int64_t t0) {
+    unsigned char *my_row = lds + lane * ROWB;
+    // wave 0 has no stores in flight (except for MASKED ops), so its prefetched loads can be waited for exactly
+    constexpr int PF = 1; // (a second tile of prefetch costs 16-32 VGPRs per input column and bought nothing measurable)
+    double2 pre[PF][NIN][NI];
+    auto prefetch = [&](double2 (&buf)[NIN][NI], int64_t t0) {
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
-            for (int i = 0; i < NI; i++) pre[k][i] = *reinterpret_cast<const double2 *>(inp[k] + crow[i] + t0);
+            for (int i = 0; i < NI; i++) buf[k][i] = *reinterpret_cast<const double2 *>(inp[k] + crow[i] + t0);
     };
-    unsigned char *my_row = lds + lane * ROWB;
-    unsigned char *co_row[NI];
-#pragma unroll
-    for (int i = 0; i < NI; i++) co_row[i] = lds + (i * SPI + csym) * ROWB + cchunk * 16;
-    if (nt > 0) prefetch(0);
-    for (int64_t it = 0; it < nt; it++) {
+    auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
             for (int i = 0; i < NI; i++) { // two b64 stores: LDS rows are only 8-byte aligned
                 double *q = reinterpret_cast<double *>(co_row[i] + k * TB);
-                q[0] = pre[k][i].x;
-                q[1] = pre[k][i].y;
+                q[0] = buf[k][i].x;
+                q[1] = buf[k][i].y;
             }
-        if (it + 1 < nt) prefetch(t0 + K);
+        if (it + PF < nt) prefetch(buf, t0 + PF * K);
         lds_fence();
         // one row at a time, NOT unrolled: every job of a suite grid runs different code, and K copies of each
         // op body would thrash the instruction cache; the next row's inputs are read from LDS ahead of the step
@@ -380,8 +416,12 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                 for (int k = 0; k < NIN; k++) xn[k] = *reinterpret_cast<const double *>(my_row + k * TB + (j + 1) * 8);
             }
+#ifdef PQ_EXP_NOCOMPUTE
+            for (int k = 0; k < NOUT; k++) y[k] = x[0] + (double)k; // experiment: memory pipeline only
+#else
             if constexpr (HasRings<Op>::value) op.step_lds(t0 + j, x, y);
             else op.step(r, t0 + j, x, y);
+#endif
             if constexpr (MASKED) {
 #pragma unroll
                 for (int k = 0; k < NOUT; k++)
@@ -393,16 +433,17 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         }
         lds_fence();
         if constexpr (!MASKED) {
-#pragma unroll
-            for (int k = 0; k < NOUT; k++)
-#pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
-                    double2 v = make_double2(q[0], q[1]);
-                    if (tile_s0 + i * SPI + csym < d.n) *reinterpret_cast<double2 *>(outp[k] + crow[i] + t0) = v;
-                }
-            lds_fence();
+            __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
+            __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
         }
+    };
+#pragma unroll
+    for (int f = 0; f < PF; f++)
+        if (f < nt) prefetch(pre[f], (int64_t)f * K);
+    for (int64_t it = 0; it < nt; it += PF) {
+#pragma unroll
+        for (int f = 0; f < PF; f++)
+            if (it + f < nt) do_tile(pre[f], it + f);
     }
     if (live) { // ragged tail: fewer than K rows left
         for (int64_t t = nt * K; t < T; t++) {
@@ -428,7 +469,7 @@ static inline bool seq_cols_aligned(const pq_batch *b, const double *const *in, 
 }
 
 template <class Op, bool LDS>
-__global__ __launch_bounds__(SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
+__global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
     if constexpr (LDS) {
         extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
         run_seq_lds(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
@@ -498,7 +539,7 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
         }
     }
     dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
-    if (use_lds) hipLaunchKernelGGL((seq_kernel<Op, true>), grid, dim3(SEQ_BLOCK), lds, ctx->stream, op, in, out, dims_of(b));
+    if (use_lds) hipLaunchKernelGGL((seq_kernel<Op, true>), grid, dim3(SEQ_LDS_BLOCK), lds, ctx->stream, op, in, out, dims_of(b));
     else hipLaunchKernelGGL((seq_kernel<Op, false>), grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b));
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;

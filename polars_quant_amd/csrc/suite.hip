@@ -36,21 +36,24 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
 };
 // Jobs are grouped by LDS need: every workgroup of a launch gets the launch's (largest) dynamic LDS size, so one grid
 // for everything would pin all jobs to the occupancy of the hungriest one.  Three grids per phase, run concurrently.
-constexpr int NCLS = 3;
-constexpr unsigned CLS_LIMIT[NCLS] = {14 * 1024, 28 * 1024, 64 * 1024}; // ~11 / 5 / 2+ single-wave workgroups per CU
+constexpr int NLDS = 3;         // LDS classes
+constexpr int NCLS = 2 * NLDS + 1; // x kernel variant (light / heavy registers) + the gather-body class
+constexpr unsigned CLS_LIMIT[NLDS] = {14 * 1024, 28 * 1024, 64 * 1024}; // ~11 / 5 / 2+ workgroups per CU by LDS
+static bool kind_is_heavy(int kind);
 static int lds_class(unsigned lds) { return lds <= CLS_LIMIT[0] ? 0 : (lds <= CLS_LIMIT[1] ? 1 : 2); }
+static int job_class(int kind, unsigned lds) { return lds == 0 ? 2 * NLDS : lds_class(lds) + (kind_is_heavy(kind) ? NLDS : 0); }
 struct Phase {
     GridStat gs[NCLS];
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
     SeqJob *d_seq = nullptr;
-    int first[NCLS + 1] = {0, 0, 0, 0}; // job index range of each class
-    unsigned lds[NCLS] = {0, 0, 0};
+    int first[NCLS + 1] = {}; // job index range of each class
+    unsigned lds[NCLS] = {};
 };
 struct Recorder {
     pq_batch b;
-    hipStream_t aux[NCLS] = {nullptr, nullptr, nullptr}; // classes 1.. of the SEQ grids + the ROW launches run beside class 0
-    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[NCLS] = {}; // classes 1.. of the SEQ grids + the ROW launches run beside class 0
+    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {};
     std::vector<Phase> phases;
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
@@ -62,45 +65,66 @@ struct pq_suite {
     Recorder rec;
 };
 
-// every recordable SEQ op: X(Type)
-#define SEQ_OPS(X)                                                                                                   \
+// every recordable SEQ op: X(Type).  Two kernel variants: the register-hungry ops (Hilbert pipeline, AD/ADOSC) would pin
+// the whole grid to 2 waves/SIMD, so they get their own kernel and everything else is compiled for 4 waves/SIMD.
+#define SEQ_OPS_LIGHT(X)                                                                                             \
     X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
     X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
     X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
-    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(HtAllOp) X(MavpBlockOp<0>) X(MavpBlockOp<1>)                                                                   \
-    X(AtrOp<false>) X(AtrOp<true>) X(AdOp<false>) X(AdOp<true>) X(ObvOp) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>)
+    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochRsiOp) X(CciOp)                                 \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<0>) X(MavpBlockOp<1>)                                          \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp)
+#define SEQ_OPS_HEAVY(X)                                                                                             \
+    X(StochOp<0>) X(StochOp<1>) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp)
+static bool kind_is_heavy(int kind) { return kind == 42 || kind == 43 || (kind >= 45 && kind <= 49) || kind == 74 || kind == 75 || kind == 79; }
 
-__global__ __launch_bounds__(SEQ_BLOCK) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char jobs_lds[];
+// V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
+// backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
+template <int V>
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 4 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
+    extern __shared__ __align__(16) unsigned char jobs_lds[];
     const SeqJob &job = jobs[blockIdx.y];
     const int64_t s0 = (int64_t)blockIdx.x * SEQ_BLOCK;
     const int64_t s = s0 + threadIdx.x;
-    if (job.lds_bytes == 0 && s >= d.n) return; // gather bodies are per-lane; LDS bodies need the whole wave
-    switch (job.kind) { // wave-uniform
-#define X(OP)                                                        \
-    case OP::SEQ_ID: {                                               \
-        OP op;                                                       \
-        __builtin_memcpy(&op, job.op, sizeof(OP));                   \
-        if (job.lds_bytes) run_seq_lds(op, job.in, job.out, d, s0, jobs_lds, job.ring_ws ? job.ring_ws + blockIdx.x * job.ring_stride : nullptr); \
-        else run_seq(op, job.in, job.out, d, s);                     \
+#define X(OP)                                                                                                        \
+    case OP::SEQ_ID: {                                                                                               \
+        OP op;                                                                                                       \
+        __builtin_memcpy(&op, job.op, sizeof(OP));                                                                   \
+        if constexpr (V == 2) run_seq(op, job.in, job.out, d, s);                                                    \
+        else                                                                                                         \
+            run_seq_lds(op, job.in, job.out, d, s0, jobs_lds, job.ring_ws ? job.ring_ws + blockIdx.x * job.ring_stride : nullptr); \
     } break;
-        SEQ_OPS(X)
-#undef X
-    case SEQ_ID_BACKTEST: {
-        BtArgs a;
-        __builtin_memcpy(&a, job.op, sizeof(BtArgs));
-        if (s < d.n) backtest_body<false, false>(a, d, s);
-    } break;
-    case SEQ_ID_BACKTEST + 1: {
-        BtArgs a;
-        __builtin_memcpy(&a, job.op, sizeof(BtArgs));
-        if (s < d.n) backtest_body<true, false>(a, d, s);
-    } break;
-    default: break;
+    if constexpr (V == 2) {
+        if (s >= d.n) return; // gather bodies are per-lane work
+        switch (job.kind) {   // wave-uniform
+            SEQ_OPS_LIGHT(X)
+            SEQ_OPS_HEAVY(X)
+        case SEQ_ID_BACKTEST: {
+            BtArgs a;
+            __builtin_memcpy(&a, job.op, sizeof(BtArgs));
+            backtest_body<false, false>(a, d, s);
+        } break;
+        case SEQ_ID_BACKTEST + 1: {
+            BtArgs a;
+            __builtin_memcpy(&a, job.op, sizeof(BtArgs));
+            backtest_body<true, false>(a, d, s);
+        } break;
+        default: break;
+        }
+    } else if constexpr (V == 1) {
+        switch (job.kind) {
+            SEQ_OPS_HEAVY(X)
+        default: break;
+        }
+    } else {
+        switch (job.kind) {
+            SEQ_OPS_LIGHT(X)
+        default: break;
+        }
     }
+#undef X
 }
 
 // rough relative cost per row, used to start the longest jobs first
@@ -209,7 +233,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) {
-            int ca = lds_class(a.lds_bytes), cb = lds_class(b.lds_bytes);
+            int ca = job_class(a.kind, a.lds_bytes), cb = job_class(b.kind, b.lds_bytes);
             if (ca != cb) return ca < cb;
             return a.cost > b.cost;
         });
@@ -218,7 +242,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         for (int c = 0; c <= NCLS; c++) p.first[c] = 0;
         for (int c = 0; c < NCLS; c++) { p.lds[c] = 0; p.gs[c].alg_bytes = 0; p.gs[c].n_jobs = 0; }
         for (const SeqJob &j : p.seq) {
-            const int g = lds_class(j.lds_bytes);
+            const int g = job_class(j.kind, j.lds_bytes);
             p.first[g + 1]++;
             p.lds[g] = std::max(p.lds[g], j.lds_bytes);
             // algorithmic bytes: 8 B per f64 column and row; a column written row-disjointly by several masked
@@ -250,7 +274,7 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         for (int i = 0; i < NCLS; i++) {
             // the LDS-hungry grids get dispatch priority: their workgroups need a large contiguous LDS block and lose every
             // race for freed LDS against the small allocations of the other grids otherwise
-            int prio = (i < NCLS - 1 && !getenv("PQ_NO_PRIO")) ? prio_hi : prio_lo;
+            int prio = (i < NCLS - 1 && (i % NLDS) != NLDS - 1 && !getenv("PQ_NO_PRIO")) ? prio_hi : prio_lo;
             PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, prio));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
@@ -273,8 +297,9 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             if (!begin) g.runs++;
             return er;
         };
-        bool side[NCLS] = {false, false, false};
-        for (int c = 1; c < NCLS; c++) side[c - 1] = p.first[c + 1] > p.first[c];
+        static const bool serial = getenv("PQ_SERIAL_CLASSES") != nullptr; // experiment: classes back to back on one stream
+        bool side[NCLS] = {};
+        for (int c = 1; c < NCLS; c++) side[c - 1] = !serial && p.first[c + 1] > p.first[c];
         side[NCLS - 1] = !p.rows.empty();
         bool any_side = false;
         for (int i = 0; i < NCLS; i++) any_side |= side[i];
@@ -284,12 +309,14 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         for (int c = NCLS - 1; c >= 0; c--) {
             const int nj = p.first[c + 1] - p.first[c];
             if (nj <= 0) continue;
-            hipStream_t st = c == 0 ? ctx->stream : r.aux[c - 1];
-            if (c > 0) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
+            hipStream_t st = (c == 0 || serial) ? ctx->stream : r.aux[c - 1];
+            if (c > 0 && !serial) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
             PQ_HIP_TRY(timed(p.gs[c], st, true));
-            hipLaunchKernelGGL(seq_jobs_kernel, dim3(tiles, (unsigned)nj), dim3(SEQ_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d);
+            if (c == 2 * NLDS) hipLaunchKernelGGL(seq_jobs_kernel<2>, dim3(tiles, (unsigned)nj), dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d);
+            else if (c >= NLDS) hipLaunchKernelGGL(seq_jobs_kernel<1>, dim3(tiles, (unsigned)nj), dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d);
+            else hipLaunchKernelGGL(seq_jobs_kernel<0>, dim3(tiles, (unsigned)nj), dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d);
             PQ_HIP_TRY(timed(p.gs[c], st, false));
-            if (c > 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[c - 1], st));
+            if (c > 0 && !serial) PQ_HIP_TRY(hipEventRecord(r.ev_join[c - 1], st));
         }
         if (side[NCLS - 1]) {
             hipStream_t st = r.aux[NCLS - 1];

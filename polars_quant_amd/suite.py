@@ -27,17 +27,22 @@ def algorithmic_bytes_per_row() -> dict:
 
 
 class Suite:
-    def __init__(self, n_series: int, T: int, device="cuda"):
+    def __init__(self, n_series: int, T: int, device="cuda", stride: int | None = None):
+        """stride (elements between consecutive series, >= T): rows whose byte pitch is a multiple of 128 B keep every
+        64/128-byte tile segment inside one cache line; default = T (dense)"""
         self.n, self.T = n_series, T
+        self.stride = T if stride is None else int(stride)
+        assert self.stride >= T
         self.dev = torch.device(device)
-        self.batch = Batch(n_series, T, T)
-        f64 = lambda: torch.empty((n_series, T), dtype=torch.float64, device=self.dev)
-        i32 = lambda: torch.empty((n_series, T), dtype=torch.int32, device=self.dev)
+        self.batch = Batch(n_series, T, self.stride)
+        f64 = lambda: torch.empty((n_series, self.stride), dtype=torch.float64, device=self.dev)[:, :T]
+        i32 = lambda: torch.empty((n_series, self.stride), dtype=torch.int32, device=self.dev)[:, :T]
         self.out = {name: [f64() if dt == "f8" else i32() for _, dt in outs] for name, (_c, _p, outs, _f) in SPEC.items()}
         self.pat = {nm: i32() for nm in PATTERN_NAMES}
         self.bt = [f64(), f64(), f64()]
         self.summary = torch.empty((n_series, 8), dtype=torch.float64, device=self.dev)
-        self.periods = torch.from_numpy(np.tile((2 + np.arange(T) % 29).astype(np.float64), (n_series, 1))).to(self.dev)
+        self.periods = f64()
+        self.periods.copy_(torch.from_numpy(np.tile((2 + np.arange(T) % 29).astype(np.float64), (n_series, 1))))
         self._pens = (C.c_double * 61)(*[PATTERN_PEN_DEFAULT[nm] for nm in PATTERN_NAMES])
         self._pat_ptrs = (C.c_void_p * 61)(*[self.pat[nm].data_ptr() for nm in PATTERN_NAMES])
         self._prm = BtParams(**BT_DEFAULTS)
