@@ -45,6 +45,13 @@ pq_status pq_backtest_macd_cross(pq_ctx *ctx, const pq_batch *b, const double *c
     BtArgs a{};
     a.price = close; a.position = position; a.cash = cash; a.summary = summary; a.prm = *params;
     a.fast = fast; a.slow = slow; a.sig = sig;
+    if (position && cash && equity) { // all three state columns: the tiled SEQ op (coalesced column traffic)
+        BtMacdOp op{};
+        op.prm = *params; op.fast = fast; op.slow = slow; op.sig = sig; op.summary = summary;
+        InCols<1> in{{close}};
+        OutCols<3> out{{position, cash, equity}};
+        return launch_seq(ctx, b, op, in, out);
+    }
     if (equity) a.equity = equity;
     else {
         PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));

@@ -148,6 +148,103 @@ __device__ __forceinline__ void backtest_body(const BtArgs &a, const Dims &d, in
 }
 
 
+// The MACD-cross backtest as a tiled SEQ op (price in; position, cash, equity out): same arithmetic as backtest_body<true,
+// false> with all three state columns requested and no benchmark, but the columns move through the coalesced tile path
+// instead of per-lane 8-byte accesses.  finish() is the summary: pass 2 re-reads the lane's own equity row.
+struct BtMacdOp {
+    static constexpr int NIN = 1, NOUT = 3;
+    static constexpr int SEQ_ID = 62;
+    pq_bt_params prm;
+    int64_t fast, slow, sig;
+    double *summary; // [n][8], nullable
+    EmaCore ef, es, eg;
+    double prev_m, prev_s, pos, avail, peak, entry_cost, max_dd, max_eq, prev_eq, ret_sum, last_eq;
+    int64_t trades, wins;
+    __device__ void init(const Row<1> &r) {
+        ef.init(fast, r.len); es.init(slow, r.len); eg.init(sig, r.len);
+        prev_m = pq_null(); prev_s = pq_null();
+        pos = 0.0; avail = prm.initial_capital; peak = prm.initial_capital; entry_cost = 0.0;
+        trades = 0; wins = 0;
+        max_dd = 0.0; max_eq = prm.initial_capital; prev_eq = prm.initial_capital; ret_sum = 0.0; last_eq = prm.initial_capital;
+    }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[3]) {
+        double px = x[0];
+        double f = ef.step(px), sl = es.step(px); // momentum.rs:250-283 + D-8 cross rule
+        double m = (!pq_isnull(f) && !pq_isnull(sl)) ? f - sl : pq_null();
+        double g = eg.step(z0b(m));
+        bool ok = i > 0 && !pq_isnull(m) && !pq_isnull(g) && !pq_isnull(prev_m) && !pq_isnull(prev_s);
+        bool buy = ok && (prev_m <= prev_s) && (m > g);
+        bool sell = ok && (prev_m >= prev_s) && (m < g);
+        prev_m = m; prev_s = g;
+        double eq;
+        if (pq_isnull(px)) px = __longlong_as_double(0x7FF8000000000000LL); // null -> NaN (vectorized.rs:70-78)
+        if (isnan(px) || px <= 0.0) { // vectorized.rs:141-144: state untouched
+            eq = avail + pos * px;
+        } else {
+            if (buy && pos == 0.0) { // :146-161
+                double exec = px + prm.buy_slippage;
+                double cur_eq = avail + pos * px;
+                double deploy = cur_eq * prm.position_size;
+                double qty = floor(deploy / exec);
+                if (qty > 0.0) {
+                    double cost = qty * exec;
+                    double fee = fmax(cost * prm.buy_commission_rate, prm.min_commission);
+                    pos += qty;
+                    avail -= cost + fee;
+                    entry_cost = pos * px;
+                    trades += 1;
+                }
+            } else if (sell && pos > 0.0) { // :162-175
+                double exec = px - prm.sell_slippage;
+                double revenue = pos * exec;
+                double fee = fmax(revenue * prm.sell_commission_rate, prm.min_commission);
+                double net = revenue - fee;
+                if (net > entry_cost) wins += 1;
+                avail += net;
+                pos = 0.0;
+            }
+            eq = avail + pos * px;
+            if (eq > peak) peak = eq;
+        }
+        y[0] = pos; y[1] = avail; y[2] = eq;
+        if (eq > max_eq) max_eq = eq; // metrics.rs:26-49
+        double dd = (max_eq > 0.0) ? (max_eq - eq) / max_eq : 0.0;
+        if (dd > max_dd) max_dd = dd;
+        double r = (prev_eq > 0.0) ? (eq - prev_eq) / prev_eq : 0.0;
+        ret_sum += r;
+        prev_eq = eq;
+        last_eq = eq;
+    }
+    __host__ __device__ void *finish_writes() const { return summary; } // what finish() writes besides the op's columns
+    // called once per live lane after every row of the series has been stored
+    __device__ void finish(double *const *outp, const Dims &d, int64_t s) {
+        if (summary == nullptr) return;
+        const int64_t T = d.len;
+        double *sm = summary + s * PQ_SUMMARY_COLS;
+        if (T == 0) { for (int k = 0; k < 8; k++) sm[k] = 0.0; return; }
+        const double DAYS = 252.0, RF = 0.03;
+        double total_return = (last_eq - prm.initial_capital) / prm.initial_capital;
+        double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
+        double mean = ret_sum / (double)T;
+        double dof = fmax((double)T - 1.0, 1.0);
+        const double *eqr = outp[2] + s * d.stride;
+        double vs = 0.0, pe = prm.initial_capital;
+        for (int64_t i = 0; i < T; i++) {
+            double e = eqr[i];
+            double r = (pe > 0.0) ? (e - pe) / pe : 0.0;
+            double dlt = r - mean;
+            vs += dlt * dlt;
+            pe = e;
+        }
+        double var = vs / dof;
+        double vol = sqrt(var) * sqrt(DAYS);
+        double sharpe = (vol > 0.0) ? (ann - RF) / vol : 0.0;
+        double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
+        sm[0] = ann; sm[1] = max_dd; sm[2] = 0.0; sm[3] = 0.0; sm[4] = sharpe;
+        sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
+    }
+};
+
 template <bool MACD_SIGNALS, bool SIGNALS_ONLY>
 __global__ __launch_bounds__(SEQ_BLOCK) void backtest_kernel(BtArgs a, Dims d) {
     const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;

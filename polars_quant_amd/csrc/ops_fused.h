@@ -249,6 +249,65 @@ struct HtAllOp {
     }
 };
 
+// MAVP with the SMA core (matype 0 / 7 / other): a job advances SIXTEEN candidate periods [lo, hi] in one walk.  Every
+// candidate's running sum lives in registers and is the exact add-new / subtract-old sequence of overlap.rs:897-910 (so the
+// rounding of every candidate is the reference's); all of them are fed from one shared input ring, and the job writes the
+// rows whose clamped period falls in its range (masked, like the block op below, which keeps its states in LDS and needs
+// twice the jobs).
+struct MavpSma16Op {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr bool MASKED = true;
+    static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0), periods
+    static constexpr int SEQ_ID = 83;
+    int lo, hi, minp, maxp, n;
+    Ring w;
+    const double *tab; // 1/P for P = lo .. lo+15 (shared by the wave)
+    double s[16];
+    __host__ __device__ int64_t ring_slots() const { return (hi > 0 ? hi : 1) + 1; }
+    __device__ void init(const Row<2> &) {}
+    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
+        n = (int)(r.len < 0x7fffffff ? r.len : 0x7fffffff);
+        w = ra.make(hi);
+        double *t = ra.make_shared(16);
+        const int k = threadIdx.x & 63;
+        if (k < 16) t[k] = 1.0 / (double)(lo + k);
+        tab = t;
+#pragma unroll
+        for (int u = 0; u < 16; u++) s[u] = 0.0;
+        lds_fence();
+    }
+    __device__ void step(const Row<2> &, int64_t, const double (&)[2], double (&y)[1]) { y[0] = pq_skip(); }
+    __device__ void step_lds(int64_t t64, const double (&x)[2], double (&y)[1]) {
+        const double v = n0(x[0]);
+        const int t = (int)t64;
+        const double pd = n0(x[1]);
+        const int64_t p64 = (int64_t)pd;
+        const int pi = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
+        const int c = t + 1; // every row is valid after nulls -> 0.0
+        double asel = 0.0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            double old[8];
+            w.get8<1>(lo + 8 * g, old); // x[t - P] for the eight periods of this group
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int P = lo + 8 * g + u;
+                double a = s[8 * g + u] + v;
+                const double b = a - old[u];
+                a = (c > P) ? b : a; // wave-uniform condition
+                a = (P <= hi && P > 0 && n >= P) ? a : 0.0;
+                s[8 * g + u] = a;
+                asel = (P == pi) ? a : asel;
+            }
+        }
+        w.push(v);
+        const bool mine = pi >= lo && pi <= hi;
+        const bool ok = pi > 0 && n >= pi && c >= pi && t >= maxp - 1;
+        const double res = asel * tab[mine ? pi - lo : 0];
+        y[0] = mine ? (ok ? res : pq_null()) : pq_skip();
+    }
+};
+
 // MAVP for the single-core MA types (SMA: matype 0/7/other, EMA: matype 1): a job advances up to EIGHT candidate
 // periods [lo, hi] together from one shared input ring (their running states live in an LDS array [period][lane]) and
 // writes the rows whose clamped period falls in its range.  Same arithmetic per period as MavpSelOp<SmaOp/EmaOp>; the

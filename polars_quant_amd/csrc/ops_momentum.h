@@ -347,15 +347,19 @@ struct MfiOp { // momentum.rs:286-342
         double tp = (x[0] + x[1] + x[2]) / 3.0;
         double mf = tp * x[3];
         if (i >= 1) {
-            if (tp > prev_tp) pos += mf;
-            else if (tp < prev_tp) neg += mf;
+            // selects, not branches: a conditional update of one of two accumulators makes the compiler index them
+            // in scratch memory (two scratch round trips per row)
+            const double padd = pos + mf, nadd = neg + mf;
+            pos = (tp > prev_tp) ? padd : pos;
+            neg = (tp < prev_tp) ? nadd : neg;
             if (p >= 0 && i >= p) {
                 int64_t q = i - p;
                 if (q > 0) {
                     double tq = tp, tq1 = prev_tp, mq = mf; // p == 0: the row just added is removed again
                     if (p > 0) { tq = wtp.get((int)p); tq1 = wtp.get((int)p + 1); mq = wmf.get((int)p); }
-                    if (tq > tq1) pos -= mq;
-                    else if (tq < tq1) neg -= mq;
+                    const double psub = pos - mq, nsub = neg - mq;
+                    pos = (tq > tq1) ? psub : pos;
+                    neg = (tq < tq1) ? nsub : neg;
                 }
                 if (neg == 0.0) y[0] = 100.0;
                 else { double mr = pos / neg; y[0] = 100.0 - (100.0 / (1.0 + mr)); }

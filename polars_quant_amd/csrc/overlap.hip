@@ -124,13 +124,18 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     pq_status st = PQ_OK;
     bool blocked = false;
     if (matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8 && maxp < (1 << 30)) {
-        // SMA / EMA: eight candidate periods per job
+        // SMA: sixteen candidate periods per job (states in registers); EMA: eight (states in LDS)
         blocked = true;
         st = PQ_OK;
-        for (int64_t lo = minp; lo <= maxp && st == PQ_OK; lo += 8) {
-            int64_t hi = lo + 7 < maxp ? lo + 7 : maxp;
+        const int64_t per_job = matype == 1 ? 8 : 16;
+        for (int64_t lo = minp; lo <= maxp && st == PQ_OK; lo += per_job) {
+            int64_t hi = lo + per_job - 1 < maxp ? lo + per_job - 1 : maxp;
             InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
-            if (matype == 1) {
+            if (matype != 1) {
+                MavpSma16Op op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
+                if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
+                st = launch_seq(ctx, b, op, in, o1);
+            } else if (matype == 1) {
                 MavpBlockOp<1> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
                 if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
                 st = launch_seq(ctx, b, op, in, o1);

@@ -74,6 +74,11 @@ struct Dims {
 };
 static inline Dims dims_of(const pq_batch *b) { return Dims{b->n_series, b->len, b->stride}; }
 
+template <class Op, class = void>
+struct HasFinish { static constexpr bool value = false; }; // void finish(double *const *outp, const Dims &, int64_t s): per-series epilogue
+template <class Op>
+struct HasFinish<Op, decltype((void)&Op::finish)> { static constexpr bool value = true; };
+
 template <int N>
 struct InCols {
     const double *p[N > 0 ? N : 1];
@@ -203,6 +208,7 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
         for (int k = 0; k < NOUT; k++)
             if (!MASKED || !pq_isskip(y[k])) o[k][t0] = y[k];
     }
+    if constexpr (HasFinish<Op>::value) op.finish(outp, d, s); // the lane re-reads only what it stored itself
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,6 +324,24 @@ constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to th
 // Hand-off per tile: wave 0 finishes the out tile in LDS -> barrier A -> wave 1 pulls it into registers -> barrier B ->
 // wave 1 issues the global stores while wave 0 already overwrites LDS with the next input tile.
 constexpr int SEQ_LDS_BLOCK = 128;
+#ifdef PQ_PROFILE_WAVES // experiment: where does the compute wave spend its cycles? [job][load wait+LDS fill, rows, hand-off, tiles]
+static __device__ unsigned long long pq_prof[128][4]; // indexed by Op::SEQ_ID
+template <class Op, class = void> struct ProfId { static constexpr int value = 0; };
+template <class Op> struct ProfId<Op, decltype((void)Op::SEQ_ID)> { static constexpr int value = Op::SEQ_ID & 127; };
+#define PQ_PROF_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define PQ_PROF_ADD(k, dt) do { if (lane == 0) atomicAdd(&pq_prof[ProfId<Op>::value][k], (unsigned long long)(dt)); } while (0)
+#else
+#define PQ_PROF_T(v)
+#define PQ_PROF_ADD(k, dt)
+#endif
+// Output columns are written once and not read again by the same step: a non-temporal store streams them past L2 / MALL
+// instead of allocating there, which keeps the (shared, re-read) input columns cached.  Tile-copy microbenchmark
+// (scripts/ubench/tilecopy2): 2.9 -> 4.3 TB/s of stores.
+typedef double pq_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
+    pq_d2v w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<pq_d2v *>(p));
+}
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
                                             int64_t tile_s0, unsigned char *lds, double *ring_ws = nullptr) {
@@ -341,6 +365,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
     for (int i = 0; i < NI; i++) co_row[i] = lds + (i * SPI + csym) * ROWB + cchunk * 16;
 
+#ifdef PQ_PROFILE_WAVES
+    if (lane == 0) atomicAdd(&pq_prof[120 + (__builtin_amdgcn_s_getreg(2308) & 3)][wave], 1ULL); // SIMD id histogram per wave role
+#endif
     if (wave == 1) { // ---------------------------------------------------------------- storer
         if constexpr (!MASKED) {
             for (int64_t it = 0; it < nt; it++) {
@@ -361,7 +388,12 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 for (int k = 0; k < NOUT; k++)
 #pragma unroll
                     for (int i = 0; i < NI; i++)
-                        if (tile_s0 + i * SPI + csym < d.n) *reinterpret_cast<double2 *>(outp[k] + crow[i] + t0) = v[k][i];
+                        if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0, v[k][i]);
+            }
+            if constexpr (HasFinish<Op>::value) { // the epilogue of wave 0 reads what this wave stored
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store acknowledged
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier(); // C
             }
         }
         return;
@@ -392,6 +424,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     };
     auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
+        PQ_PROF_T(c0);
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
@@ -402,6 +435,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
             }
         if (it + PF < nt) prefetch(buf, t0 + PF * K);
         lds_fence();
+        PQ_PROF_T(c1);
         // one row at a time, NOT unrolled: every job of a suite grid runs different code, and K copies of each
         // op body would thrash the instruction cache; the next row's inputs are read from LDS ahead of the step
         double xn[NIN];
@@ -432,10 +466,13 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
             }
         }
         lds_fence();
+        PQ_PROF_T(c2);
         if constexpr (!MASKED) {
             __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
             __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
         }
+        PQ_PROF_T(c3);
+        PQ_PROF_ADD(0, c1 - c0); PQ_PROF_ADD(1, c2 - c1); PQ_PROF_ADD(2, c3 - c2); PQ_PROF_ADD(3, 1);
     };
 #pragma unroll
     for (int f = 0; f < PF; f++)
@@ -456,6 +493,12 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
             for (int k = 0; k < NOUT; k++)
                 if (!MASKED || !pq_isskip(y[k])) outp[k][s * d.stride + t] = y[k];
         }
+    }
+    if constexpr (HasFinish<Op>::value) {
+        static_assert(!MASKED, "finish() is not supported for row-masked ops");
+        __builtin_amdgcn_s_barrier(); // C: wave 1's stores have been acknowledged
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (live) op.finish(outp, d, s);
     }
 }
 
@@ -483,7 +526,7 @@ __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK) void seq_kernel(Op
 // ---- recording hooks (implemented in suite.hip)
 // a recordable SEQ op carries `static constexpr int SEQ_ID` = its switch case in the job grid (suite.hip)
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes);
+                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write = nullptr);
 struct RowThunk { // type-erased ROW launch for replay
     void (*launch)(const void *blob, hipStream_t stream);
     unsigned char blob[1200];
@@ -531,8 +574,10 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     if (ctx->rec) {
         if constexpr (HasSeqId<Op>::value) {
             static_assert(sizeof(Op) <= 1024, "SEQ op too large for a job slot");
+            void *extra = nullptr;
+            if constexpr (HasFinish<Op>::value) extra = op.finish_writes();
             return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0,
-                               SeqTile<Op>::BYTES);
+                               SeqTile<Op>::BYTES, extra);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");
             return PQ_ERR_UNSUPPORTED;

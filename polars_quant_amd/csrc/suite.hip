@@ -34,26 +34,38 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
     std::vector<hipEvent_t> ev; // start/stop pairs, one pair per timed run
     int runs = 0;
 };
-// Jobs are grouped by LDS need: every workgroup of a launch gets the launch's (largest) dynamic LDS size, so one grid
-// for everything would pin all jobs to the occupancy of the hungriest one.  Three grids per phase, run concurrently.
-constexpr int NLDS = 3;         // LDS classes
-constexpr int NCLS = 2 * NLDS + 1; // x kernel variant (light / heavy registers) + the gather-body class
-constexpr unsigned CLS_LIMIT[NLDS] = {14 * 1024, 28 * 1024, 64 * 1024}; // ~11 / 5 / 2+ workgroups per CU by LDS
+// How the SEQ jobs of a phase are grouped into grids.  Facts that shape this (measured, scripts/wg_residency.py):
+//  * every workgroup walks its 64 series for the whole step (0.4 .. 4 ms), so the step ends when the last-started long
+//    workgroup ends: long jobs must be placed first and the tail should consist of short jobs;
+//  * a launch has ONE dynamic-LDS size, and a 40 KB workgroup loses every race for freed LDS against 10 KB ones;
+//  * HIP multiplexes streams onto 4 hardware queues; a fifth concurrent stream is serialized behind another one.
+// Hence four concurrent chains:  A = light-register jobs needing > 28 KB (caller's stream), B = 14..28 KB (longest job
+// first inside the grid), H = register-heavy Hilbert jobs followed by the small short jobs E (<= 14 KB, which thereby start
+// once LDS begins to free up), and one chain with the ROW launches and the gather-body fallbacks (G).
+enum { CLS_A = 0, CLS_B = 1, CLS_H = 2, CLS_G = 3, CLS_E = 4, NCLS = 5 };
 static bool kind_is_heavy(int kind);
-static int lds_class(unsigned lds) { return lds <= CLS_LIMIT[0] ? 0 : (lds <= CLS_LIMIT[1] ? 1 : 2); }
-static int job_class(int kind, unsigned lds) { return lds == 0 ? 2 * NLDS : lds_class(lds) + (kind_is_heavy(kind) ? NLDS : 0); }
+static int job_cost(int kind);
+static int job_class(int kind, unsigned lds) {
+    if (kind_is_heavy(kind) && (lds > 0 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1)) return CLS_H;
+    if (lds == 0) return CLS_G;
+    if (getenv("PQ_SPLIT_E")) return lds > 28 * 1024 ? CLS_A : ((lds > 14 * 1024 || job_cost(kind) >= 140) ? CLS_B : CLS_E);
+    return lds > 28 * 1024 ? CLS_A : CLS_B; // the short small jobs sort to the end of B's grid and run in the tail of the step
+}
 struct Phase {
     GridStat gs[NCLS];
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
     SeqJob *d_seq = nullptr;
+    unsigned long long *d_dbg = nullptr; // PQ_SUITE_DEBUG: [job][first start, last end] device timestamps
+    unsigned long long *d_wg = nullptr;  // PQ_SUITE_DEBUG=2: [job][tile][start, end, hw id] of every workgroup
+    unsigned wg_tiles = 0;
     int first[NCLS + 1] = {}; // job index range of each class
     unsigned lds[NCLS] = {};
 };
 struct Recorder {
     pq_batch b;
-    hipStream_t aux[NCLS] = {}; // classes 1.. of the SEQ grids + the ROW launches run beside class 0
-    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {};
+    hipStream_t aux[3] = {};   // B, H, ROW+G+E chains (A runs on the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
     std::vector<Phase> phases;
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
@@ -65,29 +77,37 @@ struct pq_suite {
     Recorder rec;
 };
 
-// every recordable SEQ op: X(Type).  Two kernel variants: the register-hungry ops (Hilbert pipeline, AD/ADOSC) would pin
-// the whole grid to 2 waves/SIMD, so they get their own kernel and everything else is compiled for 4 waves/SIMD.
+// every recordable SEQ op: X(Type).  Kernel variants: the register-hungry Hilbert ops would pin the whole grid to
+// 2 waves/SIMD, so they (and the backtest scan) get their own kernel; everything else is compiled for 3 waves/SIMD
+// (168 VGPRs), which matches the 5-6 two-wave workgroups per CU that LDS admits anyway.
 #define SEQ_OPS_LIGHT(X)                                                                                             \
     X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
     X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
     X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
-    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochRsiOp) X(CciOp)                                 \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<0>) X(MavpBlockOp<1>)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp)
+    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<0>) X(MavpBlockOp<1>) X(MavpSma16Op)                                          \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(HtOp<4>) X(BtMacdOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
-    X(StochOp<0>) X(StochOp<1>) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp)
-static bool kind_is_heavy(int kind) { return kind == 42 || kind == 43 || (kind >= 45 && kind <= 49) || kind == 74 || kind == 75 || kind == 79; }
+    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp)
+static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
 
 // V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
 template <int V>
-__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 4 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d) {
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];
     const SeqJob &job = jobs[blockIdx.y];
+    if (dbg && threadIdx.x == 0) atomicMin(&dbg[2 * blockIdx.y], wall_clock64()); // PQ_SUITE_DEBUG: first start / last end per job
+    if (wg && threadIdx.x == 0) {
+        unsigned long long *q = wg + 3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        q[0] = wall_clock64();
+        q[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); // XCC_ID, HW_ID
+    }
     const int64_t s0 = (int64_t)blockIdx.x * SEQ_BLOCK;
     const int64_t s = s0 + threadIdx.x;
+    if (s0 >= d.n) return; // grid.x is padded to a multiple of 8 (see pq_suite_run)
 #define X(OP)                                                                                                        \
     case OP::SEQ_ID: {                                                                                               \
         OP op;                                                                                                       \
@@ -101,21 +121,21 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 4 : 2)
         switch (job.kind) {   // wave-uniform
             SEQ_OPS_LIGHT(X)
             SEQ_OPS_HEAVY(X)
-        case SEQ_ID_BACKTEST: {
-            BtArgs a;
-            __builtin_memcpy(&a, job.op, sizeof(BtArgs));
-            backtest_body<false, false>(a, d, s);
-        } break;
-        case SEQ_ID_BACKTEST + 1: {
-            BtArgs a;
-            __builtin_memcpy(&a, job.op, sizeof(BtArgs));
-            backtest_body<true, false>(a, d, s);
-        } break;
         default: break;
         }
     } else if constexpr (V == 1) {
         switch (job.kind) {
             SEQ_OPS_HEAVY(X)
+        case SEQ_ID_BACKTEST: { // one series per lane of wave 0, no tiles
+            BtArgs a;
+            __builtin_memcpy(&a, job.op, sizeof(BtArgs));
+            if (threadIdx.x < SEQ_BLOCK && s < d.n) backtest_body<false, false>(a, d, s);
+        } break;
+        case SEQ_ID_BACKTEST + 1: {
+            BtArgs a;
+            __builtin_memcpy(&a, job.op, sizeof(BtArgs));
+            if (threadIdx.x < SEQ_BLOCK && s < d.n) backtest_body<true, false>(a, d, s);
+        } break;
         default: break;
         }
     } else {
@@ -125,19 +145,41 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 4 : 2)
         }
     }
 #undef X
+    if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
+    if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
-// rough relative cost per row, used to start the longest jobs first
+// solo replay time of the job at the suite's default parameters, in 0.01 ms per 2520 rows (measured, scripts/exp_solo.py):
+// orders jobs inside a grid (longest first) and splits long from short jobs
 static int job_cost(int kind) {
-    if ((kind >= 45 && kind <= 49) || kind == 79) return 30; // Hilbert pipeline
-    if (kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1) return 25;
-    if (kind == 24 || kind == 25) return 20;      // ultosc, mfi: lagged recomputation
-    if (kind == 9 || kind == 10) return 20;       // rolling extrema
-    if ((kind >= 26 && kind <= 28) || kind == 78 || kind == 80) return 15; // DM family
-    if (kind >= 74 && kind <= 77) return 14;      // stochastics, cci
-    if (kind == 81 || kind == 82) return 16;      // eight MAVP periods per walk
-    if (kind == 6 || kind == 8) return 12;
-    return 8;
+    switch (kind) {
+    case 79: return 300;                       // ht_all
+    case 45: case 46: case 47: case 48: return 250; // single Hilbert outputs
+    case 49: return 200;                       // mama
+    case 25: return 270;                       // mfi
+    case 81: case 82: return 260;              // eight MAVP periods per walk
+    case 83: return 270;                       // sixteen MAVP periods per walk
+    case 76: return 260;                       // stochrsi
+    case SEQ_ID_BACKTEST: case SEQ_ID_BACKTEST + 1: case 62: return 250;
+    case 74: case 78: case 80: case 77: return 235; // stoch, dm family, cci
+    case 26: case 27: case 28: return 200;
+    case 75: return 200;                       // stochf
+    case 24: return 180;                       // ultosc
+    case 10: return 150;                       // midprice
+    case 73: return 146;                       // macdext
+    case 43: case 11: case 8: return 110;      // adosc, sar/sarext, kama
+    case 21: case 23: return 102;              // rsi, trix
+    case 71: case 72: case 22: case 6: return 97; // apo/ppo, macd, t3
+    case 3: return 85;
+    case 20: return 80;
+    case 41: case 9: return 73;
+    case 42: case 70: case 5: return 67;
+    case 40: case 29: case 30: return 60;
+    case 7: case 4: return 52;
+    case 1: case 44: return 46;
+    case 2: return 39;
+    default: return 60;
+    }
 }
 
 static int phase_for(Recorder &r, const void *const *reads, int nr, void *const *writes, int nw) {
@@ -175,7 +217,7 @@ static pq_status same_batch(Recorder &r, const pq_batch *b) {
 }
 
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes) {
+                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
     if (nin > 6 || nout > 8) { pq_set_error("internal: SEQ job has too many columns"); return PQ_ERR_UNSUPPORTED; }
@@ -185,7 +227,10 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, 
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
     memcpy(j.op, op, op_bytes);
-    int ph = phase_for(r, (const void *const *)in, nin, (void *const *)out, nout);
+    void *writes[9];
+    for (int k = 0; k < nout; k++) writes[k] = out[k];
+    writes[nout] = extra_write; // e.g. the backtest's summary table: hazard tracking only
+    int ph = phase_for(r, (const void *const *)in, nin, writes, nout + 1);
     r.phases[ph].seq.push_back(j);
     return PQ_OK;
 }
@@ -250,8 +295,9 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             GridStat &st = p.gs[g];
             st.n_jobs++;
             if (j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1) { st.alg_bytes += 32.0 * rows + 64.0 * r.b.n_series; continue; }
+            if (j.kind == 62) st.alg_bytes += 64.0 * r.b.n_series; // + the summary row
             st.alg_bytes += 8.0 * rows * j.nin;
-            const bool masked = (j.kind == 12) || (j.kind >= 100) || j.kind == 81 || j.kind == 82;
+            const bool masked = (j.kind == 12) || (j.kind >= 100) || j.kind == 81 || j.kind == 82 || j.kind == 83;
             for (int k = 0; k < j.nout; k++) {
                 if (masked) { if (masked_seen[g][j.out[k]]++) continue; }
                 st.alg_bytes += 8.0 * rows;
@@ -262,6 +308,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost);
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (getenv("PQ_SUITE_DEBUG")) PQ_HIP_TRY(hipMalloc((void **)&p.d_dbg, 16 * p.seq.size()));
     }
     PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); // the host vectors are pageable
     return PQ_OK;
@@ -271,16 +318,16 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     if (!r.aux[0]) { // lazily create the side streams (they live as long as the suite)
         int prio_lo = 0, prio_hi = 0;
         PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)); // numerically lower = higher priority
-        for (int i = 0; i < NCLS; i++) {
-            // the LDS-hungry grids get dispatch priority: their workgroups need a large contiguous LDS block and lose every
-            // race for freed LDS against the small allocations of the other grids otherwise
-            int prio = (i < NCLS - 1 && (i % NLDS) != NLDS - 1 && !getenv("PQ_NO_PRIO")) ? prio_hi : prio_lo;
-            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, prio));
+        for (int i = 0; i < 3; i++) {
+            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, (i < 2 && !getenv("PQ_NO_PRIO")) ? prio_hi : prio_lo));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
         PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
     }
-    const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
+    // workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8, series tile x runs on XCD x % 8 for
+    // EVERY job, so jobs that read the same input column share that XCD's L2 for it
+    const unsigned tiles = getenv("PQ_NO_XCD_PAD") ? (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK)
+                                                   : (unsigned)((r.b.n_series + SEQ_BLOCK * 8 - 1) / (SEQ_BLOCK * 8)) * 8;
     for (Phase &p : r.phases) {
         // the launches of one phase are independent of each other: SEQ grid class 0 runs on the caller's stream, classes
         // 1.. on side streams aux[0..], the ROW launches on the last side stream
@@ -297,48 +344,98 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             if (!begin) g.runs++;
             return er;
         };
-        static const bool serial = getenv("PQ_SERIAL_CLASSES") != nullptr; // experiment: classes back to back on one stream
-        bool side[NCLS] = {};
-        for (int c = 1; c < NCLS; c++) side[c - 1] = !serial && p.first[c + 1] > p.first[c];
-        side[NCLS - 1] = !p.rows.empty();
-        bool any_side = false;
-        for (int i = 0; i < NCLS; i++) any_side |= side[i];
+        auto njobs = [&](int c) { return p.first[c + 1] - p.first[c]; };
+        // chain -> stream: 0 = caller's stream (A), 1 = B, 2 = H, 3 = ROW launches, G, E
+        const bool side[3] = {njobs(CLS_B) > 0, njobs(CLS_H) > 0 || njobs(CLS_E) > 0, !p.rows.empty() || njobs(CLS_G) > 0};
+        const bool any_side = side[0] || side[1] || side[2];
+        if (p.d_dbg && atoi(getenv("PQ_SUITE_DEBUG")) >= 2 && !p.d_wg) {
+            p.wg_tiles = tiles;
+            PQ_HIP_TRY(hipMalloc((void **)&p.d_wg, 24 * (size_t)tiles * p.seq.size()));
+        }
+        if (p.d_wg) PQ_HIP_TRY(hipMemset(p.d_wg, 0, 24 * (size_t)tiles * p.seq.size()));
+        if (p.d_dbg) { // min slots start at ~0, max slots at 0
+            std::vector<unsigned long long> init(2 * p.seq.size());
+            for (size_t i = 0; i < p.seq.size(); i++) { init[2 * i] = ~0ULL; init[2 * i + 1] = 0; }
+            PQ_HIP_TRY(hipMemcpy(p.d_dbg, init.data(), 16 * p.seq.size(), hipMemcpyHostToDevice));
+        }
         if (any_side) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
-        // hungriest class first: its workgroups need a large contiguous LDS block each and would otherwise starve behind
-        // the steady stream of small allocations until the other grids drain
-        for (int c = NCLS - 1; c >= 0; c--) {
-            const int nj = p.first[c + 1] - p.first[c];
-            if (nj <= 0) continue;
-            hipStream_t st = (c == 0 || serial) ? ctx->stream : r.aux[c - 1];
-            if (c > 0 && !serial) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
+        auto launch_class = [&](int c, hipStream_t st) -> pq_status {
+            const int nj = njobs(c);
+            if (nj <= 0) return PQ_OK;
             PQ_HIP_TRY(timed(p.gs[c], st, true));
-            if (c == 2 * NLDS) hipLaunchKernelGGL(seq_jobs_kernel<2>, dim3(tiles, (unsigned)nj), dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d);
-            else if (c >= NLDS) hipLaunchKernelGGL(seq_jobs_kernel<1>, dim3(tiles, (unsigned)nj), dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d);
-            else hipLaunchKernelGGL(seq_jobs_kernel<0>, dim3(tiles, (unsigned)nj), dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d);
+            unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
+            const dim3 grid(tiles, (unsigned)nj);
+            if (c == CLS_G) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
+            else if (c == CLS_H) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
+            else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             PQ_HIP_TRY(timed(p.gs[c], st, false));
-            if (c > 0 && !serial) PQ_HIP_TRY(hipEventRecord(r.ev_join[c - 1], st));
-        }
-        if (side[NCLS - 1]) {
-            hipStream_t st = r.aux[NCLS - 1];
+            return PQ_OK;
+        };
+        pq_status ps;
+        const int chain_cls[3][2] = {{CLS_B, -1}, {CLS_H, CLS_E}, {CLS_G, -1}};
+        const int chain_order[3] = {1, 0, 2}; // the Hilbert job is the longest of all: enqueue it first
+        for (int oi = 0; oi < 3; oi++) {
+            const int i = chain_order[oi];
+            if (i == 0 && (ps = launch_class(CLS_A, ctx->stream)) != PQ_OK) return ps; // A before B: hungriest first
+            if (!side[i]) continue;
+            hipStream_t st = r.aux[i];
             PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
-            for (const RowThunk &t : p.rows) t.launch(t.blob, st);
-            PQ_HIP_TRY(hipEventRecord(r.ev_join[NCLS - 1], st));
+            if (i == 2) for (const RowThunk &t : p.rows) t.launch(t.blob, st);
+            for (int k = 0; k < 2; k++)
+                if (chain_cls[i][k] >= 0 && (ps = launch_class(chain_cls[i][k], st)) != PQ_OK) return ps;
+            PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
         }
-        for (int i = 0; i < NCLS; i++)
+        for (int i = 0; i < 3; i++)
             if (side[i]) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[i], 0));
+        if (p.d_dbg) { // debug only: wait and print the per-job schedule (100 MHz device clock)
+            PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            std::vector<unsigned long long> t(2 * p.seq.size());
+            PQ_HIP_TRY(hipMemcpy(t.data(), p.d_dbg, 16 * p.seq.size(), hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ULL;
+            for (size_t i = 0; i < p.seq.size(); i++) t0 = t[2 * i] < t0 ? t[2 * i] : t0;
+            for (size_t i = 0; i < p.seq.size(); i++)
+                fprintf(stderr, "[pq suite] job %2zu kind=%3d class=%d lds=%6u  start %8.1f us  end %8.1f us\n", i, p.seq[i].kind,
+                        job_class(p.seq[i].kind, p.seq[i].lds_bytes), p.seq[i].lds_bytes, (double)(t[2 * i] - t0) / 100.0,
+                        (double)(t[2 * i + 1] - t0) / 100.0);
+            if (p.d_wg) {
+                std::vector<unsigned long long> w(3 * (size_t)tiles * p.seq.size());
+                PQ_HIP_TRY(hipMemcpy(w.data(), p.d_wg, 8 * w.size(), hipMemcpyDeviceToHost));
+                for (size_t j = 0; j < p.seq.size(); j++)
+                    for (unsigned x = 0; x < tiles; x++) {
+                        const unsigned long long *q = &w[3 * (j * tiles + x)];
+                        if (q[1]) fprintf(stderr, "[pq wg] %zu %u %.2f %.2f %llu %llu %u\n", j, x, (double)(q[0] - t0) / 100.0, (double)(q[1] - t0) / 100.0,
+                                          q[2] >> 32, q[2] & 0xffffffffULL, p.seq[j].lds_bytes);
+                    }
+            }
+#ifdef PQ_PROFILE_WAVES
+            {
+                static unsigned long long prof[128][4], zero[128][4];
+                PQ_HIP_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(pq_prof), sizeof(prof)));
+                for (int y = 120; y < 124; y++)
+                    fprintf(stderr, "[pq prof] SIMD %d: compute waves %llu, storer waves %llu\n", y - 120, prof[y][0], prof[y][1]);
+                for (int y = 0; y < 120; y++)
+                    if (prof[y][3])
+                        fprintf(stderr, "[pq prof] kind=%3d  fill+loadwait %8.0f  rows %8.0f  handoff %8.0f  cycles per tile, tiles=%llu\n", y,
+                                (double)prof[y][0] / prof[y][3], (double)prof[y][1] / prof[y][3], (double)prof[y][2] / prof[y][3], prof[y][3]);
+                PQ_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pq_prof), zero, sizeof(zero)));
+            }
+#endif
+        }
     }
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }
 static void suite_free(pq_ctx *ctx, Recorder &r) {
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < NCLS; i++) {
+    for (int i = 0; i < 3; i++) {
         if (r.aux[i]) { (void)hipStreamSynchronize(r.aux[i]); (void)hipStreamDestroy(r.aux[i]); r.aux[i] = nullptr; }
         if (r.ev_join[i]) { (void)hipEventDestroy(r.ev_join[i]); r.ev_join[i] = nullptr; }
     }
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     for (Phase &p : r.phases) {
         if (p.d_seq) (void)hipFree(p.d_seq);
+        if (p.d_dbg) (void)hipFree(p.d_dbg);
+        if (p.d_wg) (void)hipFree(p.d_wg);
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
     }
     for (void *s : r.scratch) (void)hipFree(s);

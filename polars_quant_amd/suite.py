@@ -74,9 +74,14 @@ class Suite:
             outs = [o["ht_dcperiod"][0], o["ht_dcphase"][0], o["ht_phasor"][0], o["ht_phasor"][1], o["ht_sine"][0], o["ht_sine"][1]]
             check(L.pq_ht_all(h, C.byref(b), C.c_void_p(ohlcv["close"].data_ptr()), *[C.c_void_p(t.data_ptr()) for t in outs]))
         else:
+            outs = self.out.get(name)
+            if "@" in name:           # experiments: "cci@3" = an independent replica of cci with its own output columns
+                name = name.split("@")[0]
+                if outs is None:
+                    outs = self.out.setdefault(name + "@" + str(len(self.out)), [torch.empty_like(t) for t in self.out[name]])
             cols = SPEC[name][0]
             check(getattr(L, "pq_" + name)(h, C.byref(b), *[C.c_void_p(self._col(ohlcv, c).data_ptr()) for c in cols],
-                                           *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in self.out[name]]))
+                                           *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in outs]))
 
     FUSED = {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"),
              "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine")}
