@@ -236,6 +236,9 @@ pq_status pq_suite_info(const pq_suite *suite, int32_t *n_phases, int32_t *n_seq
 pq_status pq_suite_set_timing(pq_suite *suite, int32_t on);
 pq_status pq_suite_grid_stats(pq_suite *suite, int32_t grid, double *avg_ms, double *algorithmic_bytes, int32_t *n_jobs,
                               int32_t *lds_bytes, int32_t *runs);
+/* which kernel a grid launches: 0 = seq_jobs_kernel<0> (tiled bodies), 1 = seq_jobs_kernel<1> (register-heavy ops),
+ * 2 = seq_jobs_kernel<2> (gather bodies) */
+pq_status pq_suite_grid_variant(pq_suite *suite, int32_t grid, int32_t *variant);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ __device__ __forceinline__ double n0m(double x) { return pq_isnull(x) ? 0.0 : x;
 // ---------------------------------------------------------------- price.rs (N-C, ROW)
 template <int KIND> // 0 avgprice(o,h,l,c) 1 medprice(h,l) 2 typprice(h,l,c) 3 wclprice(h,l,c)
 struct PriceOp {
+    static constexpr int ROW_ID = 1 + KIND;
     static constexpr int NIN = (KIND == 0 ? 4 : (KIND == 1 ? 2 : 3)), NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<NIN> &r, int64_t t, double (&y)[1]) {
@@ -16,9 +17,9 @@ struct PriceOp {
 #pragma unroll
         for (int k = 0; k < NIN; k++) { a[k] = r.in[k][t]; nul |= pq_isnull(a[k]); }
         if (nul) { y[0] = pq_null(); return; }
-        if (KIND == 0) y[0] = (a[0] + a[1] + a[2] + a[NIN - 1]) * 0.25;      // price.rs:25
-        else if (KIND == 1) y[0] = (a[0] + a[1]) * 0.5;                        // price.rs:44
-        else if (KIND == 2) y[0] = (a[0] + a[1] + a[NIN - 1]) / 3.0;          // price.rs:65
+        if constexpr (KIND == 0) y[0] = (a[0] + a[1] + a[2] + a[NIN - 1]) * 0.25; // price.rs:25
+        else if constexpr (KIND == 1) y[0] = (a[0] + a[1]) * 0.5;                        // price.rs:44
+        else if constexpr (KIND == 2) y[0] = (a[0] + a[1] + a[NIN - 1]) / 3.0; // price.rs:65
         else y[0] = (a[0] + a[1] + 2.0 * a[NIN - 1]) / 4.0;                   // price.rs:86
     }
 };
@@ -28,6 +29,7 @@ __device__ __forceinline__ double true_range(double h, double l, double pc) { //
     return fmax(fmax(h - l, fabs(h - pc)), fabs(l - pc));
 }
 struct TrangeOp { // volatility.rs:67-84 (ROW; row 0 null because pre_close = close.shift(1))
+    static constexpr int ROW_ID = 5;
     static constexpr int NIN = 3, NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {
@@ -193,6 +195,7 @@ struct HtOp {
 };
 // cycle.rs:310-374 / :377-448: pure functions of real[i-3..i] (the pipeline result is unused)
 struct TrendlineOp {
+    static constexpr int ROW_ID = 6;
     static constexpr int NIN = 1, NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<1> &r, int64_t i, double (&y)[1]) {
@@ -205,6 +208,7 @@ struct TrendlineOp {
     }
 };
 struct TrendmodeOp {
+    static constexpr int ROW_ID = 7;
     static constexpr int NIN = 1, NOUT = 1;
     typedef int32_t OutT;
     __device__ void eval(const Row<1> &r, int64_t i, int32_t (&y)[1]) {

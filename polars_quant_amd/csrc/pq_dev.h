@@ -414,7 +414,10 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     }
     unsigned char *my_row = lds + lane * ROWB;
     // wave 0 has no stores in flight (except for MASKED ops), so its prefetched loads can be waited for exactly
-    constexpr int PF = 1; // (a second tile of prefetch costs 16-32 VGPRs per input column and bought nothing measurable)
+#ifndef PQ_PF2_MAX
+#define PQ_PF2_MAX 0
+#endif
+    constexpr int PF = (NIN * NI * 4 <= PQ_PF2_MAX) ? 2 : 1; // a second tile of prefetch costs NIN*NI*4 VGPRs
     double2 pre[PF][NIN][NI];
     auto prefetch = [&](double2 (&buf)[NIN][NI], int64_t t0) {
 #pragma unroll
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK) void seq_kernel(Op
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
                       int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write = nullptr);
 struct RowThunk { // type-erased ROW launch for replay
+    int kind = -1; // Op::ROW_ID when the op can run inside the fused row_jobs_kernel of a suite (blob = RowBlob<Op>), else -1
     void (*launch)(const void *blob, hipStream_t stream);
     unsigned char blob[1200];
     const void *reads[8];
@@ -610,8 +614,13 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> i
     typename Op::OutT y[Op::NOUT];
     op.eval(r, t, y);
 #pragma unroll
-    for (int k = 0; k < Op::NOUT; k++) out.p[k][s * d.stride + t] = y[k];
+    for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][s * d.stride + t]); // written once, not re-read
 }
+constexpr int ROW_JOB_BLOB = 184; // bytes of a fused-row job slot
+template <class Op, class = void>
+struct HasRowId { static constexpr bool value = false; };
+template <class Op>
+struct HasRowId<Op, decltype((void)Op::ROW_ID)> { static constexpr bool value = true; };
 template <class Op>
 struct RowBlob {
     Op op;
@@ -619,6 +628,20 @@ struct RowBlob {
     OutColsT<Op, typename Op::OutT> out;
     pq_batch b;
 };
+// one (series, row) of a recorded ROW op, evaluated from its blob (fused row_jobs_kernel)
+template <class Op>
+__device__ __forceinline__ void row_eval_blob(const unsigned char *blob, const Dims &d, int64_t s, int64_t t) {
+    RowBlob<Op> rb;
+    __builtin_memcpy(&rb, blob, sizeof rb);
+    Row<Op::NIN> r;
+    r.len = d.len;
+#pragma unroll
+    for (int k = 0; k < Op::NIN; k++) r.in[k] = rb.in.p[k] + s * d.stride;
+    typename Op::OutT y[Op::NOUT];
+    rb.op.eval(r, t, y);
+#pragma unroll
+    for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &rb.out.p[k][s * d.stride + t]);
+}
 template <class Op>
 static void row_launch_blob(const void *blob, hipStream_t stream) {
     const RowBlob<Op> &rb = *reinterpret_cast<const RowBlob<Op> *>(blob);
@@ -643,6 +666,7 @@ static inline pq_status launch_row(pq_ctx *ctx, const pq_batch *b, const Op &op,
         static_assert(sizeof(RowBlob<Op>) <= sizeof(RowThunk::blob), "ROW blob too large");
         RowThunk t;
         t.launch = &row_launch_blob<Op>;
+        if constexpr (HasRowId<Op>::value) t.kind = (sizeof(RowBlob<Op>) <= ROW_JOB_BLOB) ? Op::ROW_ID : -1;
         memcpy(t.blob, &rb, sizeof rb);
         t.n_reads = Op::NIN;
         for (int k = 0; k < Op::NIN; k++) t.reads[k] = in.p[k];

@@ -34,38 +34,71 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
     std::vector<hipEvent_t> ev; // start/stop pairs, one pair per timed run
     int runs = 0;
 };
-// How the SEQ jobs of a phase are grouped into grids.  Facts that shape this (measured, scripts/wg_residency.py):
+// How the SEQ jobs of a phase are grouped into grids.  Facts that shape this (measured, scripts/wg_residency.py and
+// scripts/ubench/nstreams.hip):
 //  * every workgroup walks its 64 series for the whole step (0.4 .. 4 ms), so the step ends when the last-started long
 //    workgroup ends: long jobs must be placed first and the tail should consist of short jobs;
-//  * a launch has ONE dynamic-LDS size, and a 40 KB workgroup loses every race for freed LDS against 10 KB ones;
-//  * HIP multiplexes streams onto 4 hardware queues; a fifth concurrent stream is serialized behind another one.
-// Hence four concurrent chains:  A = light-register jobs needing > 28 KB (caller's stream), B = 14..28 KB (longest job
-// first inside the grid), H = register-heavy Hilbert jobs followed by the small short jobs E (<= 14 KB, which thereby start
-// once LDS begins to free up), and one chain with the ROW launches and the gather-body fallbacks (G).
-enum { CLS_A = 0, CLS_B = 1, CLS_H = 2, CLS_G = 3, CLS_E = 4, NCLS = 5 };
+//  * a launch has ONE dynamic-LDS size (every workgroup is charged the largest need in its grid), and a 40 KB workgroup
+//    loses every race for freed LDS against 10 KB ones;
+//  * HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): the caller's stream + 3 side streams run
+//    concurrently, any further stream is serialized behind another one; hipExtAnyOrderLaunch is a no-op on gfx9.
+// Plan "narrow" (4 queues):  light-register jobs > 28 KB on the caller's stream | the rest of the light jobs, longest first,
+// so the short small ones run in the tail | the register-heavy Hilbert jobs | ROW launches + gather-body fallbacks.
+// Plan "wide" (experiment, PQ_SUITE_PLAN=w with GPU_MAX_HW_QUEUES >= 8): five LDS size classes (160 KB / 3, 5, 6, 7, 11 per CU)
+// so that less LDS is charged than needed, the smallest (short jobs) held back by a timed gate.
+constexpr int NCLS = 8, NCHAIN = 7; // chain 0 = the caller's stream
+struct ClassDef { int variant; unsigned lds_lo, lds_hi; int chain, gate_us; }; // variant 0 light, 1 heavy, 2 gather; LDS in (lo, hi]
+struct Plan { int ncls, nchain, row_chain; ClassDef cls[NCLS]; int chain_order[NCHAIN]; };
+static const Plan PLAN_NARROW = {4, 4, 3,
+    {{0, 28 * 1024, 1u << 30, 0, 0}, {0, 0, 28 * 1024, 1, 0}, {1, 0, 1u << 30, 2, 0}, {2, 0, 0, 3, 0}},
+    {2, 0, 1, 3}};
+static const Plan PLAN_WIDE = {7, 7, 5,
+    {{0, 32 * 1024, 1u << 30, 0, 0}, {0, 27264, 32 * 1024, 1, 0}, {0, 23360, 27264, 2, 0}, {0, 14 * 1024, 23360, 3, 0},
+     {1, 0, 1u << 30, 4, 0}, {2, 0, 0, 5, 0}, {0, 0, 14 * 1024, 6, 1500}},
+    {4, 0, 1, 2, 3, 5, 6}};
+static const Plan &plan() {
+    static const Plan *p = [] {
+        // measured: the wide plan does not pay (7.2 vs 6.3 ms per step: more fork/join traffic, short jobs still start late),
+        // so it is opt-in for experiments and needs GPU_MAX_HW_QUEUES >= 8 in the environment of the process
+        const char *force = getenv("PQ_SUITE_PLAN");
+        return (force && force[0] == 'w') ? &PLAN_WIDE : &PLAN_NARROW;
+    }();
+    return *p;
+}
 static bool kind_is_heavy(int kind);
 static int job_cost(int kind);
 static int job_class(int kind, unsigned lds) {
-    if (kind_is_heavy(kind) && (lds > 0 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1)) return CLS_H;
-    if (lds == 0) return CLS_G;
-    if (getenv("PQ_SPLIT_E")) return lds > 28 * 1024 ? CLS_A : ((lds > 14 * 1024 || job_cost(kind) >= 140) ? CLS_B : CLS_E);
-    return lds > 28 * 1024 ? CLS_A : CLS_B; // the short small jobs sort to the end of B's grid and run in the tail of the step
+    const Plan &pl = plan();
+    const bool bt = kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1;
+    const int variant = (kind_is_heavy(kind) && (lds > 0 || bt)) ? 1 : (lds == 0 ? 2 : 0);
+    for (int c = 0; c < pl.ncls; c++)
+        if (pl.cls[c].variant == variant && (variant == 2 || (lds > pl.cls[c].lds_lo && lds <= pl.cls[c].lds_hi))) return c;
+    return pl.ncls - 1;
 }
+// Timed gate in front of a grid of short jobs (wall_clock64: 100 MHz).  Bounded: it only ever waits for time to pass.
+__global__ void gate_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+struct RowJob;
 struct Phase {
     GridStat gs[NCLS];
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
     SeqJob *d_seq = nullptr;
+    RowJob *d_rowjobs = nullptr; // the fusable ROW launches of the phase (the others stay in `rows`)
+    int n_rowjobs = 0;
     unsigned long long *d_dbg = nullptr; // PQ_SUITE_DEBUG: [job][first start, last end] device timestamps
     unsigned long long *d_wg = nullptr;  // PQ_SUITE_DEBUG=2: [job][tile][start, end, hw id] of every workgroup
     unsigned wg_tiles = 0;
+    bool gate = false;        // timed gates only when the jobs do not all fit on the chip at once
     int first[NCLS + 1] = {}; // job index range of each class
     unsigned lds[NCLS] = {};
 };
 struct Recorder {
     pq_batch b;
-    hipStream_t aux[3] = {};   // B, H, ROW+G+E chains (A runs on the caller's stream)
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
+    hipStream_t aux[NCHAIN] = {};   // chains 1.. (chain 0 is the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[NCHAIN] = {};
     std::vector<Phase> phases;
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
@@ -108,6 +141,10 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
     const int64_t s0 = (int64_t)blockIdx.x * SEQ_BLOCK;
     const int64_t s = s0 + threadIdx.x;
     if (s0 >= d.n) return; // grid.x is padded to a multiple of 8 (see pq_suite_run)
+    // long jobs are the critical path of the step: their waves win the issue arbitration against short jobs on the same SIMD
+    if (job.cost >= 200) __builtin_amdgcn_s_setprio(3);
+    else if (job.cost >= 140) __builtin_amdgcn_s_setprio(2);
+    else if (job.cost >= 100) __builtin_amdgcn_s_setprio(1);
 #define X(OP)                                                                                                        \
     case OP::SEQ_ID: {                                                                                               \
         OP op;                                                                                                       \
@@ -147,6 +184,28 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
 #undef X
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
+}
+
+// ---- fused ROW jobs: every recorded row-parallel op that has a ROW_ID runs inside ONE kernel, thread = (series, row).
+// The ops of a suite read the same few input columns (OHLC): evaluated back to back by the same thread block, only the
+// first one misses in L1/L2 -- 16 launches with 296 B/row of reads become one launch with ~40 B/row.
+struct RowJob { int kind; alignas(8) unsigned char blob[ROW_JOB_BLOB]; };
+#define ROW_OPS(X)                                                                                                   \
+    X(PriceOp<0>) X(PriceOp<1>) X(PriceOp<2>) X(PriceOp<3>) X(TrangeOp) X(TrendlineOp) X(TrendmodeOp) X(LagOp<0>) X(LagOp<1>) \
+    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(WillrOp)
+__global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJob *jobs, int njobs, Dims d, int64_t s0) {
+    const int64_t s = s0 + blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
+    if (t >= d.len) return;
+    for (int j = 0; j < njobs; j++) {
+        const RowJob &job = jobs[j];
+        switch (job.kind) { // uniform
+#define X(OP) case OP::ROW_ID: row_eval_blob<OP>(job.blob, d, s, t); break;
+            ROW_OPS(X)
+#undef X
+        default: break;
+        }
+    }
 }
 
 // solo replay time of the job at the suite's default parameters, in 0.01 ms per 2520 rows (measured, scripts/exp_solo.py):
@@ -263,6 +322,23 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
     const char *gr = getenv("PQ_GLOBAL_RINGS");
     const unsigned gr_min = gr ? (unsigned)atoi(gr) : 0; // experiment: jobs needing more LDS than this keep their rings in global memory
     for (Phase &p : r.phases) {
+        if (getenv("PQ_ROW_FUSION")) { // experiment (no gain measured: the separate launches already run at cache speed)
+            std::vector<RowJob> rj;
+            std::vector<RowThunk> rest;
+            for (const RowThunk &t : p.rows) {
+                if (t.kind < 0) { rest.push_back(t); continue; }
+                RowJob j;
+                j.kind = t.kind;
+                memcpy(j.blob, t.blob, ROW_JOB_BLOB);
+                rj.push_back(j);
+            }
+            if (rj.size() >= 2) {
+                p.rows.swap(rest);
+                p.n_rowjobs = (int)rj.size();
+                PQ_HIP_TRY(hipMalloc((void **)&p.d_rowjobs, sizeof(RowJob) * rj.size()));
+                PQ_HIP_TRY(hipMemcpy(p.d_rowjobs, rj.data(), sizeof(RowJob) * rj.size(), hipMemcpyHostToDevice));
+            }
+        }
         if (p.seq.empty()) continue;
         if (gr_min) {
             const size_t tiles = (size_t)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
@@ -304,6 +380,14 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         for (int c = 0; c < NCLS; c++) { p.first[c + 1] += p.first[c]; p.gs[c].lds = p.lds[c]; }
+        {
+            hipDeviceProp_t prop;
+            PQ_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+            double need = 0;
+            for (const SeqJob &j : p.seq) need += (double)j.lds_bytes;
+            need *= (double)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
+            p.gate = need > 0.6 * (double)prop.multiProcessorCount * 160.0 * 1024.0;
+        }
         if (getenv("PQ_SUITE_DEBUG"))
             for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost);
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
@@ -315,11 +399,15 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
 }
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     Dims d = dims_of(&r.b);
-    if (!r.aux[0]) { // lazily create the side streams (they live as long as the suite)
+    const Plan &pl = plan();
+    if (!r.aux[1]) { // lazily create the side streams (they live as long as the suite)
         int prio_lo = 0, prio_hi = 0;
         PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)); // numerically lower = higher priority
-        for (int i = 0; i < 3; i++) {
-            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, (i < 2 && !getenv("PQ_NO_PRIO")) ? prio_hi : prio_lo));
+        for (int i = 1; i < pl.nchain; i++) {
+            bool gated = false;
+            for (int c = 0; c < pl.ncls; c++) gated |= pl.cls[c].chain == i && pl.cls[c].gate_us > 0;
+            const bool hi = !gated && i != pl.row_chain && !getenv("PQ_NO_PRIO");
+            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, hi ? prio_hi : prio_lo));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
         PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
@@ -345,9 +433,11 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             return er;
         };
         auto njobs = [&](int c) { return p.first[c + 1] - p.first[c]; };
-        // chain -> stream: 0 = caller's stream (A), 1 = B, 2 = H, 3 = ROW launches, G, E
-        const bool side[3] = {njobs(CLS_B) > 0, njobs(CLS_H) > 0 || njobs(CLS_E) > 0, !p.rows.empty() || njobs(CLS_G) > 0};
-        const bool any_side = side[0] || side[1] || side[2];
+        bool side[NCHAIN] = {};
+        for (int c = 0; c < pl.ncls; c++) side[pl.cls[c].chain] |= njobs(c) > 0;
+        side[pl.row_chain] |= !p.rows.empty() || p.n_rowjobs > 0;
+        bool any_side = false;
+        for (int i = 1; i < pl.nchain; i++) any_side |= side[i];
         if (p.d_dbg && atoi(getenv("PQ_SUITE_DEBUG")) >= 2 && !p.d_wg) {
             p.wg_tiles = tiles;
             PQ_HIP_TRY(hipMalloc((void **)&p.d_wg, 24 * (size_t)tiles * p.seq.size()));
@@ -359,33 +449,41 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             PQ_HIP_TRY(hipMemcpy(p.d_dbg, init.data(), 16 * p.seq.size(), hipMemcpyHostToDevice));
         }
         if (any_side) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
+        static const int gate_override = getenv("PQ_GATE_US") ? atoi(getenv("PQ_GATE_US")) : -1;
         auto launch_class = [&](int c, hipStream_t st) -> pq_status {
             const int nj = njobs(c);
             if (nj <= 0) return PQ_OK;
+            const int gate_us = (pl.cls[c].gate_us > 0 && gate_override >= 0) ? gate_override : pl.cls[c].gate_us;
+            if (gate_us > 0 && p.gate) hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)gate_us * 100ULL);
             PQ_HIP_TRY(timed(p.gs[c], st, true));
             unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
             const dim3 grid(tiles, (unsigned)nj);
-            if (c == CLS_G) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
-            else if (c == CLS_H) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
+            const int v = pl.cls[c].variant;
+            if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
+            else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             PQ_HIP_TRY(timed(p.gs[c], st, false));
             return PQ_OK;
         };
         pq_status ps;
-        const int chain_cls[3][2] = {{CLS_B, -1}, {CLS_H, CLS_E}, {CLS_G, -1}};
-        const int chain_order[3] = {1, 0, 2}; // the Hilbert job is the longest of all: enqueue it first
-        for (int oi = 0; oi < 3; oi++) {
-            const int i = chain_order[oi];
-            if (i == 0 && (ps = launch_class(CLS_A, ctx->stream)) != PQ_OK) return ps; // A before B: hungriest first
-            if (!side[i]) continue;
-            hipStream_t st = r.aux[i];
-            PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
-            if (i == 2) for (const RowThunk &t : p.rows) t.launch(t.blob, st);
-            for (int k = 0; k < 2; k++)
-                if (chain_cls[i][k] >= 0 && (ps = launch_class(chain_cls[i][k], st)) != PQ_OK) return ps;
-            PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
+        for (int oi = 0; oi < pl.nchain; oi++) { // enqueue order: the longest / hungriest chains first
+            const int i = pl.chain_order[oi];
+            if (!side[i] && i != 0) continue;
+            hipStream_t st = i == 0 ? ctx->stream : r.aux[i];
+            if (i != 0) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
+            if (i == pl.row_chain) {
+                for (int64_t s0 = 0; s0 < r.b.n_series && p.n_rowjobs > 0; s0 += 65535) { // grid.y is limited to 65535
+                    const int64_t ns = r.b.n_series - s0 < 65535 ? r.b.n_series - s0 : 65535;
+                    hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((r.b.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0,
+                                       st, p.d_rowjobs, p.n_rowjobs, d, s0);
+                }
+                for (const RowThunk &t : p.rows) t.launch(t.blob, st);
+            }
+            for (int c = 0; c < pl.ncls; c++)
+                if (pl.cls[c].chain == i && (ps = launch_class(c, st)) != PQ_OK) return ps;
+            if (i != 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
         }
-        for (int i = 0; i < 3; i++)
+        for (int i = 1; i < pl.nchain; i++)
             if (side[i]) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[i], 0));
         if (p.d_dbg) { // debug only: wait and print the per-job schedule (100 MHz device clock)
             PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -427,13 +525,14 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
 }
 static void suite_free(pq_ctx *ctx, Recorder &r) {
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < NCHAIN; i++) {
         if (r.aux[i]) { (void)hipStreamSynchronize(r.aux[i]); (void)hipStreamDestroy(r.aux[i]); r.aux[i] = nullptr; }
         if (r.ev_join[i]) { (void)hipEventDestroy(r.ev_join[i]); r.ev_join[i] = nullptr; }
     }
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     for (Phase &p : r.phases) {
         if (p.d_seq) (void)hipFree(p.d_seq);
+        if (p.d_rowjobs) (void)hipFree(p.d_rowjobs);
         if (p.d_dbg) (void)hipFree(p.d_dbg);
         if (p.d_wg) (void)hipFree(p.d_wg);
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
@@ -552,6 +651,19 @@ pq_status pq_suite_grid_stats(pq_suite *s, int32_t k, double *avg_ms, double *al
             return PQ_OK;
         }
     pq_set_error("pq_suite_grid_stats: grid index out of range");
+    return PQ_ERR_ARG;
+}
+pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
+    PQ_REQUIRE(s && variant, "pq_suite_grid_variant: null pointer");
+    int idx = 0;
+    for (Phase &p : s->rec.phases)
+        for (int c = 0; c < NCLS; c++) {
+            if (p.gs[c].n_jobs == 0) continue;
+            if (idx++ != k) continue;
+            *variant = plan().cls[c].variant;
+            return PQ_OK;
+        }
+    pq_set_error("pq_suite_grid_variant: grid index out of range");
     return PQ_ERR_ARG;
 }
 pq_status pq_suite_info(const pq_suite *s, int32_t *n_phases, int32_t *n_seq_jobs, int32_t *n_row_launches) {

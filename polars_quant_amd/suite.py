@@ -134,7 +134,10 @@ class Suite:
             st = lib().pq_suite_grid_stats(self._suite, k, C.byref(ms), C.byref(by), C.byref(nj), C.byref(lds), C.byref(runs))
             if st != 0:
                 break
-            out.append({"avg_ms": ms.value, "alg_bytes": by.value, "n_jobs": nj.value, "lds_bytes": lds.value, "runs": runs.value})
+            var = C.c_int32()
+            check(lib().pq_suite_grid_variant(self._suite, k, C.byref(var)))
+            out.append({"avg_ms": ms.value, "alg_bytes": by.value, "n_jobs": nj.value, "lds_bytes": lds.value, "runs": runs.value,
+                        "kernel": f"seq_jobs_kernel<{var.value}>"})
             k += 1
         return out
 
