@@ -6,12 +6,13 @@ Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C p
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 from ._spec import I, SPEC
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libpolars_quant_hip.so"
+LIB_PATH = Path(os.environ["PQ_LIB_PATH"]) if os.environ.get("PQ_LIB_PATH") else _HERE / "libpolars_quant_hip.so"  # override: A/B builds
 
 PQ_OK = 0
 NULL_BITS = 0x7FF80000504E554C

@@ -24,6 +24,38 @@ struct Ma2 {
     __device__ double step(double v) { return kind ? e.step(v) : s.step_ring(w, v); }
 };
 
+// Two moving averages of the SAME input: when both are SMAs they share one ring (depth = the longer period; the shorter
+// one reads its expiring value with Ring::get) -- same values, same operation order, 6-13 KB less LDS per job.
+struct Ma2Pair {
+    Ma2 a, b;
+    Ring w;
+    bool shared;
+    int pa, pb;
+    __host__ __device__ static int64_t slots(int64_t mta, int64_t pa_, int64_t mtb, int64_t pb_) {
+        if (mta != 1 && mtb != 1) { int64_t m = pa_ > pb_ ? pa_ : pb_; return m > 0 ? m : 1; }
+        return Ma2::slots(mta, pa_) + Ma2::slots(mtb, pb_);
+    }
+    __device__ void init(int64_t mta, int64_t pa_, int64_t mtb, int64_t pb_, int64_t n, RingAlloc &ra) {
+        shared = (mta != 1 && mtb != 1);
+        if (shared) {
+            a.kind = b.kind = 0;
+            a.s.init(pa_, n); b.s.init(pb_, n);
+            pa = (int)(pa_ > 0 ? pa_ : 1); pb = (int)(pb_ > 0 ? pb_ : 1);
+            w = ra.make(pa_ > pb_ ? pa_ : pb_);
+        } else {
+            a.init(mta, pa_, n, ra); b.init(mtb, pb_, n, ra);
+        }
+    }
+    __device__ void step(double v, double &ya, double &yb) {
+        if (!shared) { ya = a.step(v); yb = b.step(v); return; }
+        if (pq_isnull(v)) { ya = yb = pq_null(); return; }
+        const double oa = w.get(pa), ob = w.get(pb);
+        ya = a.s.step_old(v, oa);
+        yb = b.s.step_old(v, ob);
+        w.push(v);
+    }
+};
+
 struct TrimaOp {
     static constexpr bool LDS_ONLY = true; // overlap.rs:1313-1326: sma(sma(x, k1), k2)
     static constexpr int NIN = 1, NOUT = 1;
@@ -44,13 +76,14 @@ struct MaDiffOp {
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 71 + MODE;
     int64_t fast, slow, matype;
-    Ma2 f, s;
-    __host__ __device__ int64_t ring_slots() const { return Ma2::slots(matype, fast) + Ma2::slots(matype, slow); }
+    Ma2Pair fs;
+    __host__ __device__ int64_t ring_slots() const { return Ma2Pair::slots(matype, fast, matype, slow); }
     __device__ void init(const Row<1> &) {}
-    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { f.init(matype, fast, r.len, ra); s.init(matype, slow, r.len, ra); }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { fs.init(matype, fast, matype, slow, r.len, ra); }
     __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[1]) { y[0] = pq_null(); }
     __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
-        double a = f.step(x[0]), b = s.step(x[0]);
+        double a, b;
+        fs.step(x[0], a, b);
         if (pq_isnull(a) || pq_isnull(b)) { y[0] = pq_null(); return; }
         if (MODE == 0) y[0] = a - b;
         else y[0] = (b == 0.0) ? pq_null() : (a - b) / b * 100.0;
@@ -62,15 +95,17 @@ struct MacdextOp {
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int SEQ_ID = 73;
     int64_t fast, fastmt, slow, slowmt, sig, sigmt;
-    Ma2 f, s, g;
-    __host__ __device__ int64_t ring_slots() const { return Ma2::slots(fastmt, fast) + Ma2::slots(slowmt, slow) + Ma2::slots(sigmt, sig); }
+    Ma2Pair fs;
+    Ma2 g;
+    __host__ __device__ int64_t ring_slots() const { return Ma2Pair::slots(fastmt, fast, slowmt, slow) + Ma2::slots(sigmt, sig); }
     __device__ void init(const Row<1> &) {}
     __device__ void init_lds(const Row<1> &r, RingAlloc &ra) {
-        f.init(fastmt, fast, r.len, ra); s.init(slowmt, slow, r.len, ra); g.init(sigmt, sig, r.len, ra);
+        fs.init(fastmt, fast, slowmt, slow, r.len, ra); g.init(sigmt, sig, r.len, ra);
     }
     __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[3]) { y[0] = y[1] = y[2] = pq_null(); }
     __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[3]) {
-        double a = f.step(x[0]), b = s.step(x[0]);
+        double a, b;
+        fs.step(x[0], a, b);
         double m = (pq_isnull(a) || pq_isnull(b)) ? pq_null() : a - b;
         double d = g.step(m); // N-A: a null macd row is skipped by the signal MA
         y[0] = m; y[1] = d;

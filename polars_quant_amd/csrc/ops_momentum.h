@@ -243,6 +243,7 @@ struct TrixOp { // momentum.rs:544-569 (quirk Q-TRIX)
 struct UltoscOp { // momentum.rs:572-627
     static constexpr int NIN = 3, NOUT = 1; // high, low, close
     static constexpr int SEQ_ID = 24;
+    static constexpr int TILE_K = 4; // 4-row tiles: 36.4 KB instead of 42.5 KB with the default periods, i.e. 4 workgroups per CU
     static constexpr int NTAP = 12; // per window: high, low, close at i-p and close at i-p-1
     static constexpr int TAP_COL[12] = {0, 1, 2, 2, 0, 1, 2, 2, 0, 1, 2, 2};
     int64_t p1, p2, p3;

@@ -220,6 +220,9 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d) {
     const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
     if (t >= d.len) return;
     const int64_t base = s * d.stride;
+    // ~2000 instructions per row: beside the SEQ grids of a suite (whose long jobs raise their own priority) this kernel would
+    // otherwise only be issued in the gaps and become the critical path of the step
+    __builtin_amdgcn_s_setprio(3);
     Cdl w[5];
     load_window(a, base, t, w);
 #pragma unroll

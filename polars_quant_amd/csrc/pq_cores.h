@@ -89,6 +89,18 @@ struct SmaCore {
         }
         return sum * denom;
     }
+    // shared-ring variant: `old` = the valid value pushed p pushes ago, read by the caller (Ring::get(p) before its push)
+    __device__ double step_old(double v, double old) {
+        if (dead || pq_isnull(v)) return pq_null();
+        count += 1;
+        sum += v;
+        if (count < p) return pq_null();
+        if (count > p) {
+            sum -= old;
+            count -= 1;
+        }
+        return sum * denom;
+    }
     // LDS-ring variant: the ring holds the last p valid values, so the popped value is ring.swap(v)
     __device__ double step_ring(Ring &w, double v) {
         if (dead || pq_isnull(v)) return pq_null();

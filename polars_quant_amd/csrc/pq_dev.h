@@ -293,9 +293,13 @@ struct HasRings<Op, decltype((void)&Op::ring_slots)> { static constexpr bool val
 #ifndef PQ_KXX
 #define PQ_KXX 8
 #endif
+template <class Op, class = void>
+struct TileK { static constexpr int value = (Op::NIN == 1 && Op::NOUT == 1) ? PQ_K11 : PQ_KXX; };
+template <class Op>
+struct TileK<Op, decltype((void)Op::TILE_K)> { static constexpr int value = Op::TILE_K; }; // an op may trade tile size for LDS
 template <class Op>
 struct SeqTile {
-    static constexpr int K = (Op::NIN == 1 && Op::NOUT == 1) ? PQ_K11 : PQ_KXX;   // rows per tile
+    static constexpr int K = TileK<Op>::value;   // rows per tile
 #ifdef PQ_DIRECT_STORES
     static constexpr bool DIRECT = true;  // experiment: outputs by per-lane 8-byte stores, no output tiles
 #else

@@ -83,8 +83,10 @@ __global__ void gate_kernel(unsigned long long ticks) {
 struct RowJob;
 struct Phase {
     GridStat gs[NCLS];
+    GridStat gs_row;           // the chain of ROW launches (timed as one unit)
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
+    std::vector<char> row_late; // 1: launched on the caller's stream behind the chain-0 SEQ grid instead of on the ROW chain
     SeqJob *d_seq = nullptr;
     RowJob *d_rowjobs = nullptr; // the fusable ROW launches of the phase (the others stay in `rows`)
     int n_rowjobs = 0;
@@ -128,6 +130,7 @@ static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind ==
 
 // V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
+__device__ int g_noprio = 0; // experiment switch
 template <int V>
 __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
     const int64_t s = s0 + threadIdx.x;
     if (s0 >= d.n) return; // grid.x is padded to a multiple of 8 (see pq_suite_run)
     // long jobs are the critical path of the step: their waves win the issue arbitration against short jobs on the same SIMD
-    if (job.cost >= 200) __builtin_amdgcn_s_setprio(3);
+    if (g_noprio) {} else if (job.cost >= 200) __builtin_amdgcn_s_setprio(3);
     else if (job.cost >= 140) __builtin_amdgcn_s_setprio(2);
     else if (job.cost >= 100) __builtin_amdgcn_s_setprio(1);
 #define X(OP)                                                                                                        \
@@ -339,6 +342,23 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
                 PQ_HIP_TRY(hipMemcpy(p.d_rowjobs, rj.data(), sizeof(RowJob) * rj.size(), hipMemcpyHostToDevice));
             }
         }
+        p.gs_row.n_jobs = (int)p.rows.size() + (p.n_rowjobs > 0 ? 1 : 0);
+        // The ROW launches are cheap streaming kernels, but beside the SEQ grids they get few wave slots and one chain of
+        // them becomes the critical path of the step.  Two chains: the heaviest launches (by columns moved) stay on the ROW
+        // chain from t = 0; the rest runs on the caller's stream behind the chain-0 grid, which is the first to drain.
+        p.row_late.assign(p.rows.size(), 0);
+        if (!p.seq.empty() && !getenv("PQ_NO_ROW_SPLIT")) {
+            double total = 0, early = 0;
+            auto weight = [](const RowThunk &t) { return (double)(t.n_reads + t.n_writes); };
+            for (const RowThunk &t : p.rows) total += weight(t);
+            std::vector<size_t> idx(p.rows.size());
+            for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
+            for (size_t k : idx) {
+                if (early < 0.5 * total) early += weight(p.rows[k]);
+                else p.row_late[k] = 1;
+            }
+        }
         if (p.seq.empty()) continue;
         if (gr_min) {
             const size_t tiles = (size_t)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
@@ -406,7 +426,9 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         for (int i = 1; i < pl.nchain; i++) {
             bool gated = false;
             for (int c = 0; c < pl.ncls; c++) gated |= pl.cls[c].chain == i && pl.cls[c].gate_us > 0;
-            const bool hi = !gated && i != pl.row_chain && !getenv("PQ_NO_PRIO");
+            // the ROW launches are short streaming kernels without LDS: at low priority they crawl behind the SEQ grids and end up
+            // as the critical path of the step
+            const bool hi = !gated && (i != pl.row_chain || !getenv("PQ_ROW_PRIO_LO")) && !getenv("PQ_NO_PRIO");
             PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, hi ? prio_hi : prio_lo));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
@@ -471,16 +493,22 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             if (!side[i] && i != 0) continue;
             hipStream_t st = i == 0 ? ctx->stream : r.aux[i];
             if (i != 0) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
-            if (i == pl.row_chain) {
+            if (i == pl.row_chain && (p.n_rowjobs > 0 || !p.rows.empty())) {
+                PQ_HIP_TRY(timed(p.gs_row, st, true));
                 for (int64_t s0 = 0; s0 < r.b.n_series && p.n_rowjobs > 0; s0 += 65535) { // grid.y is limited to 65535
                     const int64_t ns = r.b.n_series - s0 < 65535 ? r.b.n_series - s0 : 65535;
                     hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((r.b.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0,
                                        st, p.d_rowjobs, p.n_rowjobs, d, s0);
                 }
-                for (const RowThunk &t : p.rows) t.launch(t.blob, st);
+                for (size_t k = 0; k < p.rows.size(); k++)
+                    if (!p.row_late[k]) p.rows[k].launch(p.rows[k].blob, st);
+                PQ_HIP_TRY(timed(p.gs_row, st, false));
             }
             for (int c = 0; c < pl.ncls; c++)
                 if (pl.cls[c].chain == i && (ps = launch_class(c, st)) != PQ_OK) return ps;
+            if (i == 0) // the second half of the ROW launches follows the first SEQ grid to finish (see suite_finalize)
+                for (size_t k = 0; k < p.rows.size(); k++)
+                    if (p.row_late[k]) p.rows[k].launch(p.rows[k].blob, st);
             if (i != 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
         }
         for (int i = 1; i < pl.nchain; i++)
@@ -536,6 +564,8 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
         if (p.d_dbg) (void)hipFree(p.d_dbg);
         if (p.d_wg) (void)hipFree(p.d_wg);
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
+        for (hipEvent_t e : p.gs_row.ev) (void)hipEventDestroy(e);
+        p.gs_row.ev.clear(); p.gs_row.runs = 0;
     }
     for (void *s : r.scratch) (void)hipFree(s);
     r.phases.clear();
@@ -634,7 +664,8 @@ pq_status pq_suite_grid_stats(pq_suite *s, int32_t k, double *avg_ms, double *al
     PQ_REQUIRE(s, "pq_suite_grid_stats: null pointer");
     int idx = 0;
     for (Phase &p : s->rec.phases)
-        for (GridStat &g : p.gs) {
+        for (int c = 0; c <= NCLS; c++) {
+            GridStat &g = c < NCLS ? p.gs[c] : p.gs_row;
             if (g.n_jobs == 0) continue;
             if (idx++ != k) continue;
             double tot = 0;
@@ -657,10 +688,10 @@ pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
     PQ_REQUIRE(s && variant, "pq_suite_grid_variant: null pointer");
     int idx = 0;
     for (Phase &p : s->rec.phases)
-        for (int c = 0; c < NCLS; c++) {
-            if (p.gs[c].n_jobs == 0) continue;
+        for (int c = 0; c <= NCLS; c++) {
+            if ((c < NCLS ? p.gs[c] : p.gs_row).n_jobs == 0) continue;
             if (idx++ != k) continue;
-            *variant = plan().cls[c].variant;
+            *variant = c < NCLS ? plan().cls[c].variant : 3; // 3 = the chain of ROW launches
             return PQ_OK;
         }
     pq_set_error("pq_suite_grid_variant: grid index out of range");
