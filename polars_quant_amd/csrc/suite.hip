@@ -47,21 +47,25 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
 // Plan "wide" (experiment, PQ_SUITE_PLAN=w with GPU_MAX_HW_QUEUES >= 8): five LDS size classes (160 KB / 3, 5, 6, 7, 11 per CU)
 // so that less LDS is charged than needed, the smallest (short jobs) held back by a timed gate.
 constexpr int NCLS = 8, NCHAIN = 7; // chain 0 = the caller's stream
-struct ClassDef { int variant; unsigned lds_lo, lds_hi; int chain, gate_us; }; // variant 0 light, 1 heavy, 2 gather; LDS in (lo, hi]
+struct ClassDef { int variant; unsigned lds_lo, lds_hi; int chain, gate_us, max_cost; }; // variant 0 light, 1 heavy, 2 gather; LDS in (lo, hi]
 struct Plan { int ncls, nchain, row_chain; ClassDef cls[NCLS]; int chain_order[NCHAIN]; };
-static const Plan PLAN_NARROW = {4, 4, 3,
-    {{0, 28 * 1024, 1u << 30, 0, 0}, {0, 0, 28 * 1024, 1, 0}, {1, 0, 1u << 30, 2, 0}, {2, 0, 0, 3, 0}},
+static const Plan PLAN_NARROW_E = {5, 4, 3, // (experiment, no gain) the small short jobs (<= 14 KB, < 1.4 ms) follow the > 28 KB grid
+    {{0, 28 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 0, 14 * 1024, 0, 0, 139}, {0, 0, 28 * 1024, 1, 0, 1 << 30}, {1, 0, 1u << 30, 2, 0, 1 << 30},
+     {2, 0, 0, 3, 0, 1 << 30}},
+    {2, 0, 1, 3}};
+static const Plan PLAN_NARROW = {4, 4, 3, // default: the small short jobs sit at the end of the 14..28 KB grid
+    {{0, 28 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 0, 28 * 1024, 1, 0, 1 << 30}, {1, 0, 1u << 30, 2, 0, 1 << 30}, {2, 0, 0, 3, 0, 1 << 30}},
     {2, 0, 1, 3}};
 static const Plan PLAN_WIDE = {7, 7, 5,
-    {{0, 32 * 1024, 1u << 30, 0, 0}, {0, 27264, 32 * 1024, 1, 0}, {0, 23360, 27264, 2, 0}, {0, 14 * 1024, 23360, 3, 0},
-     {1, 0, 1u << 30, 4, 0}, {2, 0, 0, 5, 0}, {0, 0, 14 * 1024, 6, 1500}},
+    {{0, 32 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 27264, 32 * 1024, 1, 0, 1 << 30}, {0, 23360, 27264, 2, 0, 1 << 30},
+     {0, 14 * 1024, 23360, 3, 0, 1 << 30}, {1, 0, 1u << 30, 4, 0, 1 << 30}, {2, 0, 0, 5, 0, 1 << 30}, {0, 0, 14 * 1024, 6, 1500, 1 << 30}},
     {4, 0, 1, 2, 3, 5, 6}};
 static const Plan &plan() {
     static const Plan *p = [] {
         // measured: the wide plan does not pay (7.2 vs 6.3 ms per step: more fork/join traffic, short jobs still start late),
         // so it is opt-in for experiments and needs GPU_MAX_HW_QUEUES >= 8 in the environment of the process
         const char *force = getenv("PQ_SUITE_PLAN");
-        return (force && force[0] == 'w') ? &PLAN_WIDE : &PLAN_NARROW;
+        return (force && force[0] == 'w') ? &PLAN_WIDE : ((force && force[0] == 'e') ? &PLAN_NARROW_E : &PLAN_NARROW);
     }();
     return *p;
 }
@@ -72,7 +76,9 @@ static int job_class(int kind, unsigned lds) {
     const bool bt = kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1;
     const int variant = (kind_is_heavy(kind) && (lds > 0 || bt)) ? 1 : (lds == 0 ? 2 : 0);
     for (int c = 0; c < pl.ncls; c++)
-        if (pl.cls[c].variant == variant && (variant == 2 || (lds > pl.cls[c].lds_lo && lds <= pl.cls[c].lds_hi))) return c;
+        if (pl.cls[c].variant == variant && (variant == 2 || (lds > pl.cls[c].lds_lo && lds <= pl.cls[c].lds_hi)) &&
+            job_cost(kind) <= pl.cls[c].max_cost)
+            return c;
     return pl.ncls - 1;
 }
 // Timed gate in front of a grid of short jobs (wall_clock64: 100 MHz).  Bounded: it only ever waits for time to pass.
@@ -86,7 +92,7 @@ struct Phase {
     GridStat gs_row;           // the chain of ROW launches (timed as one unit)
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
-    std::vector<char> row_late; // 1: launched on the caller's stream behind the chain-0 SEQ grid instead of on the ROW chain
+    std::vector<char> row_late; // 0: on the ROW chain; 1 + c: behind the SEQ grid(s) of chain c
     SeqJob *d_seq = nullptr;
     RowJob *d_rowjobs = nullptr; // the fusable ROW launches of the phase (the others stay in `rows`)
     int n_rowjobs = 0;
@@ -348,15 +354,26 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // chain from t = 0; the rest runs on the caller's stream behind the chain-0 grid, which is the first to drain.
         p.row_late.assign(p.rows.size(), 0);
         if (!p.seq.empty() && !getenv("PQ_NO_ROW_SPLIT")) {
-            double total = 0, early = 0;
+            // chains whose SEQ grid drains early take the lighter ROW launches: chain 0 (the > 28 KB jobs, all placed at t = 0)
+            // and the chain of the register-heavy jobs
+            const Plan &pl = plan();
+            int late_chain[2] = {0, 0}, nlate = 1;
+            for (int c = 0; c < pl.ncls; c++) {
+                bool has = false;
+                for (const SeqJob &j : p.seq) has |= job_class(j.kind, j.lds_bytes) == c;
+                if (has && pl.cls[c].variant == 1) late_chain[nlate++] = pl.cls[c].chain;
+            }
+            double total = 0, early = 0, load[2] = {0, 0};
             auto weight = [](const RowThunk &t) { return (double)(t.n_reads + t.n_writes); };
             for (const RowThunk &t : p.rows) total += weight(t);
             std::vector<size_t> idx(p.rows.size());
             for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
             std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
             for (size_t k : idx) {
-                if (early < 0.5 * total) early += weight(p.rows[k]);
-                else p.row_late[k] = 1;
+                if (early < 0.5 * total) { early += weight(p.rows[k]); continue; }
+                const int g = (nlate == 2 && load[1] < load[0]) ? 1 : 0;
+                load[g] += weight(p.rows[k]);
+                p.row_late[k] = (char)(1 + late_chain[g]);
             }
         }
         if (p.seq.empty()) continue;
@@ -506,9 +523,8 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             }
             for (int c = 0; c < pl.ncls; c++)
                 if (pl.cls[c].chain == i && (ps = launch_class(c, st)) != PQ_OK) return ps;
-            if (i == 0) // the second half of the ROW launches follows the first SEQ grid to finish (see suite_finalize)
-                for (size_t k = 0; k < p.rows.size(); k++)
-                    if (p.row_late[k]) p.rows[k].launch(p.rows[k].blob, st);
+            for (size_t k = 0; k < p.rows.size(); k++) // the lighter ROW launches follow an early-draining SEQ grid (suite_finalize)
+                if (p.row_late[k] == 1 + i) p.rows[k].launch(p.rows[k].blob, st);
             if (i != 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
         }
         for (int i = 1; i < pl.nchain; i++)

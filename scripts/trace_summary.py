@@ -28,3 +28,10 @@ span = (max(int(r["End_Timestamp"]) for r in c) - t0) / 1e3
 print(f"step span {span:.1f} us (launches of one step overlap on 4 streams)")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:8]:
     print(f"   {v:9.1f} us  {k}")
+# gaps between consecutive steps (last kernel end -> next step's first kernel start)
+gaps = []
+for a, b in zip(steps[:-1], steps[1:]):
+    gaps.append((int(b[0]["Start_Timestamp"]) - max(int(r["End_Timestamp"]) for r in a)) / 1e3)
+if gaps:
+    spans = [(max(int(r["End_Timestamp"]) for r in c) - int(c[0]["Start_Timestamp"])) / 1e3 for c in steps]
+    print(f"step spans: median {sorted(spans)[len(spans)//2]:.1f} us; inter-step gaps: median {sorted(gaps)[len(gaps)//2]:.1f} us, max {max(gaps):.1f} us")
