@@ -30,25 +30,25 @@ pq_status pq_trange(pq_ctx *ctx, const pq_batch *b, const double *h, const doubl
 pq_status pq_atr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                  double *out) {
     CHK("pq_atr", h && l && c && out);
-    AtrOp<false> op; op.p = p;
+    AtrOp<false> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});
 }
 pq_status pq_natr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                   double *out) {
     CHK("pq_natr", h && l && c && out);
-    AtrOp<true> op; op.p = p;
+    AtrOp<true> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});
 }
 pq_status pq_ad(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, const double *v,
                 double *out) {
     CHK("pq_ad", h && l && c && v && out);
-    AdOp<false> op; op.fast = op.slow = 0;
+    AdOp<false> op{}; op.fast = op.slow = 0;
     return launch_seq(ctx, b, op, InCols<4>{{h, l, c, v}}, OutCols<1>{{out}});
 }
 pq_status pq_adosc(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, const double *v,
                    int64_t fast, int64_t slow, double *out) {
     CHK("pq_adosc", h && l && c && v && out);
-    AdOp<true> op; op.fast = fast; op.slow = slow;
+    AdOp<true> op{}; op.fast = fast; op.slow = slow;
     return launch_seq(ctx, b, op, InCols<4>{{h, l, c, v}}, OutCols<1>{{out}});
 }
 pq_status pq_obv(pq_ctx *ctx, const pq_batch *b, const double *c, const double *v, double *out) {
@@ -74,7 +74,7 @@ pq_status pq_ht_sine(pq_ctx *ctx, const pq_batch *b, const double *real, double 
 pq_status pq_mama(pq_ctx *ctx, const pq_batch *b, const double *real, double fastlimit, double slowlimit,
                   double *mama, double *fama) {
     CHK("pq_mama", real && mama && fama);
-    HtOp<4> op; op.fastlimit = fastlimit; op.slowlimit = slowlimit;
+    HtOp<4> op{}; op.fastlimit = fastlimit; op.slowlimit = slowlimit;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<2>{{mama, fama}});
 }
 pq_status pq_ht_trendline(pq_ctx *ctx, const pq_batch *b, const double *real, double *out) {

@@ -13,7 +13,7 @@ extern "C" {
 #define LAGFN(name, KIND)                                                                                   \
     pq_status name(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {            \
         CHK(#name, real && out);                                                                            \
-        LagOp<KIND> op; op.p = p;                                                                           \
+        LagOp<KIND> op{}; op.p = p;                                                                           \
         return launch_row(ctx, b, op, InCols<1>{{real}}, OutColsT<LagOp<KIND>, double>{{out}});             \
     }
 LAGFN(pq_mom, 0)
@@ -29,18 +29,18 @@ pq_status pq_bop(pq_ctx *ctx, const pq_batch *b, const double *o, const double *
 }
 pq_status pq_aroon(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *up, double *dn) {
     CHK("pq_aroon", h && l && up && dn);
-    AroonOp<0> op; op.p = p;
+    AroonOp<0> op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<2>{{h, l}}, OutColsT<AroonOp<0>, double>{{up, dn}});
 }
 pq_status pq_aroonosc(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *out) {
     CHK("pq_aroonosc", h && l && out);
-    AroonOp<1> op; op.p = p;
+    AroonOp<1> op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<2>{{h, l}}, OutColsT<AroonOp<1>, double>{{out}});
 }
 pq_status pq_willr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                    double *out) {
     CHK("pq_willr", h && l && c && out);
-    WillrOp op; op.p = p;
+    WillrOp op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<3>{{h, l, c}}, OutColsT<WillrOp, double>{{out}});
 }
 pq_status pq_cci_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
@@ -48,25 +48,25 @@ pq_status pq_cci_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const do
     CHK("pq_cci", h && l && c && out);
     WS(8);
     double *sma_tp = pq_ws_col(ctx, b, 0);
-    SmaTpOp s; s.p = p;
+    SmaTpOp s{}; s.p = p;
     PQ_TRY(launch_seq(ctx, b, s, InCols<3>{{h, l, c}}, OutCols<1>{{sma_tp}}));
-    CciDevOp op; op.p = p;
+    CciDevOp op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<4>{{h, l, c, sma_tp}}, OutColsT<CciDevOp, double>{{out}});
 }
 pq_status pq_cmo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     CHK("pq_cmo", real && out);
-    CmoOp op; op.p = p;
+    CmoOp op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<1>{{out}});
 }
 pq_status pq_rsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     CHK("pq_rsi", real && out);
-    RsiOp op; op.p = p;
+    RsiOp op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<1>{{out}});
 }
 pq_status pq_macd(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t sig,
                   double *macd, double *signal, double *hist) {
     CHK("pq_macd", real && macd && signal && hist);
-    MacdOp op; op.fast = fast; op.slow = slow; op.sig = sig;
+    MacdOp op{}; op.fast = fast; op.slow = slow; op.sig = sig;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<3>{{macd, signal, hist}});
 }
 pq_status pq_macdfix(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t sig, double *macd, double *signal,
@@ -75,26 +75,26 @@ pq_status pq_macdfix(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
 }
 pq_status pq_trix(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     CHK("pq_trix", real && out);
-    TrixOp op; op.p = p;
+    TrixOp op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<1>{{out}});
 }
 pq_status pq_ultosc(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p1,
                     int64_t p2, int64_t p3, double *out) {
     CHK("pq_ultosc", h && l && c && out);
-    UltoscOp op; op.p1 = p1; op.p2 = p2; op.p3 = p3;
+    UltoscOp op{}; op.p1 = p1; op.p2 = p2; op.p3 = p3;
     return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});
 }
 pq_status pq_mfi(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, const double *v,
                  int64_t p, double *out) {
     CHK("pq_mfi", h && l && c && v && out);
-    MfiOp op; op.p = p;
+    MfiOp op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<4>{{h, l, c, v}}, OutCols<1>{{out}});
 }
 #define DMFN(name, MODE)                                                                                       \
     pq_status name(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, \
                    double *out) {                                                                              \
         CHK(#name, h && l && c && out);                                                                        \
-        DmOp<MODE> op; op.p = p;                                                                               \
+        DmOp<MODE> op{}; op.p = p;                                                                               \
         return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});                                \
     }
 DMFN(pq_dx, 0)
@@ -107,17 +107,17 @@ pq_status pq_adxr_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const d
     WS(8);
     double *adx = pq_ws_col(ctx, b, 0);
     PQ_TRY(pq_adx(ctx, b, h, l, c, p, adx));
-    AdxrOp op; op.p = p;
+    AdxrOp op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<1>{{adx}}, OutColsT<AdxrOp, double>{{out}});
 }
 pq_status pq_plus_dm(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *out) {
     CHK("pq_plus_dm", h && l && out);
-    DmRawOp<true> op; op.p = p;
+    DmRawOp<true> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<2>{{h, l}}, OutCols<1>{{out}});
 }
 pq_status pq_minus_dm(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *out) {
     CHK("pq_minus_dm", h && l && out);
-    DmRawOp<false> op; op.p = p;
+    DmRawOp<false> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<2>{{h, l}}, OutCols<1>{{out}});
 }
 // D-6: APO = MA(fast) - MA(slow); PPO = (MA(fast)-MA(slow))/MA(slow)*100 on the reference's calc_ma
@@ -153,7 +153,7 @@ pq_status pq_macdext_chain(pq_ctx *ctx, const pq_batch *b, const double *real, i
 pq_status pq_stochf_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk,
                     int64_t fastd, int64_t fastd_mt, double *outk, double *outd) {
     CHK("pq_stochf", h && l && c && outk && outd); // momentum.py:188-195
-    FastkOp op; op.k = fastk;
+    FastkOp op{}; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{h, l, c}}, OutColsT<FastkOp, double>{{outk}}));
     return pq_ma(ctx, b, outk, fastd, fastd_mt, outd);
 }
@@ -162,7 +162,7 @@ pq_status pq_stoch_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const 
     CHK("pq_stoch", h && l && c && outk && outd); // momentum.py:178-186
     WS(8);
     double *fk = pq_ws_col(ctx, b, 0);
-    FastkOp op; op.k = fastk;
+    FastkOp op{}; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{h, l, c}}, OutColsT<FastkOp, double>{{fk}}));
     PQ_TRY(pq_ma(ctx, b, fk, slowk, slowk_mt, outk));
     return pq_ma(ctx, b, outk, slowd, slowd_mt, outd);
@@ -173,7 +173,7 @@ pq_status pq_stochrsi_chain(pq_ctx *ctx, const pq_batch *b, const double *real, 
     WS(8);
     double *rsi = pq_ws_col(ctx, b, 0);
     PQ_TRY(pq_rsi(ctx, b, real, p, rsi));
-    FastkOp op; op.k = fastk;
+    FastkOp op{}; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{rsi, rsi, rsi}}, OutColsT<FastkOp, double>{{outk}}));
     return pq_ma(ctx, b, outk, fastd, fastd_mt, outd);
 }

@@ -11,7 +11,7 @@ template <class Inner>
 static pq_status mavp_jobs(pq_ctx *ctx, const pq_batch *b, const double *r0, const double *periods, int64_t minp,
                            int64_t maxp, Inner proto, double *out) {
     for (int64_t P = minp; P <= maxp; P++) {
-        MavpSelOp<Inner> op; op.P = P; op.minp = minp; op.maxp = maxp; op.inner = proto; op.inner.p = P;
+        MavpSelOp<Inner> op{}; op.P = P; op.minp = minp; op.maxp = maxp; op.inner = proto; op.inner.p = P;
         PQ_TRY(launch_seq(ctx, b, op, IN2(r0, periods), OUT1(out)));
     }
     return PQ_OK;
@@ -21,33 +21,33 @@ extern "C" {
 
 pq_status pq_sma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_sma: null pointer");
-    SmaOp op; op.p = p;
+    SmaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_ema(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_ema: null pointer");
-    EmaOp op; op.p = p;
+    EmaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_bbands(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double up, double dn,
                     double *u, double *m, double *l) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && u && m && l, "pq_bbands: null pointer");
-    BbandsOp op; op.p = p; op.up = up; op.dn = dn;
+    BbandsOp op{}; op.p = p; op.up = up; op.dn = dn;
     return launch_seq(ctx, b, op, IN1(real), OutCols<3>{{u, m, l}});
 }
 pq_status pq_dema(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_dema: null pointer");
-    DemaOp op; op.p = p;
+    DemaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_tema(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_tema: null pointer");
-    TemaOp op; op.p = p;
+    TemaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_t3(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double vf, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_t3: null pointer");
-    T3Op op; op.p = p;
+    T3Op op{}; op.p = p;
     t3_coeffs(op, vf);
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
@@ -62,12 +62,12 @@ pq_status pq_trima_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int
 }
 pq_status pq_wma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_wma: null pointer");
-    WmaOp op; op.p = p;
+    WmaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_kama(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_kama: null pointer");
-    KamaOp op; op.p = p;
+    KamaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_ma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, int64_t matype, double *out) {
@@ -85,18 +85,18 @@ pq_status pq_ma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, i
 }
 pq_status pq_midpoint(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_midpoint: null pointer");
-    MidpointOp op; op.p = p;
+    MidpointOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_midprice(pq_ctx *ctx, const pq_batch *b, const double *high, const double *low, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(high && low && out, "pq_midprice: null pointer");
-    MidpriceOp op; op.p = p;
+    MidpriceOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN2(high, low), OUT1(out));
 }
 pq_status pq_sar(pq_ctx *ctx, const pq_batch *b, const double *high, const double *low, double accel, double maxv,
                  double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(high && low && out, "pq_sar: null pointer");
-    SarextOp op; op.ext = false; op.startvalue = 0.0; op.offset = 0.0;
+    SarextOp op{}; op.ext = false; op.startvalue = 0.0; op.offset = 0.0;
     op.ai_long = op.a_long = op.ai_short = op.a_short = accel;
     op.am_long = op.am_short = maxv;
     return launch_seq(ctx, b, op, IN2(high, low), OUT1(out));
@@ -105,7 +105,7 @@ pq_status pq_sarext(pq_ctx *ctx, const pq_batch *b, const double *high, const do
                     double offsetonreverse, double ai_long, double a_long, double am_long, double ai_short,
                     double a_short, double am_short, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(high && low && out, "pq_sarext: null pointer");
-    SarextOp op; op.ext = true; op.startvalue = startvalue; op.offset = offsetonreverse;
+    SarextOp op{}; op.ext = true; op.startvalue = startvalue; op.offset = offsetonreverse;
     op.ai_long = ai_long; op.a_long = a_long; op.am_long = am_long;
     op.ai_short = ai_short; op.a_short = a_short; op.am_short = am_short;
     return launch_seq(ctx, b, op, IN2(high, low), OUT1(out));
@@ -165,7 +165,7 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
             rec_set_shared_out(ctx, false);
             st = pq_trima(ctx, b, r0, P, ma);
             if (st != PQ_OK) break;
-            MavpPickOp sel; sel.P = P; sel.minp = minp; sel.maxp = maxp;
+            MavpPickOp sel{}; sel.P = P; sel.minp = minp; sel.maxp = maxp;
             rec_set_shared_out(ctx, true);
             st = launch_seq(ctx, b, sel, IN2(ma, periods), OUT1(out));
         }
