@@ -3,6 +3,10 @@
 #pragma once
 #include "pq_dev.h"
 
+// true when the condition holds on every active lane: lets a state machine take its steady-state path without any
+// per-lane branching (the warm-up / null paths below stay the general case)
+__device__ __forceinline__ bool wave_all(bool x) { return __builtin_amdgcn_ballot_w64(x) == __builtin_amdgcn_ballot_w64(true); }
+
 // overlap.rs:660-730 calc_ema: null-transparent (N-A), SMA seed at count == p, then
 // alpha.mul_add(x - ema, ema).
 struct EmaCore {
@@ -18,6 +22,10 @@ struct EmaCore {
         sum = 0.0;
     }
     __device__ double step(double v) {
+        if (wave_all(!dead && count >= p && !pq_isnull(v))) { // steady state on the whole wave (count only matters relative to p)
+            ema = fma(alpha, v - ema, ema);
+            return ema;
+        }
         if (dead || pq_isnull(v)) return pq_null();
         count += 1;
         if (count < p) {
@@ -91,6 +99,11 @@ struct SmaCore {
     }
     // shared-ring variant: `old` = the valid value pushed p pushes ago, read by the caller (Ring::get(p) before its push)
     __device__ double step_old(double v, double old) {
+        if (wave_all(!dead && count >= p && !pq_isnull(v))) { // full window on the whole wave: count stays at p
+            sum += v;
+            sum -= old;
+            return sum * denom;
+        }
         if (dead || pq_isnull(v)) return pq_null();
         count += 1;
         sum += v;
@@ -103,6 +116,11 @@ struct SmaCore {
     }
     // LDS-ring variant: the ring holds the last p valid values, so the popped value is ring.swap(v)
     __device__ double step_ring(Ring &w, double v) {
+        if (wave_all(!dead && count >= p && !pq_isnull(v))) { // full window on the whole wave: count stays at p
+            sum += v;
+            sum -= w.swap(v);
+            return sum * denom;
+        }
         if (dead || pq_isnull(v)) return pq_null();
         count += 1;
         sum += v;
@@ -131,6 +149,10 @@ struct RmaCore {
         pf = (double)p;
     }
     __device__ double step(int64_t i, double x) {
+        if (wave_all(!dead && i >= p)) { // steady state on the whole wave
+            r = (r * pm1 + x) / pf;
+            return r;
+        }
         if (dead) return pq_null();
         if (i < p - 1) {
             sum += x;
