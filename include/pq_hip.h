@@ -218,6 +218,30 @@ pq_status pq_backtest_macd_cross(pq_ctx *, const pq_batch *, const double *close
 pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close, int64_t fastperiod,
                                 int64_t slowperiod, int64_t signalperiod, uint8_t *buy, uint8_t *sell);
 
+/* ---- the README's multi-symbol `Backtest` (README.md:346-640; README-only, no source).
+ * Semantics = decision D-10 (oracle/backtest.c): independent capital pool per symbol, 100-share lots, leverage
+ * with daily compounding interest on the debt, margin call (forced sale), commission with a minimum, proportional
+ * slippage.  One symbol per lane; every column is [n_series][stride].
+ *   cash_net = cash - debt, stock_value, total_value: daily records (get_daily_records), all required.
+ *   trade records (get_position_records): the first max_trades closed trades per symbol in [n_series][max_trades] arrays,
+ *   all eight arrays or none (NULL); trade_count [n_series] counts every closed trade.  reason: 1 signal, 2 margin call.
+ *   benchmark: ONE series of b->len rows shared by all symbols, or NULL; summary [n_series][8] as pq_backtest_vectorized. */
+typedef struct {
+    double initial_capital, position_size, leverage, margin_call_threshold, interest_rate, commission_rate,
+        min_commission, slippage;
+} pq_lev_params; /* README.md:356-365 defaults: 1e5, 1, 1, 0.3, 0.06, 3e-4, 5, 0 */
+pq_status pq_backtest_leveraged(pq_ctx *, const pq_batch *, const double *price, const uint8_t *buy, const uint8_t *sell,
+                                const double *benchmark, const pq_lev_params *params, double *cash_net,
+                                double *stock_value, double *total_value, int32_t max_trades, int32_t *trade_count,
+                                int32_t *entry_day, int32_t *exit_day, double *entry_price, double *exit_price,
+                                double *quantity, double *pnl, double *pnl_pct, int32_t *reason, double *summary);
+#define PQ_PORTFOLIO_COLS 10 /* portfolio_value, daily_pnl, daily_return_pct, cumulative_pnl, cumulative_return_pct,
+                                benchmark_return_pct, alpha_pct, relative_return_pct, beta, (reserved 0) */
+/* get_performance_metrics (README.md:455-477): per-day sums over the symbols of this batch in ascending order, then the
+ * day-to-day metrics; out is [b->len][PQ_PORTFOLIO_COLS]; benchmark: one series of b->len rows or NULL */
+pq_status pq_portfolio_metrics(pq_ctx *, const pq_batch *, const double *total_value, double initial_total,
+                               const double *benchmark, double *out);
+
 /* ---- suites: record many calls, replay them as a few chip-filling grids ----
  * One indicator over N symbols is only N/64 wavefronts -- far too few for 256 CUs -- but a DataFrame query asks
  * for many indicators at once (df.with_columns([...]) in the reference; Polars then calls the plugin once per

@@ -121,6 +121,128 @@ void pqo_macd_cross_signals(const double *close, int64_t n, int64_t fast, int64_
     free(md); free(sg); free(hs);
 }
 
+/* ---------------------------------------------------------------------------------------------------------
+ * the README's multi-symbol `Backtest` with leverage / margin call / interest and 100-share lots
+ * (README.md:346-640).  README-only: there is no source, so decision D-10 below IS the specification.
+ *
+ * D-10, per symbol with its own capital pool (README.md:17,405), day t with price p:
+ *   0. p null / NaN / <= 0: no trading; the position is valued at the last valid price (0 before the first).
+ *   1. interest: debt += debt * interest_rate / 252                      (financing cost compounds daily)
+ *   2. margin call: holding with debt > 0 and  cash + shares*p - debt  <  margin_call_threshold * shares*p
+ *      -> forced sale today (reason 2), same mechanics as a signalled sale
+ *   3. else sell signal while holding -> sale (reason 1): exec = p*(1-slippage), fee = max(rev*rate, min_commission),
+ *      cash += rev - fee - debt, debt = 0; pnl = (rev - fee) - entry_outlay; a win iff pnl > 0
+ *   4. else buy signal while flat: power = cash * position_size * leverage, exec = p*(1+slippage),
+ *      lots = floor(power / (exec*100)), reduced while lots*100*exec + fee > cash*leverage; outlay = cost + fee;
+ *      debt = max(outlay - cash, 0); cash = max(cash - outlay, 0)
+ *   daily record: cash_net = cash - debt, stock_value = shares * p, total_value = cash_net + stock_value.
+ * Trade records: the first max_trades closed trades per symbol (trade_count keeps counting).  A position still open
+ * on the last day is not a trade.  The per-symbol summary is calculate_summary (metrics.rs:7-152) on total_value with
+ * an optional single benchmark series shared by all symbols (README.md:366).                                        */
+void pqo_backtest_leveraged(const double *price, const uint8_t *buy, const uint8_t *sell, const double *benchmark,
+                            int64_t n, const pqo_lev_params *prm, double *cash_net, double *stock_value,
+                            double *total_value, int32_t max_trades, int32_t *trade_count, int32_t *entry_day,
+                            int32_t *exit_day, double *entry_price, double *exit_price, double *quantity, double *pnl,
+                            double *pnl_pct, int32_t *reason, double *summary) {
+    double cash = prm->initial_capital, debt = 0.0, shares = 0.0, last_px = 0.0;
+    double e_outlay = 0.0, e_price = 0.0;
+    int64_t e_day = 0, trades = 0, wins = 0;
+    for (int64_t t = 0; t < n; t++) {
+        double p = price[t];
+        const int valid = !(isnan(p) || p <= 0.0);
+        if (debt > 0.0) debt += debt * prm->interest_rate / 252.0;
+        if (valid) {
+            last_px = p;
+            int do_sell = 0;
+            if (shares > 0.0) {
+                if (debt > 0.0 && cash + shares * p - debt < prm->margin_call_threshold * (shares * p)) do_sell = 2;
+                else if (sell[t]) do_sell = 1;
+            }
+            if (do_sell) {
+                double exec = p * (1.0 - prm->slippage);
+                double rev = shares * exec;
+                double fee = RMAX(rev * prm->commission_rate, prm->min_commission);
+                double net = rev - fee;
+                double gain = net - e_outlay;
+                if (trades < max_trades && entry_day) {
+                    entry_day[trades] = (int32_t)e_day; exit_day[trades] = (int32_t)t;
+                    entry_price[trades] = e_price; exit_price[trades] = exec; quantity[trades] = shares;
+                    pnl[trades] = gain; pnl_pct[trades] = gain / e_outlay * 100.0; reason[trades] = do_sell;
+                }
+                trades += 1;
+                if (gain > 0.0) wins += 1;
+                cash = cash + net - debt;
+                debt = 0.0;
+                shares = 0.0;
+            } else if (buy[t] && shares == 0.0) {
+                double exec = p * (1.0 + prm->slippage);
+                double power = cash * prm->position_size * prm->leverage;
+                double lots = floor(power / (exec * 100.0));
+                double cost = 0.0, fee = 0.0;
+                while (lots > 0.0) {
+                    cost = lots * 100.0 * exec;
+                    fee = RMAX(cost * prm->commission_rate, prm->min_commission);
+                    if (cost + fee <= cash * prm->leverage) break;
+                    lots -= 1.0;
+                }
+                if (lots > 0.0) {
+                    double outlay = cost + fee;
+                    debt = RMAX(outlay - cash, 0.0);
+                    cash = RMAX(cash - outlay, 0.0);
+                    shares = lots * 100.0;
+                    e_outlay = outlay; e_price = exec; e_day = t;
+                }
+            }
+        }
+        double sv = shares * last_px;
+        cash_net[t] = cash - debt;
+        stock_value[t] = sv;
+        total_value[t] = (cash - debt) + sv;
+    }
+    if (trade_count) *trade_count = (int32_t)trades;
+    if (summary) pqo_summary(total_value, benchmark, n, benchmark ? n : 0, prm->initial_capital, trades, wins, summary);
+}
+
+/* README.md:455-477 get_performance_metrics over all symbols.  total_value: [n_sym][n] row-major.  out: [n][10] =
+ * portfolio_value, daily_pnl, daily_return_pct, cumulative_pnl, cumulative_return_pct, benchmark_return_pct, alpha_pct,
+ * relative_return_pct, beta, 0 (columns 5-8 are 0 without a benchmark).  Sums run over symbols in ascending order;
+ * beta = sample covariance / sample variance (dof max(n-1, 1)) of the daily percentage returns, one value for all rows. */
+void pqo_portfolio_metrics(const double *total_value, int64_t n_sym, int64_t n, int64_t stride, double initial_total,
+                           const double *benchmark, double *out) {
+    double prev = initial_total;
+    for (int64_t t = 0; t < n; t++) {
+        double pv = 0.0;
+        for (int64_t s = 0; s < n_sym; s++) pv += total_value[s * stride + t];
+        double *o = out + t * 10;
+        o[0] = pv;
+        o[1] = pv - prev;
+        o[2] = (prev > 0.0) ? (pv - prev) / prev * 100.0 : 0.0;
+        o[3] = pv - initial_total;
+        o[4] = (initial_total > 0.0) ? (pv - initial_total) / initial_total * 100.0 : 0.0;
+        o[5] = o[6] = o[7] = o[8] = o[9] = 0.0;
+        if (benchmark) {
+            double pb = t > 0 ? benchmark[t - 1] : benchmark[0];
+            o[5] = (t > 0 && pb > 0.0) ? (benchmark[t] - pb) / pb * 100.0 : 0.0;
+            o[6] = o[2] - o[5];
+            o[7] = o[4] - ((benchmark[0] > 0.0) ? (benchmark[t] - benchmark[0]) / benchmark[0] * 100.0 : 0.0);
+        }
+        prev = pv;
+    }
+    if (benchmark && n > 0) {
+        double sr = 0.0, sb = 0.0;
+        for (int64_t t = 0; t < n; t++) { sr += out[t * 10 + 2]; sb += out[t * 10 + 5]; }
+        double mr = sr / (double)n, mb = sb / (double)n, cv = 0.0, bv = 0.0;
+        for (int64_t t = 0; t < n; t++) {
+            double dr = out[t * 10 + 2] - mr, db = out[t * 10 + 5] - mb;
+            cv += dr * db; bv += db * db;
+        }
+        double dof = RMAX((double)n - 1.0, 1.0);
+        cv /= dof; bv /= dof;
+        double beta = (bv > 0.0) ? cv / bv : 0.0;
+        for (int64_t t = 0; t < n; t++) out[t * 10 + 8] = beta;
+    }
+}
+
 /* SURVEY.md 8(d) generator: splitmix64-driven, transcendental-free, bit-reproducible. */
 static uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -143,6 +143,19 @@ void pqo_summary(const double *equity, const double *benchmark, int64_t n, int64
 void pqo_macd_cross_signals(const double *close, int64_t n, int64_t fast, int64_t slow,
                             int64_t sig, uint8_t *buy, uint8_t *sell);
 
+/* ---- README multi-symbol Backtest with leverage (decision D-10, see backtest.c) ---- */
+typedef struct {
+    double initial_capital, position_size, leverage, margin_call_threshold, interest_rate, commission_rate,
+        min_commission, slippage;
+} pqo_lev_params;
+void pqo_backtest_leveraged(const double *price, const uint8_t *buy, const uint8_t *sell, const double *benchmark,
+                            int64_t n, const pqo_lev_params *prm, double *cash_net, double *stock_value,
+                            double *total_value, int32_t max_trades, int32_t *trade_count, int32_t *entry_day,
+                            int32_t *exit_day, double *entry_price, double *exit_price, double *quantity, double *pnl,
+                            double *pnl_pct, int32_t *reason, double *summary);
+void pqo_portfolio_metrics(const double *total_value, int64_t n_sym, int64_t n, int64_t stride, double initial_total,
+                           const double *benchmark, double *out /* [n][10] */);
+
 /* ---- synthetic OHLCV generator ---- */
 void pqo_gen_ohlcv(uint64_t seed, int64_t n_sym, int64_t T, int mode /*0 plain,1 pattern-rich*/,
                    double *open, double *high, double *low, double *close, double *volume);

@@ -217,6 +217,50 @@ def backtest(price, buy, sell, benchmark=None, **kw):
     return pos, cash, eq, summ
 
 
+class LevParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("initial_capital", "position_size", "leverage", "margin_call_threshold",
+                                          "interest_rate", "commission_rate", "min_commission", "slippage")]
+
+
+LEV_DEFAULTS = dict(initial_capital=100000.0, position_size=1.0, leverage=1.0, margin_call_threshold=0.3,
+                    interest_rate=0.06, commission_rate=0.0003, min_commission=5.0, slippage=0.0)  # README.md:350-366
+TRADE_FIELDS = ("entry_day", "exit_day", "entry_price", "exit_price", "quantity", "pnl", "pnl_pct", "reason")
+
+
+def backtest_leveraged(price, buy, sell, benchmark=None, max_trades=64, **kw):
+    """D-10 (oracle/backtest.c).  price/buy/sell: [N, T]; benchmark: [T] or None.
+    -> dict(cash, stock_value, total_value [N,T]; trade_count [N]; trades {field: [N,max_trades]}; summary [N,8])"""
+    prm = LevParams(**{**LEV_DEFAULTS, **kw})
+    p2, _ = _as2d(price)
+    b2, _ = _as2d(buy, np.uint8)
+    s2, _ = _as2d(sell, np.uint8)
+    bm = np.ascontiguousarray(benchmark, dtype=np.float64) if benchmark is not None else None
+    N, T = p2.shape
+    cash, sv, tv = (np.empty((N, T)) for _ in range(3))
+    cnt = np.zeros(N, np.int32)
+    tr = {k: (np.zeros((N, max_trades), np.int32) if k in ("entry_day", "exit_day", "reason") else np.zeros((N, max_trades)))
+          for k in TRADE_FIELDS}
+    summ = np.zeros((N, 8))
+    fn = lib().pqo_backtest_leveraged
+    fn.restype = None
+    for s in range(N):
+        fn(_p(p2[s]), _p(b2[s]), _p(s2[s]), _p(bm) if bm is not None else None, C.c_int64(T), C.byref(prm),
+           _p(cash[s]), _p(sv[s]), _p(tv[s]), C.c_int32(max_trades), _p(cnt[s:s + 1]),
+           *[_p(tr[k][s]) for k in TRADE_FIELDS], _p(summ[s]))
+    return dict(cash=cash, stock_value=sv, total_value=tv, trade_count=cnt, trades=tr, summary=summ)
+
+
+def portfolio_metrics(total_value, initial_total, benchmark=None):
+    tv = np.ascontiguousarray(total_value, dtype=np.float64)
+    N, T = tv.shape
+    bm = np.ascontiguousarray(benchmark, dtype=np.float64) if benchmark is not None else None
+    out = np.zeros((T, 10))
+    fn = lib().pqo_portfolio_metrics
+    fn.restype = None
+    fn(_p(tv), C.c_int64(N), C.c_int64(T), C.c_int64(T), C.c_double(initial_total), _p(bm) if bm is not None else None, _p(out))
+    return out
+
+
 def summary(equity, benchmark, initial_capital, trades, wins):
     eq = np.ascontiguousarray(equity, dtype=np.float64)
     bm = np.ascontiguousarray(benchmark, dtype=np.float64) if benchmark is not None else None

@@ -7,7 +7,7 @@ All compute goes through libpolars_quant_hip.so (hand-written HIP kernels); ther
 from . import talib
 from ._lib import NullsNotAllowed, PqError
 from ._spec import PATTERN_NAMES, SPEC, SUMMARY_KEYS
-from .backtest import VectorizedBacktester
+from .backtest import Backtest, VectorizedBacktester
 from .talib import *  # noqa: F401,F403
 
 __version__ = "0.1.0"

@@ -36,6 +36,11 @@ class BtParams(C.Structure):
                                           "sell_commission_rate", "min_commission", "position_size")]
 
 
+class LevParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("initial_capital", "position_size", "leverage", "margin_call_threshold",
+                                          "interest_rate", "commission_rate", "min_commission", "slippage")]
+
+
 _lib = None
 
 
@@ -72,6 +77,10 @@ def lib() -> C.CDLL:
                                              C.POINTER(BtParams), vp, vp, vp, vp]
         L.pq_macd_cross_signals.restype = C.c_int32
         L.pq_macd_cross_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_int64, C.c_int64, C.c_int64, vp, vp]
+        L.pq_backtest_leveraged.restype = C.c_int32
+        L.pq_backtest_leveraged.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp, C.POINTER(LevParams), vp, vp, vp, C.c_int32] + [vp] * 10
+        L.pq_portfolio_metrics.restype = C.c_int32
+        L.pq_portfolio_metrics.argtypes = [vp, C.POINTER(Batch), vp, C.c_double, vp, vp]
         L.pq_ctx_create.argtypes = [C.c_int32, vp, C.POINTER(vp)]
         L.pq_ctx_destroy.argtypes = [vp]
         L.pq_ctx_set_stream.argtypes = [vp, vp]

@@ -115,3 +115,10 @@ SUMMARY_KEYS = ["annualized_return", "max_drawdown", "alpha", "beta", "sharpe_ra
                 "total_trades"]  # metrics.rs:142-149
 BT_DEFAULTS = dict(initial_capital=100000.0, buy_slippage=0.0, sell_slippage=0.0, buy_commission_rate=0.0003,
                    sell_commission_rate=0.0003, min_commission=5.0, position_size=1.0)  # vectorized.rs:38
+
+# README.md:350-366 `Backtest(...)` defaults (decision D-10)
+LEV_DEFAULTS = dict(initial_capital=100000.0, position_size=1.0, leverage=1.0, margin_call_threshold=0.3,
+                    interest_rate=0.06, commission_rate=0.0003, min_commission=5.0, slippage=0.0)
+TRADE_FIELDS = ("entry_day", "exit_day", "entry_price", "exit_price", "quantity", "pnl", "pnl_pct", "reason")
+PORTFOLIO_COLS = ("portfolio_value", "daily_pnl", "daily_return_pct", "cumulative_pnl", "cumulative_return_pct",
+                  "benchmark_return_pct", "alpha_pct", "relative_return_pct", "beta")

@@ -249,6 +249,57 @@ def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, wan
     return f(pos), f(cash), f(eq), f(summ)
 
 
+def backtest_leveraged(price, buy, sell, benchmark=None, max_trades: int = 64, **kw):
+    """README `Backtest` engine (decision D-10): price/buy/sell [N, T], benchmark [T] or None.
+    -> dict of device tensors: cash, stock_value, total_value [N,T]; trade_count [N]; trades {field: [N,max_trades]};
+    summary [N,8]"""
+    from ._lib import LevParams
+    from ._spec import LEV_DEFAULTS, TRADE_FIELDS
+    prm = LevParams(**{**LEV_DEFAULTS, **kw})
+    p, _, _ = _to_device(price)
+    bu, _, _ = _to_device(buy, torch.uint8)
+    se, _, _ = _to_device(sell, torch.uint8)
+    p = p.contiguous(); bu = bu.contiguous(); se = se.contiguous()
+    dev = p.device
+    n, T = p.shape
+    bm = None
+    if benchmark is not None:
+        bm = _to_device(benchmark)[0].contiguous().reshape(-1)
+        if bm.numel() != T:
+            raise ValueError("benchmark must be one series with as many rows as the prices")
+    b = Batch(n, T, T)
+    mk = lambda: torch.empty((n, T), dtype=torch.float64, device=dev)
+    cash, sv, tv = mk(), mk(), mk()
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    tr = {k: torch.zeros((n, max_trades), dtype=torch.int32 if k in ("entry_day", "exit_day", "reason") else torch.float64, device=dev)
+          for k in TRADE_FIELDS}
+    summ = torch.empty((n, 8), dtype=torch.float64, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+    if n * T:
+        with torch.cuda.device(dev):
+            check(lib().pq_backtest_leveraged(ctx(dev.index), C.byref(b), vp(p), vp(bu), vp(se), vp(bm), C.byref(prm), vp(cash), vp(sv),
+                                              vp(tv), max_trades, vp(cnt),
+                                              *[vp(tr[k]) if max_trades > 0 else None for k in ("entry_day", "exit_day", "entry_price", "exit_price",
+                                                                          "quantity", "pnl", "pnl_pct", "reason")], vp(summ)))
+    return dict(cash=cash, stock_value=sv, total_value=tv, trade_count=cnt, trades=tr, summary=summ)
+
+
+def portfolio_metrics(total_value, initial_total: float, benchmark=None):
+    """get_performance_metrics: total_value [N, T] -> [T, 10] device tensor (columns: _spec.PORTFOLIO_COLS + reserved)"""
+    tv, _, _ = _to_device(total_value)
+    tv = tv.contiguous()
+    dev = tv.device
+    n, T = tv.shape
+    bm = _to_device(benchmark)[0].contiguous().reshape(-1) if benchmark is not None else None
+    out = torch.zeros((T, 10), dtype=torch.float64, device=dev)
+    b = Batch(n, T, T)
+    if n * T:
+        with torch.cuda.device(dev):
+            check(lib().pq_portfolio_metrics(ctx(dev.index), C.byref(b), C.c_void_p(tv.data_ptr()), float(initial_total),
+                                             C.c_void_p(bm.data_ptr()) if bm is not None else None, C.c_void_p(out.data_ptr())))
+    return out
+
+
 def macd_cross_signals(close, fastperiod=12, slowperiod=26, signalperiod=9):
     p, kind, squeeze = _to_device(close)
     p = p.contiguous()

@@ -69,4 +69,41 @@ pq_status pq_macd_cross_signals(pq_ctx *ctx, const pq_batch *b, const double *cl
     return bt_launch<true, true>(ctx, b, a);
 }
 
+pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *price, const uint8_t *buy, const uint8_t *sell,
+                                const double *benchmark, const pq_lev_params *params, double *cash_net,
+                                double *stock_value, double *total_value, int32_t max_trades, int32_t *trade_count,
+                                int32_t *entry_day, int32_t *exit_day, double *entry_price, double *exit_price,
+                                double *quantity, double *pnl, double *pnl_pct, int32_t *reason, double *summary) {
+    PQ_TRY(pq_check(ctx, b));
+    PQ_REQUIRE(price && buy && sell && params && cash_net && stock_value && total_value, "pq_backtest_leveraged: null pointer");
+    const int nrec = (entry_day != nullptr) + (exit_day != nullptr) + (entry_price != nullptr) + (exit_price != nullptr) +
+                     (quantity != nullptr) + (pnl != nullptr) + (pnl_pct != nullptr) + (reason != nullptr);
+    PQ_REQUIRE(nrec == 0 || nrec == 8, "pq_backtest_leveraged: pass all eight trade-record arrays or none");
+    PQ_REQUIRE(max_trades >= 0, "pq_backtest_leveraged: max_trades < 0");
+    if (ctx->rec) { pq_set_error("pq_backtest_leveraged cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
+    if (b->n_series == 0) return PQ_OK;
+    LevArgs a{};
+    a.price = price; a.buy = buy; a.sell = sell; a.bench = benchmark;
+    a.cash_net = cash_net; a.stock_value = stock_value; a.total_value = total_value;
+    a.max_trades = max_trades; a.trade_count = trade_count; a.entry_day = entry_day; a.exit_day = exit_day; a.reason = reason;
+    a.entry_price = entry_price; a.exit_price = exit_price; a.quantity = quantity; a.pnl = pnl; a.pnl_pct = pnl_pct;
+    a.summary = summary; a.prm = *params;
+    dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
+    hipLaunchKernelGGL(lev_backtest_kernel, grid, dim3(SEQ_BLOCK), 0, ctx->stream, a, dims_of(b));
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+
+pq_status pq_portfolio_metrics(pq_ctx *ctx, const pq_batch *b, const double *total_value, double initial_total,
+                               const double *benchmark, double *out) {
+    PQ_TRY(pq_check(ctx, b));
+    PQ_REQUIRE(total_value && out, "pq_portfolio_metrics: null pointer");
+    if (ctx->rec) { pq_set_error("pq_portfolio_metrics cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
+    if (b->len == 0) return PQ_OK;
+    hipLaunchKernelGGL(portfolio_sum_kernel, dim3((unsigned)((b->len + 255) / 256)), dim3(256), 0, ctx->stream, total_value, dims_of(b), out);
+    hipLaunchKernelGGL(portfolio_metrics_kernel, dim3(1), dim3(256), 0, ctx->stream, b->len, initial_total, benchmark, out);
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+
 } // extern "C"

@@ -245,6 +245,194 @@ struct BtMacdOp {
     }
 };
 
+// calculate_summary (metrics.rs:7-152) from a stored equity row; `bench`: this lane's benchmark rows or nullptr.
+__device__ __forceinline__ void bt_summary_from_row(const double *eqr, int64_t T, double initial_capital, int64_t trades,
+                                                    int64_t wins, const double *bm, double *sm) {
+    if (T == 0) { for (int k = 0; k < 8; k++) sm[k] = 0.0; return; }
+    const double DAYS = 252.0, RF = 0.03;
+    double max_dd = 0.0, max_eq = initial_capital, pe = initial_capital, ret_sum = 0.0;
+    for (int64_t i = 0; i < T; i++) { // metrics.rs:26-49
+        double e = eqr[i];
+        if (e > max_eq) max_eq = e;
+        double dd = (max_eq > 0.0) ? (max_eq - e) / max_eq : 0.0;
+        if (dd > max_dd) max_dd = dd;
+        ret_sum += (pe > 0.0) ? (e - pe) / pe : 0.0;
+        pe = e;
+    }
+    const double last_eq = eqr[T - 1];
+    double total_return = (last_eq - initial_capital) / initial_capital;
+    double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
+    double mean = ret_sum / (double)T;
+    double dof = fmax((double)T - 1.0, 1.0);
+    double vs = 0.0;
+    pe = initial_capital;
+    for (int64_t i = 0; i < T; i++) {
+        double e = eqr[i];
+        double r = (pe > 0.0) ? (e - pe) / pe : 0.0;
+        double dlt = r - mean;
+        vs += dlt * dlt;
+        pe = e;
+    }
+    double var = vs / dof;
+    double vol = sqrt(var) * sqrt(DAYS);
+    double sharpe = (vol > 0.0) ? (ann - RF) / vol : 0.0;
+    double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
+    double alpha = 0.0, beta = 0.0;
+    if (bm) { // metrics.rs:86-140
+        double pb = bm[0], bs = 0.0;
+        for (int64_t i = 0; i < T; i++) { double bv = bm[i]; bs += (pb > 0.0) ? (bv - pb) / pb : 0.0; pb = bv; }
+        double bmean = bs / (double)T;
+        double bvar = 0.0, cov = 0.0;
+        pb = bm[0];
+        for (int64_t i = 0; i < T; i++) {
+            double bv = bm[i];
+            double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
+            double dlt = br - bmean;
+            bvar += dlt * dlt;
+            pb = bv;
+        }
+        bvar /= dof;
+        pb = bm[0]; pe = initial_capital;
+        for (int64_t i = 0; i < T; i++) {
+            double bv = bm[i], e = eqr[i];
+            double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
+            double r = (pe > 0.0) ? (e - pe) / pe : 0.0;
+            cov += (r - mean) * (br - bmean);
+            pb = bv; pe = e;
+        }
+        cov /= dof;
+        if (bvar > 0.0) beta = cov / bvar;
+        double b0 = bm[0], b1 = bm[T - 1];
+        double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;
+        double bann = (btr > -1.0) ? pow(1.0 + btr, DAYS / (double)T) - 1.0 : -1.0;
+        alpha = ann - (RF + beta * (bann - RF));
+    }
+    sm[0] = ann; sm[1] = max_dd; sm[2] = alpha; sm[3] = beta; sm[4] = sharpe;
+    sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
+}
+
+// SURVEY 8(f) rank 1 / decision D-10 (oracle/backtest.c pqo_backtest_leveraged): leveraged per-symbol pool.
+struct LevArgs {
+    const double *price;
+    const uint8_t *buy, *sell;
+    const double *bench; // one shared series or nullptr
+    double *cash_net, *stock_value, *total_value;
+    int32_t max_trades;
+    int32_t *trade_count, *entry_day, *exit_day, *reason; // nullable (records) ; trade_count nullable
+    double *entry_price, *exit_price, *quantity, *pnl, *pnl_pct;
+    double *summary;
+    pq_lev_params prm;
+};
+static __global__ __launch_bounds__(SEQ_BLOCK) void lev_backtest_kernel(LevArgs a, Dims d) {
+    const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (s >= d.n) return;
+    const int64_t base = s * d.stride, T = d.len;
+    const pq_lev_params prm = a.prm;
+    double cash = prm.initial_capital, debt = 0.0, shares = 0.0, last_px = 0.0, e_outlay = 0.0, e_price = 0.0;
+    int64_t e_day = 0, trades = 0, wins = 0;
+    const int64_t rb = s * (int64_t)a.max_trades;
+    for (int64_t t = 0; t < T; t++) {
+        double p = a.price[base + t];
+        if (pq_isnull(p)) p = __longlong_as_double(0x7FF8000000000000LL);
+        const bool valid = !(isnan(p) || p <= 0.0);
+        if (debt > 0.0) debt += debt * prm.interest_rate / 252.0;
+        if (valid) {
+            last_px = p;
+            int do_sell = 0;
+            if (shares > 0.0) {
+                if (debt > 0.0 && cash + shares * p - debt < prm.margin_call_threshold * (shares * p)) do_sell = 2;
+                else if (a.sell[base + t]) do_sell = 1;
+            }
+            if (do_sell) {
+                double exec = p * (1.0 - prm.slippage);
+                double rev = shares * exec;
+                double fee = fmax(rev * prm.commission_rate, prm.min_commission);
+                double net = rev - fee;
+                double gain = net - e_outlay;
+                if (trades < a.max_trades && a.entry_day) {
+                    a.entry_day[rb + trades] = (int32_t)e_day; a.exit_day[rb + trades] = (int32_t)t;
+                    a.entry_price[rb + trades] = e_price; a.exit_price[rb + trades] = exec; a.quantity[rb + trades] = shares;
+                    a.pnl[rb + trades] = gain; a.pnl_pct[rb + trades] = gain / e_outlay * 100.0; a.reason[rb + trades] = do_sell;
+                }
+                trades += 1;
+                if (gain > 0.0) wins += 1;
+                cash = cash + net - debt;
+                debt = 0.0;
+                shares = 0.0;
+            } else if (a.buy[base + t] && shares == 0.0) {
+                double exec = p * (1.0 + prm.slippage);
+                double power = cash * prm.position_size * prm.leverage;
+                double lots = floor(power / (exec * 100.0));
+                double cost = 0.0, fee = 0.0;
+                while (lots > 0.0) {
+                    cost = lots * 100.0 * exec;
+                    fee = fmax(cost * prm.commission_rate, prm.min_commission);
+                    if (cost + fee <= cash * prm.leverage) break;
+                    lots -= 1.0;
+                }
+                if (lots > 0.0) {
+                    double outlay = cost + fee;
+                    debt = fmax(outlay - cash, 0.0);
+                    cash = fmax(cash - outlay, 0.0);
+                    shares = lots * 100.0;
+                    e_outlay = outlay; e_price = exec; e_day = t;
+                }
+            }
+        }
+        double sv = shares * last_px;
+        a.cash_net[base + t] = cash - debt;
+        a.stock_value[base + t] = sv;
+        a.total_value[base + t] = (cash - debt) + sv;
+    }
+    if (a.trade_count) a.trade_count[s] = (int32_t)trades;
+    if (a.summary) bt_summary_from_row(a.total_value + base, T, prm.initial_capital, trades, wins, a.bench, a.summary + s * PQ_SUMMARY_COLS);
+}
+
+// get_performance_metrics: per-day sum over the symbols (ascending, one day per thread: coalesced across days), then the
+// day-to-day columns; beta needs ordered sums over the days and is done by one thread (T is a few thousand).
+static __global__ __launch_bounds__(256) void portfolio_sum_kernel(const double *tv, Dims d, double *out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.len) return;
+    double pv = 0.0;
+    for (int64_t s = 0; s < d.n; s++) pv += tv[s * d.stride + t];
+    out[t * PQ_PORTFOLIO_COLS] = pv;
+}
+static __global__ __launch_bounds__(256) void portfolio_metrics_kernel(int64_t T, double initial_total, const double *bm, double *out) {
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        double *o = out + t * PQ_PORTFOLIO_COLS;
+        const double pv = o[0], prev = t > 0 ? out[(t - 1) * PQ_PORTFOLIO_COLS] : initial_total;
+        o[1] = pv - prev;
+        o[2] = (prev > 0.0) ? (pv - prev) / prev * 100.0 : 0.0;
+        o[3] = pv - initial_total;
+        o[4] = (initial_total > 0.0) ? (pv - initial_total) / initial_total * 100.0 : 0.0;
+        o[5] = o[6] = o[7] = o[8] = o[9] = 0.0;
+        if (bm) {
+            double pb = t > 0 ? bm[t - 1] : bm[0];
+            o[5] = (t > 0 && pb > 0.0) ? (bm[t] - pb) / pb * 100.0 : 0.0;
+            o[6] = o[2] - o[5];
+            o[7] = o[4] - ((bm[0] > 0.0) ? (bm[t] - bm[0]) / bm[0] * 100.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    if (bm && T > 0) {
+        __shared__ double beta_s;
+        if (threadIdx.x == 0) {
+            double sr = 0.0, sb = 0.0;
+            for (int64_t t = 0; t < T; t++) { sr += out[t * PQ_PORTFOLIO_COLS + 2]; sb += out[t * PQ_PORTFOLIO_COLS + 5]; }
+            double mr = sr / (double)T, mb = sb / (double)T, cv = 0.0, bv = 0.0;
+            for (int64_t t = 0; t < T; t++) {
+                double dr = out[t * PQ_PORTFOLIO_COLS + 2] - mr, db = out[t * PQ_PORTFOLIO_COLS + 5] - mb;
+                cv += dr * db; bv += db * db;
+            }
+            double dof = fmax((double)T - 1.0, 1.0);
+            cv /= dof; bv /= dof;
+            beta_s = (bv > 0.0) ? cv / bv : 0.0;
+        }
+        __syncthreads();
+        for (int64_t t = threadIdx.x; t < T; t += 256) out[t * PQ_PORTFOLIO_COLS + 8] = beta_s;
+    }
+}
+
 template <bool MACD_SIGNALS, bool SIGNALS_ONLY>
 __global__ __launch_bounds__(SEQ_BLOCK) void backtest_kernel(BtArgs a, Dims d) {
     const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;

@@ -271,6 +271,63 @@ def test_backtest_macd_cross_fused(pq, oracle, data):
     assert (bits(s2.cpu().numpy()) == bits(s)).all()
 
 
+def test_backtest_leveraged_matches_oracle(pq, oracle, data):
+    """SURVEY 8(f) rank 1 (decision D-10): leveraged multi-symbol engine, bit-exact against the oracle."""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(11)
+    price = data["close"].copy()
+    price[2, 40] = np.nan
+    price[5, 70:75] = oracle.NULL
+    price[6, 90] = -3.0
+    buy = (rng.random(price.shape) < 0.04).astype(np.uint8)
+    sell = (rng.random(price.shape) < 0.04).astype(np.uint8)
+    bench = data["open"][0].copy()
+    for kw in (dict(), dict(leverage=3.0, slippage=0.002, interest_rate=0.5, margin_call_threshold=0.6),
+               dict(leverage=2.0, position_size=0.5, min_commission=50.0, initial_capital=5000.0)):
+        e = oracle.backtest_leveraged(np.where(np.isnan(price), np.nan, price), buy, sell, benchmark=bench, max_trades=16, **kw)
+        g = api.backtest_leveraged(torch.from_numpy(price).cuda(), torch.from_numpy(buy).cuda(), torch.from_numpy(sell).cuda(),
+                                   benchmark=torch.from_numpy(bench).cuda(), max_trades=16, **kw)
+        for k in ("cash", "stock_value", "total_value"):
+            assert (bits(g[k].cpu().numpy()) == bits(e[k])).all(), k
+        assert (g["trade_count"].cpu().numpy() == e["trade_count"]).all() and e["trade_count"].sum() > 0
+        for k, v in e["trades"].items():
+            gv = g["trades"][k].cpu().numpy()
+            assert (gv == v).all() if v.dtype == np.int32 else (bits(gv) == bits(v)).all(), k
+        s, es = g["summary"].cpu().numpy(), e["summary"]
+        for k in (1, 5, 6, 7):
+            assert (bits(s[:, k]) == bits(es[:, k])).all(), pq.SUMMARY_KEYS[k]
+        np.testing.assert_allclose(s, es, rtol=1e-12, atol=1e-13)
+        init_total = kw.get("initial_capital", 100000.0) * price.shape[0]
+        em = oracle.portfolio_metrics(e["total_value"], init_total, bench)
+        gm = api.portfolio_metrics(g["total_value"], init_total, torch.from_numpy(bench).cuda()).cpu().numpy()
+        assert (bits(gm) == bits(em)).all()
+    if any(kw.get("leverage", 1.0) > 1.0 for kw in (dict(leverage=3.0),)):
+        e = oracle.backtest_leveraged(price, buy, sell, leverage=3.0, interest_rate=0.5, margin_call_threshold=0.6, max_trades=16)
+        assert (e["trades"]["reason"] == 2).any(), "the margin-call path must be exercised"
+
+
+def test_backtest_class_tables(pq, oracle, data):
+    """README.md:416-477 table shapes of the `Backtest` class."""
+    close = data["close"][:3, :200]
+    ebuy, esell = oracle.macd_cross_signals(close)
+    dates = [f"d{t:03d}" for t in range(close.shape[1])]
+    syms = ["AAA", "BBB", "CCC"]
+    wide = lambda a: {"date": dates, **{s: a[i] for i, s in enumerate(syms)}}
+    bt = pq.Backtest(wide(close), wide(ebuy), wide(esell), leverage=2.0, benchmark={"date": dates, "IDX": data["open"][0, :200]})
+    bt.run()
+    daily = bt.get_daily_records()
+    assert len(daily["symbol"]) == 3 * 200 and set(daily) == {"symbol", "date", "cash", "stock_value", "total_value"}
+    e = oracle.backtest_leveraged(close, ebuy, esell, benchmark=data["open"][0, :200], leverage=2.0)
+    assert (bits(np.asarray(daily["total_value"])) == bits(e["total_value"].reshape(-1))).all()
+    pos = bt.get_position_records()
+    assert len(pos["symbol"]) == int(e["trade_count"].sum()) and (np.asarray(pos["holding_days"]) > 0).all()
+    one = bt.get_stock_positions("BBB")
+    assert len(one["symbol"]) == int(e["trade_count"][1])
+    perf = bt.get_performance_metrics()
+    assert list(perf)[:3] == ["date", "portfolio_value", "daily_pnl"] and "beta" in perf
+    assert "sharpe_ratio" in bt.get_stock_summary("AAA")
+
+
 def test_numpy_and_arrow_roundtrip(pq, oracle, data):
     import pyarrow as pa
     x = data["close"][0].copy()

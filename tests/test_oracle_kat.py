@@ -296,6 +296,68 @@ def test_backtest_skips_bad_price_rows(oracle):
     assert math.isnan(eq[1]) and eq[2] == cash[2] + pos[2] * -1.0
 
 
+def test_leveraged_backtest_lots_and_fees(oracle):
+    # D-10 (oracle/backtest.c; README.md:346-366, :443): 100-share lots, the lot count shrinks until cost + fee fits
+    price = np.array([[10.0, 11.0, 12.0]])
+    buy = np.array([[1, 0, 0]], np.uint8)
+    sell = np.array([[0, 0, 1]], np.uint8)
+    r = oracle.backtest_leveraged(price, buy, sell)
+    cost = 99 * 100.0 * 10.0                       # 100 lots would need 100000 + 30 > 100000
+    outlay = cost + cost * 0.0003
+    assert r["stock_value"][0, 0] == 9900 * 10.0 and r["cash"][0, 0] == 100000.0 - outlay
+    assert r["total_value"][0, 1] == (100000.0 - outlay) + 9900 * 11.0
+    rev = 9900 * 12.0
+    net = rev - rev * 0.0003
+    assert r["total_value"][0, 2] == (100000.0 - outlay) + net and r["stock_value"][0, 2] == 0.0
+    t = r["trades"]
+    assert r["trade_count"][0] == 1 and t["entry_day"][0, 0] == 0 and t["exit_day"][0, 0] == 2 and t["reason"][0, 0] == 1
+    assert t["quantity"][0, 0] == 9900.0 and t["pnl"][0, 0] == net - outlay and t["pnl_pct"][0, 0] == (net - outlay) / outlay * 100.0
+    assert r["summary"][0, 7] == 1.0 and r["summary"][0, 6] == 1.0
+
+
+def test_leveraged_backtest_interest_and_margin_call(oracle):
+    # D-10 steps 1-2: the debt compounds daily at rate/252; equity below threshold * position value forces a sale
+    price = np.array([[10.0, 10.0, 6.0, 7.0]])
+    buy = np.array([[1, 0, 0, 0]], np.uint8)
+    sell = np.zeros((1, 4), np.uint8)
+    r = oracle.backtest_leveraged(price, buy, sell, leverage=2.0)
+    cost = 199 * 100.0 * 10.0                      # 200 lots: 200000 + 60 > 2 * 100000
+    outlay = cost + cost * 0.0003
+    debt = outlay - 100000.0
+    assert r["cash"][0, 0] == 0.0 - debt and r["stock_value"][0, 0] == 199000.0
+    debt += debt * 0.06 / 252.0
+    assert r["cash"][0, 1] == 0.0 - debt
+    debt += debt * 0.06 / 252.0
+    assert 0.0 + 19900 * 6.0 - debt < 0.3 * (19900 * 6.0)       # margin call on day 2
+    rev = 19900 * 6.0
+    net = rev - rev * 0.0003
+    assert r["total_value"][0, 2] == (0.0 + net - debt) and r["stock_value"][0, 2] == 0.0
+    assert r["trades"]["reason"][0, 0] == 2 and r["trades"]["pnl"][0, 0] == net - outlay
+    assert r["total_value"][0, 3] == r["total_value"][0, 2]      # flat afterwards, no interest without debt
+
+
+def test_leveraged_backtest_invalid_prices_and_portfolio(oracle):
+    # D-10 step 0: no trading on a null / non-positive price, valuation at the last valid price
+    price = np.array([[10.0, np.nan, -1.0, 12.0], [20.0, 21.0, 22.0, 23.0]])
+    buy = np.array([[1, 1, 1, 0], [0, 0, 0, 0]], np.uint8)
+    sell = np.array([[0, 1, 1, 0], [0, 0, 0, 0]], np.uint8)
+    r = oracle.backtest_leveraged(price, buy, sell)
+    assert list(r["stock_value"][0]) == [99000.0, 99000.0, 99000.0, 9900 * 12.0]
+    assert list(r["total_value"][1]) == [100000.0] * 4 and r["trade_count"][1] == 0
+    bench = np.array([100.0, 101.0, 99.0, 102.0])
+    m = oracle.portfolio_metrics(r["total_value"], 200000.0, bench)
+    pv = r["total_value"][0] + r["total_value"][1]
+    assert list(m[:, 0]) == list(pv)
+    assert m[0, 1] == pv[0] - 200000.0 and m[2, 2] == (pv[2] - pv[1]) / pv[1] * 100.0
+    assert m[3, 3] == pv[3] - 200000.0 and m[3, 4] == (pv[3] - 200000.0) / 200000.0 * 100.0
+    assert m[0, 5] == 0.0 and m[2, 5] == (99.0 - 101.0) / 101.0 * 100.0 and m[2, 6] == m[2, 2] - m[2, 5]
+    assert m[3, 7] == m[3, 4] - (102.0 - 100.0) / 100.0 * 100.0
+    rr, br = m[:, 2], m[:, 5]
+    cov = sum((rr - sum(rr) / 4) * (br - sum(br) / 4)) / 3.0
+    var = sum((br - sum(br) / 4) ** 2) / 3.0
+    assert m[0, 8] == pytest.approx(cov / var, rel=1e-12) and (m[:, 8] == m[0, 8]).all()
+
+
 def test_summary_small(oracle):
     # metrics.rs:7-152 on [100k, 101k, 99k]
     eq = np.array([100000.0, 101000.0, 99000.0])
