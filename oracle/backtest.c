@@ -127,7 +127,7 @@ void pqo_macd_cross_signals(const double *close, int64_t n, int64_t fast, int64_
  *
  * D-10, per symbol with its own capital pool (README.md:17,405), day t with price p:
  *   0. p null / NaN / <= 0: no trading; the position is valued at the last valid price (0 before the first).
- *   1. interest: debt += debt * interest_rate / 252                      (financing cost compounds daily)
+ *   1. interest: debt += debt * (interest_rate / 252)                    (financing cost compounds daily)
  *   2. margin call: holding with debt > 0 and  cash + shares*p - debt  <  margin_call_threshold * shares*p
  *      -> forced sale today (reason 2), same mechanics as a signalled sale
  *   3. else sell signal while holding -> sale (reason 1): exec = p*(1-slippage), fee = max(rev*rate, min_commission),
@@ -147,10 +147,11 @@ void pqo_backtest_leveraged(const double *price, const uint8_t *buy, const uint8
     double cash = prm->initial_capital, debt = 0.0, shares = 0.0, last_px = 0.0;
     double e_outlay = 0.0, e_price = 0.0;
     int64_t e_day = 0, trades = 0, wins = 0;
+    const double daily_rate = prm->interest_rate / 252.0;
     for (int64_t t = 0; t < n; t++) {
         double p = price[t];
         const int valid = !(isnan(p) || p <= 0.0);
-        if (debt > 0.0) debt += debt * prm->interest_rate / 252.0;
+        if (debt > 0.0) debt += debt * daily_rate;
         if (valid) {
             last_px = p;
             int do_sell = 0;

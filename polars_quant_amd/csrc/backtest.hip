@@ -88,6 +88,11 @@ pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *pr
     a.max_trades = max_trades; a.trade_count = trade_count; a.entry_day = entry_day; a.exit_day = exit_day; a.reason = reason;
     a.entry_price = entry_price; a.exit_price = exit_price; a.quantity = quantity; a.pnl = pnl; a.pnl_pct = pnl_pct;
     a.summary = summary; a.prm = *params;
+    if (b->stride % 8 == 0 && reinterpret_cast<uintptr_t>(buy) % 8 == 0 && reinterpret_cast<uintptr_t>(sell) % 8 == 0) {
+        LevOp op{};                        // tiled path: coalesced column traffic
+        op.a = a; op.stride = b->stride;
+        return launch_seq(ctx, b, op, InCols<1>{{price}}, OutCols<3>{{cash_net, stock_value, total_value}});
+    }
     dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
     hipLaunchKernelGGL(lev_backtest_kernel, grid, dim3(SEQ_BLOCK), 0, ctx->stream, a, dims_of(b));
     PQ_HIP_TRY(hipGetLastError());
@@ -100,7 +105,7 @@ pq_status pq_portfolio_metrics(pq_ctx *ctx, const pq_batch *b, const double *tot
     PQ_REQUIRE(total_value && out, "pq_portfolio_metrics: null pointer");
     if (ctx->rec) { pq_set_error("pq_portfolio_metrics cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
     if (b->len == 0) return PQ_OK;
-    hipLaunchKernelGGL(portfolio_sum_kernel, dim3((unsigned)((b->len + 255) / 256)), dim3(256), 0, ctx->stream, total_value, dims_of(b), out);
+    hipLaunchKernelGGL(portfolio_sum_kernel, dim3((unsigned)((b->len + 63) / 64)), dim3(64), 0, ctx->stream, total_value, dims_of(b), out);
     hipLaunchKernelGGL(portfolio_metrics_kernel, dim3(1), dim3(256), 0, ctx->stream, b->len, initial_total, benchmark, out);
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;

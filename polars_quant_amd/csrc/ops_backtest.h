@@ -335,7 +335,7 @@ static __global__ __launch_bounds__(SEQ_BLOCK) void lev_backtest_kernel(LevArgs 
         double p = a.price[base + t];
         if (pq_isnull(p)) p = __longlong_as_double(0x7FF8000000000000LL);
         const bool valid = !(isnan(p) || p <= 0.0);
-        if (debt > 0.0) debt += debt * prm.interest_rate / 252.0;
+        if (debt > 0.0) debt += debt * (prm.interest_rate / 252.0); // D-10 step 1: the daily rate is formed first
         if (valid) {
             last_px = p;
             int do_sell = 0;
@@ -388,13 +388,124 @@ static __global__ __launch_bounds__(SEQ_BLOCK) void lev_backtest_kernel(LevArgs 
     if (a.summary) bt_summary_from_row(a.total_value + base, T, prm.initial_capital, trades, wins, a.bench, a.summary + s * PQ_SUMMARY_COLS);
 }
 
+// The same engine as a tiled SEQ op: the price and the three daily columns move through the coalesced tile path; the
+// two uint8 signal columns are read by the lane itself, eight rows (one aligned 8-byte word each) at a time and one tile
+// ahead; trade records are rare events and go straight to global memory.  Requires stride % 8 == 0 and 8-byte aligned
+// signal columns (the launcher checks; otherwise lev_backtest_kernel above runs).
+struct LevOp {
+    static constexpr int NIN = 1, NOUT = 3;
+    static constexpr int TILE_K = 8;
+    LevArgs a;
+    int64_t stride; // elements between series (set by the launcher)
+    // per-lane state
+    const uint8_t *brow, *srow;
+    int64_t rec0, T;
+    unsigned long long bcur, scur, bnext, snext;
+    double cash, debt, shares, last_px, e_outlay, e_price;
+    int64_t e_day, trades, wins;
+    __device__ void init(const Row<1> &r) {
+        const int64_t off = r.in[0] - a.price; // element offset of this lane's series
+        brow = a.buy + off; srow = a.sell + off;
+        T = r.len;
+        rec0 = (off / stride) * (int64_t)a.max_trades; // this series' slice of the trade-record arrays
+        cash = a.prm.initial_capital; debt = 0.0; shares = 0.0; last_px = 0.0; e_outlay = 0.0; e_price = 0.0;
+        e_day = 0; trades = 0; wins = 0;
+        bcur = scur = 0;
+        bnext = T >= 8 ? *reinterpret_cast<const unsigned long long *>(brow) : 0;
+        snext = T >= 8 ? *reinterpret_cast<const unsigned long long *>(srow) : 0;
+    }
+    __device__ void step(const Row<1> &, int64_t t, const double (&x)[1], double (&y)[3]) {
+        const int j = (int)(t & 7);
+        if (j == 0) { // next eight rows of signals: use the words fetched a tile ago, fetch the following ones
+            if (t + 8 <= T) {
+                bcur = bnext; scur = snext;
+                if (t + 16 <= T) {
+                    bnext = *reinterpret_cast<const unsigned long long *>(brow + t + 8);
+                    snext = *reinterpret_cast<const unsigned long long *>(srow + t + 8);
+                }
+            } else { // ragged tail: byte loads
+                bcur = scur = 0;
+                for (int64_t q = t; q < T; q++) {
+                    bcur |= (unsigned long long)(brow[q] != 0) << (8 * (q - t));
+                    scur |= (unsigned long long)(srow[q] != 0) << (8 * (q - t));
+                }
+            }
+        }
+        const bool buy = ((bcur >> (8 * j)) & 0xff) != 0, sell = ((scur >> (8 * j)) & 0xff) != 0;
+        const pq_lev_params &prm = a.prm;
+        double p = x[0];
+        if (pq_isnull(p)) p = __longlong_as_double(0x7FF8000000000000LL);
+        const bool valid = !(isnan(p) || p <= 0.0);
+        if (debt > 0.0) debt += debt * (prm.interest_rate / 252.0); // D-10 step 1: the daily rate is formed first
+        if (valid) {
+            last_px = p;
+            int do_sell = 0;
+            if (shares > 0.0) {
+                if (debt > 0.0 && cash + shares * p - debt < prm.margin_call_threshold * (shares * p)) do_sell = 2;
+                else if (sell) do_sell = 1;
+            }
+            if (do_sell) {
+                double exec = p * (1.0 - prm.slippage);
+                double rev = shares * exec;
+                double fee = fmax(rev * prm.commission_rate, prm.min_commission);
+                double net = rev - fee;
+                double gain = net - e_outlay;
+                if (trades < a.max_trades && a.entry_day) {
+                    const int64_t rb = rec0 + trades;
+                    a.entry_day[rb] = (int32_t)e_day; a.exit_day[rb] = (int32_t)t;
+                    a.entry_price[rb] = e_price; a.exit_price[rb] = exec; a.quantity[rb] = shares;
+                    a.pnl[rb] = gain; a.pnl_pct[rb] = gain / e_outlay * 100.0; a.reason[rb] = do_sell;
+                }
+                trades += 1;
+                if (gain > 0.0) wins += 1;
+                cash = cash + net - debt;
+                debt = 0.0;
+                shares = 0.0;
+            } else if (buy && shares == 0.0) {
+                double exec = p * (1.0 + prm.slippage);
+                double power = cash * prm.position_size * prm.leverage;
+                double lots = floor(power / (exec * 100.0));
+                double cost = 0.0, fee = 0.0;
+                while (lots > 0.0) {
+                    cost = lots * 100.0 * exec;
+                    fee = fmax(cost * prm.commission_rate, prm.min_commission);
+                    if (cost + fee <= cash * prm.leverage) break;
+                    lots -= 1.0;
+                }
+                if (lots > 0.0) {
+                    double outlay = cost + fee;
+                    debt = fmax(outlay - cash, 0.0);
+                    cash = fmax(cash - outlay, 0.0);
+                    shares = lots * 100.0;
+                    e_outlay = outlay; e_price = exec; e_day = t;
+                }
+            }
+        }
+        const double sv = shares * last_px;
+        y[0] = cash - debt; y[1] = sv; y[2] = (cash - debt) + sv;
+    }
+    __host__ __device__ void *finish_writes() const { return a.summary; }
+    __device__ void finish(double *const *outp, const Dims &d, int64_t s) {
+        if (a.trade_count) a.trade_count[s] = (int32_t)trades;
+        if (a.summary) bt_summary_from_row(outp[2] + s * d.stride, d.len, a.prm.initial_capital, trades, wins, a.bench, a.summary + s * PQ_SUMMARY_COLS);
+    }
+};
+
 // get_performance_metrics: per-day sum over the symbols (ascending, one day per thread: coalesced across days), then the
 // day-to-day columns; beta needs ordered sums over the days and is done by one thread (T is a few thousand).
-static __global__ __launch_bounds__(256) void portfolio_sum_kernel(const double *tv, Dims d, double *out) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+static __global__ __launch_bounds__(64) void portfolio_sum_kernel(const double *tv, Dims d, double *out) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= d.len) return;
     double pv = 0.0;
-    for (int64_t s = 0; s < d.n; s++) pv += tv[s * d.stride + t];
+    int64_t s = 0;
+    for (; s + 32 <= d.n; s += 32) { // 32 independent loads in flight, then the adds in ascending symbol order
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) v[k] = tv[(s + k) * d.stride + t];
+#pragma unroll
+        for (int k = 0; k < 32; k++) pv += v[k];
+    }
+    for (; s < d.n; s++) pv += tv[s * d.stride + t];
     out[t * PQ_PORTFOLIO_COLS] = pv;
 }
 static __global__ __launch_bounds__(256) void portfolio_metrics_kernel(int64_t T, double initial_total, const double *bm, double *out) {

@@ -325,9 +325,9 @@ def test_leveraged_backtest_interest_and_margin_call(oracle):
     outlay = cost + cost * 0.0003
     debt = outlay - 100000.0
     assert r["cash"][0, 0] == 0.0 - debt and r["stock_value"][0, 0] == 199000.0
-    debt += debt * 0.06 / 252.0
+    debt += debt * (0.06 / 252.0)
     assert r["cash"][0, 1] == 0.0 - debt
-    debt += debt * 0.06 / 252.0
+    debt += debt * (0.06 / 252.0)
     assert 0.0 + 19900 * 6.0 - debt < 0.3 * (19900 * 6.0)       # margin call on day 2
     rev = 19900 * 6.0
     net = rev - rev * 0.0003
