@@ -218,6 +218,18 @@ pq_status pq_backtest_macd_cross(pq_ctx *, const pq_batch *, const double *close
 pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close, int64_t fastperiod,
                                 int64_t slowperiod, int64_t signalperiod, uint8_t *buy, uint8_t *sell);
 
+/* ---- the README's `Strategy` signal rules (README.md:862-994; README-only, decision D-11 in
+ * oracle/backtest.c): indicator columns -> uint8 buy / sell columns for the backtests above.  Row-parallel.
+ *   cross:   buy = a[i-1] <= b[i-1] && a[i] > b[i];  sell mirrored            (MA / MACD / STOCH / trend strategies)
+ *   band:    buy = x[i-1] < lower && x[i] >= lower;  sell = x[i-1] > upper && x[i] <= upper      (RSI / CCI / STOCH)
+ *   channel: mode 0 reversion (BBANDS): buy = price crosses below `lo`, sell = crosses above `hi`;
+ *            mode 1 breakout (Donchian): buy = price[i] > hi[i-1], sell = price[i] < lo[i-1]
+ * a rule is false where any value it reads is null, and on row 0 */
+pq_status pq_cross_signals(pq_ctx *, const pq_batch *, const double *a, const double *b, uint8_t *buy, uint8_t *sell);
+pq_status pq_band_signals(pq_ctx *, const pq_batch *, const double *x, double lower, double upper, uint8_t *buy, uint8_t *sell);
+pq_status pq_channel_signals(pq_ctx *, const pq_batch *, const double *price, const double *lo, const double *hi, int32_t mode,
+                             uint8_t *buy, uint8_t *sell);
+
 /* ---- the README's multi-symbol `Backtest` (README.md:346-640; README-only, no source).
  * Semantics = decision D-10 (oracle/backtest.c): independent capital pool per symbol, 100-share lots, leverage
  * with daily compounding interest on the debt, margin call (forced sale), commission with a minimum, proportional

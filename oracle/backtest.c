@@ -244,6 +244,49 @@ void pqo_portfolio_metrics(const double *total_value, int64_t n_sym, int64_t n, 
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------------
+ * the README's `Strategy` signal generators (README.md:862-994; README-only => decision D-11).
+ * Three row-local rules turn indicator columns into the uint8 buy/sell columns of the backtests; a rule is false
+ * wherever one of the values it looks at is null (or, for rules using row i-1, on row 0):
+ *   cross(a, b):            buy  = a[i-1] <= b[i-1] && a[i] >  b[i]       (golden cross: MA, MACD, STOCH %K/%D, trend)
+ *                           sell = a[i-1] >= b[i-1] && a[i] <  b[i]
+ *   band(x, lower, upper):  buy  = x[i-1] <  lower  && x[i] >= lower      (leaves the oversold zone: RSI, CCI, STOCH)
+ *                           sell = x[i-1] >  upper  && x[i] <= upper      (leaves the overbought zone)
+ *   channel(p, lo, hi, mode 0 = reversion): buy = p[i] < lo[i] && p[i-1] >= lo[i-1]; sell = p[i] > hi[i] && p[i-1] <= hi[i-1]
+ *                           (mode 1 = breakout): buy = p[i] > hi[i-1];  sell = p[i] < lo[i-1]       (Donchian on prior bars) */
+void pqo_cross_signals(const double *a, const double *b, int64_t n, uint8_t *buy, uint8_t *sell) {
+    for (int64_t i = 0; i < n; i++) {
+        buy[i] = sell[i] = 0;
+        if (i == 0 || pqo_isnull(a[i]) || pqo_isnull(b[i]) || pqo_isnull(a[i - 1]) || pqo_isnull(b[i - 1])) continue;
+        buy[i] = (a[i - 1] <= b[i - 1]) && (a[i] > b[i]);
+        sell[i] = (a[i - 1] >= b[i - 1]) && (a[i] < b[i]);
+    }
+}
+void pqo_band_signals(const double *x, int64_t n, double lower, double upper, uint8_t *buy, uint8_t *sell) {
+    for (int64_t i = 0; i < n; i++) {
+        buy[i] = sell[i] = 0;
+        if (i == 0 || pqo_isnull(x[i]) || pqo_isnull(x[i - 1])) continue;
+        buy[i] = (x[i - 1] < lower) && (x[i] >= lower);
+        sell[i] = (x[i - 1] > upper) && (x[i] <= upper);
+    }
+}
+void pqo_channel_signals(const double *p, const double *lo, const double *hi, int64_t n, int mode, uint8_t *buy,
+                         uint8_t *sell) {
+    for (int64_t i = 0; i < n; i++) {
+        buy[i] = sell[i] = 0;
+        if (i == 0 || pqo_isnull(p[i])) continue;
+        if (mode == 0) {
+            if (pqo_isnull(p[i - 1]) || pqo_isnull(lo[i]) || pqo_isnull(hi[i]) || pqo_isnull(lo[i - 1]) || pqo_isnull(hi[i - 1])) continue;
+            buy[i] = (p[i] < lo[i]) && (p[i - 1] >= lo[i - 1]);
+            sell[i] = (p[i] > hi[i]) && (p[i - 1] <= hi[i - 1]);
+        } else {
+            if (pqo_isnull(lo[i - 1]) || pqo_isnull(hi[i - 1])) continue;
+            buy[i] = p[i] > hi[i - 1];
+            sell[i] = p[i] < lo[i - 1];
+        }
+    }
+}
+
 /* SURVEY.md 8(d) generator: splitmix64-driven, transcendental-free, bit-reproducible. */
 static uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -156,6 +156,11 @@ void pqo_backtest_leveraged(const double *price, const uint8_t *buy, const uint8
 void pqo_portfolio_metrics(const double *total_value, int64_t n_sym, int64_t n, int64_t stride, double initial_total,
                            const double *benchmark, double *out /* [n][10] */);
 
+/* ---- Strategy signal rules (decision D-11, see backtest.c) ---- */
+void pqo_cross_signals(const double *a, const double *b, int64_t n, uint8_t *buy, uint8_t *sell);
+void pqo_band_signals(const double *x, int64_t n, double lower, double upper, uint8_t *buy, uint8_t *sell);
+void pqo_channel_signals(const double *p, const double *lo, const double *hi, int64_t n, int mode, uint8_t *buy, uint8_t *sell);
+
 /* ---- synthetic OHLCV generator ---- */
 void pqo_gen_ohlcv(uint64_t seed, int64_t n_sym, int64_t T, int mode /*0 plain,1 pattern-rich*/,
                    double *open, double *high, double *low, double *close, double *volume);

@@ -261,6 +261,30 @@ def portfolio_metrics(total_value, initial_total, benchmark=None):
     return out
 
 
+def _signals(fn_name, cols, *scalars):
+    arrs = [_as2d(c)[0] for c in cols]
+    sq = np.asarray(cols[0]).ndim == 1
+    N, T = arrs[0].shape
+    buy, sell = np.zeros((N, T), np.uint8), np.zeros((N, T), np.uint8)
+    fn = getattr(lib(), fn_name)
+    fn.restype = None
+    for s in range(N):
+        fn(*[_p(a[s]) for a in arrs], C.c_int64(T), *scalars, _p(buy[s]), _p(sell[s]))
+    return (buy[0], sell[0]) if sq else (buy, sell)
+
+
+def cross_signals(a, b):
+    return _signals("pqo_cross_signals", [a, b])
+
+
+def band_signals(x, lower, upper):
+    return _signals("pqo_band_signals", [x], C.c_double(lower), C.c_double(upper))
+
+
+def channel_signals(p, lo, hi, mode):
+    return _signals("pqo_channel_signals", [p, lo, hi], C.c_int(mode))
+
+
 def summary(equity, benchmark, initial_capital, trades, wins):
     eq = np.ascontiguousarray(equity, dtype=np.float64)
     bm = np.ascontiguousarray(benchmark, dtype=np.float64) if benchmark is not None else None

@@ -8,6 +8,7 @@ from . import talib
 from ._lib import NullsNotAllowed, PqError
 from ._spec import PATTERN_NAMES, SPEC, SUMMARY_KEYS
 from .backtest import Backtest, VectorizedBacktester
+from .strategy import Strategy
 from .talib import *  # noqa: F401,F403
 
 __version__ = "0.1.0"

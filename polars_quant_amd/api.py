@@ -249,6 +249,38 @@ def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, wan
     return f(pos), f(cash), f(eq), f(summ)
 
 
+def _signal_call(fn_name, cols, *scalars):
+    ts = [_to_device(c)[0].contiguous() for c in cols]
+    dev = ts[0].device
+    n, T = ts[0].shape
+    for t in ts:
+        if t.shape != (n, T):
+            raise ValueError("signal rule inputs must have the same shape")
+    b = Batch(n, T, T)
+    buy = torch.zeros((n, T), dtype=torch.uint8, device=dev)
+    sell = torch.zeros((n, T), dtype=torch.uint8, device=dev)
+    if n * T:
+        with torch.cuda.device(dev):
+            check(getattr(lib(), fn_name)(ctx(dev.index), C.byref(b), *[C.c_void_p(t.data_ptr()) for t in ts], *scalars,
+                                          C.c_void_p(buy.data_ptr()), C.c_void_p(sell.data_ptr())))
+    return buy, sell
+
+
+def cross_signals(a, b):
+    """D-11: buy = a crosses above b, sell = a crosses below b -> (buy, sell) uint8 device tensors [N, T]"""
+    return _signal_call("pq_cross_signals", [a, b])
+
+
+def band_signals(x, lower: float, upper: float):
+    """D-11: buy = x comes back up through `lower`, sell = x comes back down through `upper`"""
+    return _signal_call("pq_band_signals", [x], float(lower), float(upper))
+
+
+def channel_signals(price, lo, hi, mode: int):
+    """D-11: mode 0 = reversion at the bands, mode 1 = breakout of the previous bar's channel"""
+    return _signal_call("pq_channel_signals", [price, lo, hi], int(mode))
+
+
 def backtest_leveraged(price, buy, sell, benchmark=None, max_trades: int = 64, **kw):
     """README `Backtest` engine (decision D-10): price/buy/sell [N, T], benchmark [T] or None.
     -> dict of device tensors: cash, stock_value, total_value [N,T]; trade_count [N]; trades {field: [N,max_trades]};

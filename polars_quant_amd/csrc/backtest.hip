@@ -69,6 +69,26 @@ pq_status pq_macd_cross_signals(pq_ctx *ctx, const pq_batch *b, const double *cl
     return bt_launch<true, true>(ctx, b, a);
 }
 
+pq_status pq_cross_signals(pq_ctx *ctx, const pq_batch *b, const double *a, const double *c, uint8_t *buy, uint8_t *sell) {
+    PQ_TRY(pq_check(ctx, b));
+    PQ_REQUIRE(a && c && buy && sell, "pq_cross_signals: null pointer");
+    return launch_row(ctx, b, CrossSigOp{}, InCols<2>{{a, c}}, OutColsT<CrossSigOp, uint8_t>{{buy, sell}});
+}
+pq_status pq_band_signals(pq_ctx *ctx, const pq_batch *b, const double *x, double lower, double upper, uint8_t *buy, uint8_t *sell) {
+    PQ_TRY(pq_check(ctx, b));
+    PQ_REQUIRE(x && buy && sell, "pq_band_signals: null pointer");
+    BandSigOp op{}; op.lower = lower; op.upper = upper;
+    return launch_row(ctx, b, op, InCols<1>{{x}}, OutColsT<BandSigOp, uint8_t>{{buy, sell}});
+}
+pq_status pq_channel_signals(pq_ctx *ctx, const pq_batch *b, const double *price, const double *lo, const double *hi, int32_t mode,
+                             uint8_t *buy, uint8_t *sell) {
+    PQ_TRY(pq_check(ctx, b));
+    PQ_REQUIRE(price && lo && hi && buy && sell, "pq_channel_signals: null pointer");
+    PQ_REQUIRE(mode == 0 || mode == 1, "pq_channel_signals: mode must be 0 (reversion) or 1 (breakout)");
+    if (mode == 0) return launch_row(ctx, b, ChannelSigOp<0>{}, InCols<3>{{price, lo, hi}}, OutColsT<ChannelSigOp<0>, uint8_t>{{buy, sell}});
+    return launch_row(ctx, b, ChannelSigOp<1>{}, InCols<3>{{price, lo, hi}}, OutColsT<ChannelSigOp<1>, uint8_t>{{buy, sell}});
+}
+
 pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *price, const uint8_t *buy, const uint8_t *sell,
                                 const double *benchmark, const pq_lev_params *params, double *cash_net,
                                 double *stock_value, double *total_value, int32_t max_trades, int32_t *trade_count,

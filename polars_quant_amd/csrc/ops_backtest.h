@@ -491,6 +491,49 @@ struct LevOp {
     }
 };
 
+// SURVEY 8(f) rank 2 / decision D-11 (oracle/backtest.c): Strategy signal rules, ROW shape, two uint8 columns out.
+__device__ __forceinline__ double sig_at(const double *col, int64_t i) { return i >= 0 ? col[i] : pq_null(); }
+struct CrossSigOp {
+    static constexpr int NIN = 2, NOUT = 2;
+    typedef uint8_t OutT;
+    __device__ void eval(const Row<2> &r, int64_t i, uint8_t (&y)[2]) {
+        const double a1 = r.in[0][i], b1 = r.in[1][i], a0 = sig_at(r.in[0], i - 1), b0 = sig_at(r.in[1], i - 1);
+        const bool ok = i > 0 && !pq_isnull(a1) && !pq_isnull(b1) && !pq_isnull(a0) && !pq_isnull(b0);
+        y[0] = ok && (a0 <= b0) && (a1 > b1);
+        y[1] = ok && (a0 >= b0) && (a1 < b1);
+    }
+};
+struct BandSigOp {
+    static constexpr int NIN = 1, NOUT = 2;
+    typedef uint8_t OutT;
+    double lower, upper;
+    __device__ void eval(const Row<1> &r, int64_t i, uint8_t (&y)[2]) {
+        const double x1 = r.in[0][i], x0 = sig_at(r.in[0], i - 1);
+        const bool ok = i > 0 && !pq_isnull(x1) && !pq_isnull(x0);
+        y[0] = ok && (x0 < lower) && (x1 >= lower);
+        y[1] = ok && (x0 > upper) && (x1 <= upper);
+    }
+};
+template <int MODE>
+struct ChannelSigOp {
+    static constexpr int NIN = 3, NOUT = 2; // price, lo, hi
+    typedef uint8_t OutT;
+    __device__ void eval(const Row<3> &r, int64_t i, uint8_t (&y)[2]) {
+        const double p1 = r.in[0][i], p0 = sig_at(r.in[0], i - 1);
+        const double lo0 = sig_at(r.in[1], i - 1), hi0 = sig_at(r.in[2], i - 1);
+        if (MODE == 0) {
+            const double lo1 = r.in[1][i], hi1 = r.in[2][i];
+            const bool ok = i > 0 && !pq_isnull(p1) && !pq_isnull(p0) && !pq_isnull(lo1) && !pq_isnull(hi1) && !pq_isnull(lo0) && !pq_isnull(hi0);
+            y[0] = ok && (p1 < lo1) && (p0 >= lo0);
+            y[1] = ok && (p1 > hi1) && (p0 <= hi0);
+        } else {
+            const bool ok = i > 0 && !pq_isnull(p1) && !pq_isnull(lo0) && !pq_isnull(hi0);
+            y[0] = ok && (p1 > hi0);
+            y[1] = ok && (p1 < lo0);
+        }
+    }
+};
+
 // get_performance_metrics: per-day sum over the symbols (ascending, one day per thread: coalesced across days), then the
 // day-to-day columns; beta needs ordered sums over the days and is done by one thread (T is a few thousand).
 static __global__ __launch_bounds__(64) void portfolio_sum_kernel(const double *tv, Dims d, double *out) {

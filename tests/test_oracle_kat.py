@@ -358,6 +358,24 @@ def test_leveraged_backtest_invalid_prices_and_portfolio(oracle):
     assert m[0, 8] == pytest.approx(cov / var, rel=1e-12) and (m[:, 8] == m[0, 8]).all()
 
 
+def test_signal_rules(oracle):
+    # D-11 (oracle/backtest.c): cross / band / channel rules, null-safe, row 0 never fires
+    a = np.array([1.0, 2.0, 3.0, 2.0, 1.0, oracle.NULL, 3.0])
+    b = np.array([2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0])
+    buy, sell = oracle.cross_signals(a, b)
+    assert list(buy) == [0, 0, 1, 0, 0, 0, 0]      # 2<=2 then 3>2 at row 2 (row 1: 2>2 is false)
+    assert list(sell) == [0, 0, 0, 0, 1, 0, 0]     # 2>=2 then 1<2 at row 4; rows touching the null never fire
+    x = np.array([25.0, 35.0, 75.0, 65.0, 28.0, 30.0])
+    buy, sell = oracle.band_signals(x, 30.0, 70.0)
+    assert list(buy) == [0, 1, 0, 0, 0, 1] and list(sell) == [0, 0, 0, 1, 0, 0]
+    p = np.array([10.0, 8.0, 9.0, 13.0, 12.0])
+    lo = np.array([9.0, 9.0, 9.0, 9.0, 9.0]); hi = np.array([12.0, 12.0, 12.0, 12.0, 12.0])
+    buy, sell = oracle.channel_signals(p, lo, hi, 0)
+    assert list(buy) == [0, 1, 0, 0, 0] and list(sell) == [0, 0, 0, 1, 0]
+    buy, sell = oracle.channel_signals(p, lo, hi, 1)
+    assert list(buy) == [0, 0, 0, 1, 0] and list(sell) == [0, 1, 0, 0, 0]
+
+
 def test_summary_small(oracle):
     # metrics.rs:7-152 on [100k, 101k, 99k]
     eq = np.array([100000.0, 101000.0, 99000.0])
