@@ -254,6 +254,16 @@ pq_status pq_backtest_leveraged(pq_ctx *, const pq_batch *, const double *price,
 pq_status pq_portfolio_metrics(pq_ctx *, const pq_batch *, const double *total_value, double initial_total,
                                const double *benchmark, double *out);
 
+/* ---- cross-sectional factor evaluation, Factor.ic / rank_ic / rolling_ic (README.md:1429-1430,
+ * :1480-1482, :1626-1634; README-only, decision D-12 in oracle/backtest.c).  factor / fwd_return: [n_series][stride];
+ * per day the cross-section = symbols where both values are non-null and finite.  method 0: Pearson IC (sums over the
+ * symbols in ascending order), 1: Spearman Rank-IC (average ranks; n_series <= 100000, n_series*len < 2^32; uses the
+ * context workspace, ~52 bytes per cell).  ic: [len] (null where fewer than 2 pairs or zero variance); n_valid: [len] or NULL */
+pq_status pq_factor_ic(pq_ctx *, const pq_batch *, const double *factor, const double *fwd_return, int32_t method, double *ic,
+                       int32_t *n_valid);
+/* rolling mean of ic over `window` rows (null unless all of them are non-null) and mean / sample std (IR) */
+pq_status pq_rolling_ic(pq_ctx *, const double *ic, int64_t len, int64_t window, double *rolling_ic, double *rolling_ir);
+
 /* ---- suites: record many calls, replay them as a few chip-filling grids ----
  * One indicator over N symbols is only N/64 wavefronts -- far too few for 256 CUs -- but a DataFrame query asks
  * for many indicators at once (df.with_columns([...]) in the reference; Polars then calls the plugin once per

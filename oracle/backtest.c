@@ -287,6 +287,88 @@ void pqo_channel_signals(const double *p, const double *lo, const double *hi, in
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------------
+ * cross-sectional factor evaluation -- Factor.ic / rank_ic / rolling_ic (README.md:1429-1430,
+ * :1480-1482, :1626-1634; README-only => decision D-12).  factor and fwd_return are symbol-major [n_sym][stride].
+ * Per day t the cross-section is the set of symbols where BOTH values are non-null and finite (pairwise deletion), n_t
+ * of them; fewer than 2, or a zero variance on either side, gives a null IC.
+ *   method 0 (IC, Pearson):  mx = sum(x)/n, my = sum(y)/n; sxy = sum((x-mx)*(y-my)), sxx, syy -- every sum over the
+ *       symbols in ascending order;  ic = sxy / (sqrt(sxx) * sqrt(syy))
+ *   method 1 (Rank IC, Spearman): x and y are replaced by their average ranks (1-based, ties share the mean rank)
+ *       inside the day's cross-section; the sums Sx, Sy, Sxx, Syy, Sxy of ranks are exact in f64 (half-integers, n <= 2^20),
+ *       and  ic = (n*Sxy - Sx*Sy) / (sqrt(n*Sxx - Sx*Sx) * sqrt(n*Syy - Sy*Sy))
+ * rolling_ic(window w): row t = mean of ic[t-w+1 .. t] if all w values are non-null, else null (sum in ascending order);
+ * rolling_ir = that mean / sample standard deviation (dof w-1) of the same w values, null if w < 2 or the deviation is 0. */
+typedef struct { double v; int64_t i; } pqo_kv;
+static int pqo_kv_cmp(const void *a, const void *b) {
+    double x = ((const pqo_kv *)a)->v, y = ((const pqo_kv *)b)->v;
+    return (x > y) - (x < y);
+}
+static void pqo_avg_ranks(const double *v, int64_t n, double *rank, pqo_kv *tmp) {
+    for (int64_t k = 0; k < n; k++) { tmp[k].v = v[k]; tmp[k].i = k; }
+    qsort(tmp, (size_t)n, sizeof(pqo_kv), pqo_kv_cmp);
+    for (int64_t a = 0; a < n;) {
+        int64_t b = a + 1;
+        while (b < n && tmp[b].v == tmp[a].v) b++;
+        double r = ((double)(a + 1) + (double)b) / 2.0; /* mean of the 1-based positions a+1 .. b */
+        for (int64_t k = a; k < b; k++) rank[tmp[k].i] = r;
+        a = b;
+    }
+}
+void pqo_factor_ic(const double *factor, const double *ret, int64_t n_sym, int64_t n, int64_t stride, int method,
+                   double *ic, int32_t *n_valid) {
+    size_t m = (size_t)(n_sym > 0 ? n_sym : 1);
+    double *x = (double *)malloc(8 * m), *y = (double *)malloc(8 * m), *rx = (double *)malloc(8 * m), *ry = (double *)malloc(8 * m);
+    pqo_kv *tmp = (pqo_kv *)malloc(sizeof(pqo_kv) * m);
+    for (int64_t t = 0; t < n; t++) {
+        int64_t k = 0;
+        for (int64_t s = 0; s < n_sym; s++) {
+            double a = factor[s * stride + t], b = ret[s * stride + t];
+            if (pqo_isnull(a) || pqo_isnull(b) || !isfinite(a) || !isfinite(b)) continue;
+            x[k] = a; y[k] = b; k++;
+        }
+        if (n_valid) n_valid[t] = (int32_t)k;
+        ic[t] = pqo_null();
+        if (k < 2) continue;
+        const double nn = (double)k;
+        if (method == 0) {
+            double sx = 0.0, sy = 0.0;
+            for (int64_t j = 0; j < k; j++) { sx += x[j]; sy += y[j]; }
+            double mx = sx / nn, my = sy / nn, sxy = 0.0, sxx = 0.0, syy = 0.0;
+            for (int64_t j = 0; j < k; j++) {
+                double dx = x[j] - mx, dy = y[j] - my;
+                sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
+            }
+            if (sxx > 0.0 && syy > 0.0) ic[t] = sxy / (sqrt(sxx) * sqrt(syy));
+        } else {
+            pqo_avg_ranks(x, k, rx, tmp);
+            pqo_avg_ranks(y, k, ry, tmp);
+            double Sx = 0.0, Sy = 0.0, Sxx = 0.0, Syy = 0.0, Sxy = 0.0;
+            for (int64_t j = 0; j < k; j++) { Sx += rx[j]; Sy += ry[j]; Sxx += rx[j] * rx[j]; Syy += ry[j] * ry[j]; Sxy += rx[j] * ry[j]; }
+            double vx = nn * Sxx - Sx * Sx, vy = nn * Syy - Sy * Sy;
+            if (vx > 0.0 && vy > 0.0) ic[t] = (nn * Sxy - Sx * Sy) / (sqrt(vx) * sqrt(vy));
+        }
+    }
+    free(x); free(y); free(rx); free(ry); free(tmp);
+}
+void pqo_rolling_ic(const double *ic, int64_t n, int64_t w, double *rolling_ic, double *rolling_ir) {
+    for (int64_t t = 0; t < n; t++) {
+        rolling_ic[t] = rolling_ir[t] = pqo_null();
+        if (w <= 0 || t + 1 < w) continue;
+        int ok = 1;
+        double sum = 0.0;
+        for (int64_t j = t - w + 1; j <= t; j++) { if (pqo_isnull(ic[j])) { ok = 0; break; } sum += ic[j]; }
+        if (!ok) continue;
+        double mean = sum / (double)w;
+        rolling_ic[t] = mean;
+        if (w < 2) continue;
+        double vs = 0.0;
+        for (int64_t j = t - w + 1; j <= t; j++) { double d = ic[j] - mean; vs += d * d; }
+        double sd = sqrt(vs / (double)(w - 1));
+        if (sd > 0.0) rolling_ir[t] = mean / sd;
+    }
+}
+
 /* SURVEY.md 8(d) generator: splitmix64-driven, transcendental-free, bit-reproducible. */
 static uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

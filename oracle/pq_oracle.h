@@ -161,6 +161,11 @@ void pqo_cross_signals(const double *a, const double *b, int64_t n, uint8_t *buy
 void pqo_band_signals(const double *x, int64_t n, double lower, double upper, uint8_t *buy, uint8_t *sell);
 void pqo_channel_signals(const double *p, const double *lo, const double *hi, int64_t n, int mode, uint8_t *buy, uint8_t *sell);
 
+/* ---- Factor.ic / rank_ic / rolling_ic (decision D-12, see backtest.c) ---- */
+void pqo_factor_ic(const double *factor, const double *fwd_return, int64_t n_sym, int64_t n, int64_t stride,
+                   int method /*0 Pearson, 1 Spearman*/, double *ic /* [n] */, int32_t *n_valid /* [n] or NULL */);
+void pqo_rolling_ic(const double *ic, int64_t n, int64_t window, double *rolling_ic, double *rolling_ir);
+
 /* ---- synthetic OHLCV generator ---- */
 void pqo_gen_ohlcv(uint64_t seed, int64_t n_sym, int64_t T, int mode /*0 plain,1 pattern-rich*/,
                    double *open, double *high, double *low, double *close, double *volume);

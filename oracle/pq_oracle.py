@@ -285,6 +285,28 @@ def channel_signals(p, lo, hi, mode):
     return _signals("pqo_channel_signals", [p, lo, hi], C.c_int(mode))
 
 
+def factor_ic(factor, fwd_return, method=0):
+    """D-12: factor, fwd_return [N, T] -> (ic [T], n_valid [T]); method 0 Pearson IC, 1 Spearman Rank-IC"""
+    f = np.ascontiguousarray(factor, dtype=np.float64)
+    r = np.ascontiguousarray(fwd_return, dtype=np.float64)
+    N, T = f.shape
+    ic = np.empty(T)
+    nv = np.zeros(T, np.int32)
+    fn = lib().pqo_factor_ic
+    fn.restype = None
+    fn(_p(f), _p(r), C.c_int64(N), C.c_int64(T), C.c_int64(T), C.c_int(method), _p(ic), _p(nv))
+    return ic, nv
+
+
+def rolling_ic(ic, window):
+    a = np.ascontiguousarray(ic, dtype=np.float64)
+    ric, rir = np.empty_like(a), np.empty_like(a)
+    fn = lib().pqo_rolling_ic
+    fn.restype = None
+    fn(_p(a), C.c_int64(len(a)), C.c_int64(window), _p(ric), _p(rir))
+    return ric, rir
+
+
 def summary(equity, benchmark, initial_capital, trades, wins):
     eq = np.ascontiguousarray(equity, dtype=np.float64)
     bm = np.ascontiguousarray(benchmark, dtype=np.float64) if benchmark is not None else None

@@ -83,6 +83,10 @@ def lib() -> C.CDLL:
         L.pq_band_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_double, C.c_double, vp, vp]
         L.pq_channel_signals.restype = C.c_int32
         L.pq_channel_signals.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, C.c_int32, vp, vp]
+        L.pq_factor_ic.restype = C.c_int32
+        L.pq_factor_ic.argtypes = [vp, C.POINTER(Batch), vp, vp, C.c_int32, vp, vp]
+        L.pq_rolling_ic.restype = C.c_int32
+        L.pq_rolling_ic.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp]
         L.pq_backtest_leveraged.restype = C.c_int32
         L.pq_backtest_leveraged.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp, C.POINTER(LevParams), vp, vp, vp, C.c_int32] + [vp] * 10
         L.pq_portfolio_metrics.restype = C.c_int32

@@ -249,6 +249,40 @@ def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, wan
     return f(pos), f(cash), f(eq), f(summ)
 
 
+def factor_ic(factor, fwd_return, method: int = 0):
+    """D-12: per-day cross-sectional IC of factor vs forward return, both [N, T] -> (ic [T], n_valid [T]) device tensors.
+    method 0 = Pearson IC, 1 = Spearman Rank-IC"""
+    f = _to_device(factor)[0].contiguous()
+    r = _to_device(fwd_return)[0].contiguous()
+    if f.shape != r.shape:
+        raise ValueError("factor and fwd_return must have the same shape")
+    dev = f.device
+    n, T = f.shape
+    ic = torch.empty(T, dtype=torch.float64, device=dev)
+    nv = torch.zeros(T, dtype=torch.int32, device=dev)
+    b = Batch(n, T, T)
+    if T:
+        with torch.cuda.device(dev):
+            check(lib().pq_factor_ic(ctx(dev.index), C.byref(b), C.c_void_p(f.data_ptr()) if n else None,
+                                     C.c_void_p(r.data_ptr()) if n else None, int(method), C.c_void_p(ic.data_ptr()),
+                                     C.c_void_p(nv.data_ptr())) if n else 0)
+        if n == 0:
+            ic.fill_(float("nan"))
+    return ic, nv
+
+
+def rolling_ic(ic, window: int):
+    """D-12: rolling mean of the IC series and its information ratio -> (rolling_ic, rolling_ir) device tensors [T]"""
+    t = _to_device(ic)[0].contiguous().reshape(-1)
+    dev = t.device
+    ric, rir = torch.empty_like(t), torch.empty_like(t)
+    if t.numel():
+        with torch.cuda.device(dev):
+            check(lib().pq_rolling_ic(ctx(dev.index), C.c_void_p(t.data_ptr()), t.numel(), int(window), C.c_void_p(ric.data_ptr()),
+                                      C.c_void_p(rir.data_ptr())))
+    return ric, rir
+
+
 def _signal_call(fn_name, cols, *scalars):
     ts = [_to_device(c)[0].contiguous() for c in cols]
     dev = ts[0].device

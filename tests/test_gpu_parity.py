@@ -379,6 +379,37 @@ def test_signal_rules_and_strategies(pq, oracle, data):
     assert int(out["trade_count"].sum()) > 0
 
 
+def test_factor_ic_matches_oracle(pq, oracle, data):
+    """SURVEY 8(f) rank 3 (decision D-12): IC, Rank-IC and rolling IC bit-exact against the oracle."""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(3)
+    for N, T in ((37, 50), (300, 131), (1, 5), (2, 3)):
+        f = rng.normal(size=(N, T))
+        r = 0.2 * f + rng.normal(size=(N, T))
+        if N > 10:
+            f[rng.random((N, T)) < 0.05] = oracle.NULL
+            r[rng.random((N, T)) < 0.03] = np.nan
+            f[:, 3] = np.round(f[:, 3] * 2.0)          # heavy ties
+            r[:, 4] = np.round(r[:, 4])
+            f[:, 5] = 2.5                                # zero variance
+            f[1:, 6] = oracle.NULL                      # one pair only
+            f[0, 7] = np.inf; r[1, 7] = -np.inf
+        for method in (0, 1):
+            eic, env = oracle.factor_ic(f, r, method)
+            gic, gnv = api.factor_ic(torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda(), method)
+            gic, gnv = gic.cpu().numpy(), gnv.cpu().numpy()
+            assert (gnv == env).all(), (N, T, method)
+            same = (bits(gic) == bits(eic)) | (np.isnan(gic) & np.isnan(eic))
+            assert same.all(), f"N={N} T={T} method={method}: {np.flatnonzero(~same)[:5]}"
+            em, eir = oracle.rolling_ic(eic, 4)
+            gm, gir = api.rolling_ic(torch.from_numpy(eic).cuda(), 4)
+            for g, e in ((gm.cpu().numpy(), em), (gir.cpu().numpy(), eir)):
+                assert ((bits(g) == bits(e)) | (np.isnan(g) & np.isnan(e))).all()
+    fac = pq.Factor()
+    out = fac.rolling_ic(torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda(), window=2, rank=True)
+    assert set(out) == {"rolling_ic", "rolling_ir"}
+
+
 def test_numpy_and_arrow_roundtrip(pq, oracle, data):
     import pyarrow as pa
     x = data["close"][0].copy()

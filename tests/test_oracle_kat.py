@@ -376,6 +376,32 @@ def test_signal_rules(oracle):
     assert list(buy) == [0, 0, 0, 1, 0] and list(sell) == [0, 1, 0, 0, 0]
 
 
+def test_factor_ic_against_scipy(oracle):
+    # D-12 (oracle/backtest.c): an independent pin -- scipy.stats.pearsonr / spearmanr on the same cross-sections
+    from scipy import stats
+    rng = np.random.default_rng(0)
+    f = rng.normal(size=(60, 9))
+    r = 0.3 * f + rng.normal(size=(60, 9))
+    f[3, 2] = oracle.NULL; r[7, 2] = np.nan; f[5, 2] = np.inf     # pairwise deletion
+    f[:, 5] = np.round(f[:, 5], 0)                                 # ties -> average ranks
+    f[:, 6] = 1.0                                                  # zero variance -> null
+    f[2:, 7] = oracle.NULL                                         # fewer than 2 pairs -> null
+    ic, nv = oracle.factor_ic(f, r, 0)
+    ric, nv2 = oracle.factor_ic(f, r, 1)
+    assert list(nv) == [60, 60, 57, 60, 60, 60, 60, 2, 60] and list(nv2) == list(nv)
+    for t in (0, 1, 2, 3, 4, 5, 8):
+        m = np.isfinite(f[:, t]) & np.isfinite(r[:, t])
+        assert ic[t] == pytest.approx(stats.pearsonr(f[m, t], r[m, t])[0], abs=1e-14)
+        assert ric[t] == pytest.approx(stats.spearmanr(f[m, t], r[m, t])[0], abs=1e-14)
+    assert math.isnan(ic[6]) and math.isnan(ric[6])
+    assert ic[7] == pytest.approx(1.0 if (f[1, 7] - f[0, 7]) * (r[1, 7] - r[0, 7]) > 0 else -1.0)   # two points
+    m3, ir3 = oracle.rolling_ic(ic, 3)
+    assert math.isnan(m3[1]) and m3[2] == (ic[0] + ic[1] + ic[2]) / 3.0
+    assert math.isnan(m3[6]) and math.isnan(m3[8])                 # a null IC inside the window
+    sd = math.sqrt(((ic[0] - m3[2]) ** 2 + (ic[1] - m3[2]) ** 2 + (ic[2] - m3[2]) ** 2) / 2.0)
+    assert ir3[2] == pytest.approx(m3[2] / sd, rel=1e-14)
+
+
 def test_summary_small(oracle):
     # metrics.rs:7-152 on [100k, 101k, 99k]
     eq = np.array([100000.0, 101000.0, 99000.0])
