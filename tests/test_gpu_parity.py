@@ -461,6 +461,45 @@ def test_suite_replay_matches_direct_calls_and_oracle(pq, oracle, data):
     st.close()
 
 
+def test_full_size_suite_sampled_parity_and_properties(pq, oracle):
+    """BASELINE full size (5000 symbols x 2520 days), the bench's own Suite object: (1) every output of a sample of symbols
+    equals the oracle run on just those symbols (series are independent, so a sample at full length is a full-length parity
+    check); (2) size-independent properties: exact scaling by a power of two, equity = cash + position * price, replay
+    idempotence."""
+    from polars_quant_amd import api
+    from polars_quant_amd.suite import Suite
+    N, TT = 5000, 2520
+    d = oracle.gen_ohlcv(0x5EED0002, N, TT, 0)
+    g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    st = Suite(N, TT, "cuda")
+    st.record(g)
+    st.run(); st.run()
+    torch.cuda.synchronize()
+    pick = np.array([0, 1, 63, 64, 65, 127, 1234, 2500, 2501, 4095, 4096, 4990, 4999])
+    sub = {k: np.ascontiguousarray(v[pick]) for k, v in d.items()}
+    sub["periods"] = st.periods[pick].cpu().numpy()
+    sub["real"] = sub["close"]
+    for name in sorted(pq.SPEC):
+        exp = oracle.call(name, *[sub[c] for c in pq.SPEC[name][0]])
+        for (oname, _), got, e in zip(pq.SPEC[name][2], st.out[name], exp):
+            assert_same(f"full:{name}.{oname}", got[pick].cpu().numpy(), e, exact=name not in TRANSCENDENTAL)
+    for nm in pq.PATTERN_NAMES[::7]:
+        assert (st.pat[nm][pick].cpu().numpy() == oracle.pattern(nm, sub["open"], sub["high"], sub["low"], sub["close"])).all(), nm
+    ebuy, esell = oracle.macd_cross_signals(sub["close"])
+    epos, ecash, eeq, es = oracle.backtest(sub["close"], ebuy, esell)
+    pos, cash, eq = (t.cpu().numpy() for t in st.bt)
+    assert (bits(eq[pick]) == bits(eeq)).all() and (bits(pos[pick]) == bits(epos)).all()
+    np.testing.assert_allclose(st.summary[pick].cpu().numpy(), es, rtol=1e-12, atol=1e-13)
+    # properties over ALL 12.6 M rows
+    assert (bits(eq) == bits(cash + pos * d["close"])).all()                       # vectorized.rs:177
+    (ema1,) = api.call("ema", g["close"], timeperiod=30)
+    (ema2,) = api.call("ema", g["close"] * 2.0, timeperiod=30)
+    a, b = ema1.cpu().numpy(), ema2.cpu().numpy()
+    assert ((bits(a * 2.0) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()         # every op of the recurrence scales exactly
+    assert (bits(st.out["ema"][0].cpu().numpy()) == bits(a)).all()                  # suite replay == direct call
+    st.close()
+
+
 def test_fused_multi_output_calls(pq, oracle, data):
     """pq_dmi_all / pq_ht_all evaluate a shared core once; every column must equal the single-output function"""
     import ctypes as C
