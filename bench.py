@@ -126,6 +126,7 @@ def main():
     mean_ms = sum(g["avg_ms"] * g["runs"] for g in dom) / n_launch
     mean_bytes = sum(g["alg_bytes"] * g["runs"] for g in dom) / n_launch
     achieved = mean_bytes / (mean_ms * 1e-3) / 1e9
+    span_ms, span_bytes = suite.span_stats(0)   # the two launches as one concurrent set
     suite_bytes = suite.suite_bytes_per_row() * rows_local
     suite_gbs = suite_bytes / (elapsed / args.steps) / 1e9
     # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
@@ -153,6 +154,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": mean_bytes, "avg_launch_ms": mean_ms,
                          "launches_per_step": len(dom),
+                         "concurrent_set": {"note": "the launches of this kernel overlap inside a step: their summed algorithmic bytes "
+                                                    "over the time from the earliest start to the latest end (HIP events)",
+                                            "span_ms": span_ms, "algorithmic_bytes": span_bytes,
+                                            "achieved": span_bytes / (span_ms * 1e-3) / 1e9 if span_ms else None,
+                                            "frac": span_bytes / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if span_ms else None},
                          "grids": [{k: g[k] for k in ("kernel", "avg_ms", "alg_bytes", "n_jobs", "lds_bytes")} for g in grids]},
         }
         if world == 1 and not args.no_cpu_baseline:

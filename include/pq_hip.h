@@ -285,6 +285,9 @@ pq_status pq_suite_grid_stats(pq_suite *suite, int32_t grid, double *avg_ms, dou
 /* which kernel a grid launches: 0 = seq_jobs_kernel<0> (tiled bodies), 1 = seq_jobs_kernel<1> (register-heavy ops),
  * 2 = seq_jobs_kernel<2> (gather bodies) */
 pq_status pq_suite_grid_variant(pq_suite *suite, int32_t grid, int32_t *variant);
+/* the launches of one kernel overlap inside a step: mean (latest end - earliest start) over the grids launching kernel
+ * `variant`, and the sum of their algorithmic bytes */
+pq_status pq_suite_span_stats(pq_suite *suite, int32_t variant, double *avg_span_ms, double *algorithmic_bytes);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
         L.pq_suite_grid_stats.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.pq_suite_grid_variant.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
+        L.pq_suite_span_stats.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 

@@ -704,6 +704,33 @@ pq_status pq_suite_grid_stats(pq_suite *s, int32_t k, double *avg_ms, double *al
     pq_set_error("pq_suite_grid_stats: grid index out of range");
     return PQ_ERR_ARG;
 }
+// The launches of one kernel overlap within a step: mean over the timed runs of (latest end - earliest start) over the grids
+// that launch kernel `variant`, on the device clock (HIP events of different streams are comparable).
+pq_status pq_suite_span_stats(pq_suite *s, int32_t variant, double *avg_span_ms, double *alg_bytes) {
+    PQ_REQUIRE(s && avg_span_ms && alg_bytes, "pq_suite_span_stats: null pointer");
+    std::vector<GridStat *> gs;
+    for (Phase &p : s->rec.phases)
+        for (int c = 0; c < NCLS; c++)
+            if (p.gs[c].n_jobs > 0 && p.gs[c].runs > 0 && plan().cls[c].variant == variant) gs.push_back(&p.gs[c]);
+    *avg_span_ms = 0.0; *alg_bytes = 0.0;
+    if (gs.empty()) return PQ_OK;
+    int runs = gs[0]->runs;
+    for (GridStat *g : gs) { runs = g->runs < runs ? g->runs : runs; *alg_bytes += g->alg_bytes; }
+    double tot = 0.0;
+    for (int i = 0; i < runs; i++) {
+        float lo = 0.0f, hi = 0.0f;
+        for (size_t k = 0; k < gs.size(); k++) {
+            float a = 0.0f, b = 0.0f;
+            if (k > 0) PQ_HIP_TRY(hipEventElapsedTime(&a, gs[0]->ev[2 * i], gs[k]->ev[2 * i]));
+            PQ_HIP_TRY(hipEventElapsedTime(&b, gs[0]->ev[2 * i], gs[k]->ev[2 * i + 1]));
+            lo = (k == 0 || a < lo) ? a : lo;
+            hi = (k == 0 || b > hi) ? b : hi;
+        }
+        tot += (double)(hi - lo);
+    }
+    *avg_span_ms = runs ? tot / runs : 0.0;
+    return PQ_OK;
+}
 pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
     PQ_REQUIRE(s && variant, "pq_suite_grid_variant: null pointer");
     int idx = 0;

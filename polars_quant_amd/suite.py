@@ -141,6 +141,13 @@ class Suite:
             k += 1
         return out
 
+    def span_stats(self, variant: int = 0):
+        """-> (mean ms from the earliest start to the latest end of the grids launching seq_jobs_kernel<variant>, their
+        algorithmic bytes per step)"""
+        ms, by = C.c_double(), C.c_double()
+        check(lib().pq_suite_span_stats(self._suite, variant, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
     def run(self, ohlcv: dict | None = None) -> None:
         """one step: every indicator + all 61 patterns + the MACD-cross backtest, enqueued on the current stream"""
         if getattr(self, "_suite", None) is None:
