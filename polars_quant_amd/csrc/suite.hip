@@ -131,12 +131,12 @@ struct pq_suite {
     X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
-    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
+    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<0>) X(MavpBlockOp<1>) X(MavpSma16Op)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(HtOp<4>) X(BtMacdOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
-    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp)
-static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
+    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp) X(StochOp<0>)
+static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == 74 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
 
 // V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
