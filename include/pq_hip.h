@@ -249,15 +249,16 @@ pq_status pq_backtest_leveraged(pq_ctx *, const pq_batch *, const double *price,
                                 double *quantity, double *pnl, double *pnl_pct, int32_t *reason, double *summary);
 #define PQ_PORTFOLIO_COLS 10 /* portfolio_value, daily_pnl, daily_return_pct, cumulative_pnl, cumulative_return_pct,
                                 benchmark_return_pct, alpha_pct, relative_return_pct, beta, (reserved 0) */
-/* get_performance_metrics (README.md:455-477): per-day sums over the symbols of this batch in ascending order, then the
+/* get_performance_metrics (README.md:455-477): per-day sums over the symbols of this batch (blocks of 256 symbols, ascending
+ * inside a block, block sums added in ascending order), then the
  * day-to-day metrics; out is [b->len][PQ_PORTFOLIO_COLS]; benchmark: one series of b->len rows or NULL */
 pq_status pq_portfolio_metrics(pq_ctx *, const pq_batch *, const double *total_value, double initial_total,
                                const double *benchmark, double *out);
 
 /* ---- cross-sectional factor evaluation, Factor.ic / rank_ic / rolling_ic (README.md:1429-1430,
  * :1480-1482, :1626-1634; README-only, decision D-12 in oracle/backtest.c).  factor / fwd_return: [n_series][stride];
- * per day the cross-section = symbols where both values are non-null and finite.  method 0: Pearson IC (sums over the
- * symbols in ascending order), 1: Spearman Rank-IC (average ranks; n_series <= 100000, n_series*len < 2^32; uses the
+ * per day the cross-section = symbols where both values are non-null and finite.  method 0: Pearson IC (sums over
+ * blocks of 256 symbols in ascending order), 1: Spearman Rank-IC (average ranks; n_series <= 100000, n_series*len < 2^32; uses the
  * context workspace, ~52 bytes per cell).  ic: [len] (null where fewer than 2 pairs or zero variance); n_valid: [len] or NULL */
 pq_status pq_factor_ic(pq_ctx *, const pq_batch *, const double *factor, const double *fwd_return, int32_t method, double *ic,
                        int32_t *n_valid);

@@ -204,16 +204,21 @@ void pqo_backtest_leveraged(const double *price, const uint8_t *buy, const uint8
     if (summary) pqo_summary(total_value, benchmark, n, benchmark ? n : 0, prm->initial_capital, trades, wins, summary);
 }
 
+#define PQO_SUM_BLOCK 256 /* cross-sectional sums (portfolio value, IC) are defined over blocks of this many symbols */
 /* README.md:455-477 get_performance_metrics over all symbols.  total_value: [n_sym][n] row-major.  out: [n][10] =
  * portfolio_value, daily_pnl, daily_return_pct, cumulative_pnl, cumulative_return_pct, benchmark_return_pct, alpha_pct,
- * relative_return_pct, beta, 0 (columns 5-8 are 0 without a benchmark).  Sums run over symbols in ascending order;
+ * relative_return_pct, beta, 0 (columns 5-8 are 0 without a benchmark).  Sums run over blocks of 256 symbols (see below);
  * beta = sample covariance / sample variance (dof max(n-1, 1)) of the daily percentage returns, one value for all rows. */
 void pqo_portfolio_metrics(const double *total_value, int64_t n_sym, int64_t n, int64_t stride, double initial_total,
                            const double *benchmark, double *out) {
     double prev = initial_total;
     for (int64_t t = 0; t < n; t++) {
-        double pv = 0.0;
-        for (int64_t s = 0; s < n_sym; s++) pv += total_value[s * stride + t];
+        double pv = 0.0; /* blocks of PQO_SUM_BLOCK symbols: ascending inside a block, block sums added in ascending order */
+        for (int64_t s0 = 0; s0 < n_sym; s0 += PQO_SUM_BLOCK) {
+            double part = 0.0;
+            for (int64_t s = s0; s < n_sym && s < s0 + PQO_SUM_BLOCK; s++) part += total_value[s * stride + t];
+            pv += part;
+        }
         double *o = out + t * 10;
         o[0] = pv;
         o[1] = pv - prev;
@@ -292,8 +297,8 @@ void pqo_channel_signals(const double *p, const double *lo, const double *hi, in
  * :1480-1482, :1626-1634; README-only => decision D-12).  factor and fwd_return are symbol-major [n_sym][stride].
  * Per day t the cross-section is the set of symbols where BOTH values are non-null and finite (pairwise deletion), n_t
  * of them; fewer than 2, or a zero variance on either side, gives a null IC.
- *   method 0 (IC, Pearson):  mx = sum(x)/n, my = sum(y)/n; sxy = sum((x-mx)*(y-my)), sxx, syy -- every sum over the
- *       symbols in ascending order;  ic = sxy / (sqrt(sxx) * sqrt(syy))
+ *   method 0 (IC, Pearson):  mx = sum(x)/n, my = sum(y)/n; sxy = sum((x-mx)*(y-my)), sxx, syy -- every sum taken over
+ *       blocks of 256 symbols (ascending inside a block, block sums added in ascending order);  ic = sxy / (sqrt(sxx) * sqrt(syy))
  *   method 1 (Rank IC, Spearman): x and y are replaced by their average ranks (1-based, ties share the mean rank)
  *       inside the day's cross-section; the sums Sx, Sy, Sxx, Syy, Sxy of ranks are exact in f64 (half-integers, n <= 2^20),
  *       and  ic = (n*Sxy - Sx*Sy) / (sqrt(n*Sxx - Sx*Sx) * sqrt(n*Syy - Sy*Sy))
@@ -331,13 +336,27 @@ void pqo_factor_ic(const double *factor, const double *ret, int64_t n_sym, int64
         ic[t] = pqo_null();
         if (k < 2) continue;
         const double nn = (double)k;
-        if (method == 0) {
+        if (method == 0) { /* blocks of PQO_SUM_BLOCK SYMBOLS (valid or not): partial sums in ascending order, then the partials */
             double sx = 0.0, sy = 0.0;
-            for (int64_t j = 0; j < k; j++) { sx += x[j]; sy += y[j]; }
+            for (int64_t s0 = 0; s0 < n_sym; s0 += PQO_SUM_BLOCK) {
+                double px = 0.0, py = 0.0;
+                for (int64_t s = s0; s < n_sym && s < s0 + PQO_SUM_BLOCK; s++) {
+                    double a = factor[s * stride + t], b = ret[s * stride + t];
+                    if (pqo_isnull(a) || pqo_isnull(b) || !isfinite(a) || !isfinite(b)) continue;
+                    px += a; py += b;
+                }
+                sx += px; sy += py;
+            }
             double mx = sx / nn, my = sy / nn, sxy = 0.0, sxx = 0.0, syy = 0.0;
-            for (int64_t j = 0; j < k; j++) {
-                double dx = x[j] - mx, dy = y[j] - my;
-                sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
+            for (int64_t s0 = 0; s0 < n_sym; s0 += PQO_SUM_BLOCK) {
+                double pxy = 0.0, pxx = 0.0, pyy = 0.0;
+                for (int64_t s = s0; s < n_sym && s < s0 + PQO_SUM_BLOCK; s++) {
+                    double a = factor[s * stride + t], b = ret[s * stride + t];
+                    if (pqo_isnull(a) || pqo_isnull(b) || !isfinite(a) || !isfinite(b)) continue;
+                    double dx = a - mx, dy = b - my;
+                    pxy += dx * dy; pxx += dx * dx; pyy += dy * dy;
+                }
+                sxy += pxy; sxx += pxx; syy += pyy;
             }
             if (sxx > 0.0 && syy > 0.0) ic[t] = sxy / (sqrt(sxx) * sqrt(syy));
         } else {

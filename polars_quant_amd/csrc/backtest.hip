@@ -125,7 +125,12 @@ pq_status pq_portfolio_metrics(pq_ctx *ctx, const pq_batch *b, const double *tot
     PQ_REQUIRE(total_value && out, "pq_portfolio_metrics: null pointer");
     if (ctx->rec) { pq_set_error("pq_portfolio_metrics cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
     if (b->len == 0) return PQ_OK;
-    hipLaunchKernelGGL(portfolio_sum_kernel, dim3((unsigned)((b->len + 63) / 64)), dim3(64), 0, ctx->stream, total_value, dims_of(b), out);
+    const int64_t nblk = (b->n_series + PORTFOLIO_BLOCK - 1) / PORTFOLIO_BLOCK > 0 ? (b->n_series + PORTFOLIO_BLOCK - 1) / PORTFOLIO_BLOCK : 1;
+    PQ_TRY(pq_ws_reserve(ctx, (size_t)nblk * (size_t)b->len * 8));
+    hipLaunchKernelGGL(portfolio_partial_kernel, dim3((unsigned)((b->len + 63) / 64), (unsigned)nblk), dim3(64), 0, ctx->stream, total_value,
+                       dims_of(b), (double *)ctx->ws);
+    hipLaunchKernelGGL(portfolio_combine_kernel, dim3((unsigned)((b->len + 63) / 64)), dim3(64), 0, ctx->stream, (const double *)ctx->ws, nblk,
+                       b->len, out);
     hipLaunchKernelGGL(portfolio_metrics_kernel, dim3(1), dim3(256), 0, ctx->stream, b->len, initial_total, benchmark, out);
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;

@@ -2,8 +2,9 @@
 // (README.md:1429-1430, :1480-1482, :1626-1634; README-only => decision D-12, oracle/backtest.c pqo_factor_ic).
 //
 // The columns are symbol-major [n_series][stride]; a day's cross-section is a strided column.
-//  * Pearson IC: one day per thread, symbols walked in ascending order (the sums are order-sensitive, so the oracle's order
-//    IS the definition); consecutive threads read consecutive days -> coalesced; 16 loads per column in flight.
+//  * Pearson IC: the sums are order-sensitive, so the oracle's order IS the definition: blocks of 256 symbols, ascending
+//    inside a block, block sums added in ascending order.  One (day, block) per thread; consecutive threads read
+//    consecutive days -> coalesced; 16 loads per column in flight.
 //  * Rank IC: a tiled transpose builds day-major key rows (invalid pairs -> +inf), rocPRIM's segmented radix sort orders
 //    every day's row (keys + symbol ids), a per-day workgroup turns sorted positions into average ranks (ties share the
 //    mean rank) and accumulates the five rank sums.  Ranks are half-integers, so the sums are exact in f64 in ANY order
@@ -14,45 +15,53 @@
 
 __device__ __forceinline__ bool ic_valid(double a, double b) { return !pq_isnull(a) && !pq_isnull(b) && isfinite(a) && isfinite(b); }
 
-__global__ __launch_bounds__(64) void ic_pearson_kernel(const double *x, const double *y, Dims d, double *ic, int32_t *n_valid) {
+// Pearson IC in four launches: cross-sectional sums are DEFINED over blocks of 256 symbols (ascending inside a block, block
+// sums added in ascending order, oracle PQO_SUM_BLOCK), which gives (len/64) x (n/256) workgroups instead of len/64.
+constexpr int IC_BLOCK = 256;
+template <int PASS> // 0: n, sum x, sum y   1: centred sums given the means
+__global__ __launch_bounds__(64) void ic_partial_kernel(const double *x, const double *y, Dims d, const double *means, double *part) {
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= d.len) return;
-    double sx = 0.0, sy = 0.0;
-    int64_t n = 0;
+    const int64_t s_lo = (int64_t)blockIdx.y * IC_BLOCK, s_hi = s_lo + IC_BLOCK < d.n ? s_lo + IC_BLOCK : d.n;
+    double mx = 0.0, my = 0.0;
+    if (PASS == 1) { mx = means[t * 3 + 1]; my = means[t * 3 + 2]; }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     constexpr int B = 16;
-    for (int64_t s0 = 0; s0 < d.n; s0 += B) {
+    for (int64_t s0 = s_lo; s0 < s_hi; s0 += B) {
         double a[B], b[B];
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const int64_t s = s0 + k < d.n ? s0 + k : d.n - 1;
+            const int64_t s = s0 + k < s_hi ? s0 + k : s_hi - 1;
             a[k] = x[s * d.stride + t]; b[k] = y[s * d.stride + t];
         }
 #pragma unroll
         for (int k = 0; k < B; k++)
-            if (s0 + k < d.n && ic_valid(a[k], b[k])) { sx += a[k]; sy += b[k]; n += 1; }
-    }
-    if (n_valid) n_valid[t] = (int32_t)n;
-    double out = pq_null();
-    if (n >= 2) {
-        const double nn = (double)n, mx = sx / nn, my = sy / nn;
-        double sxy = 0.0, sxx = 0.0, syy = 0.0;
-        for (int64_t s0 = 0; s0 < d.n; s0 += B) {
-            double a[B], b[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                const int64_t s = s0 + k < d.n ? s0 + k : d.n - 1;
-                a[k] = x[s * d.stride + t]; b[k] = y[s * d.stride + t];
+            if (s0 + k < s_hi && ic_valid(a[k], b[k])) {
+                if (PASS == 0) { a0 += 1.0; a1 += a[k]; a2 += b[k]; }
+                else { const double dx = a[k] - mx, dy = b[k] - my; a0 += dx * dy; a1 += dx * dx; a2 += dy * dy; }
             }
-#pragma unroll
-            for (int k = 0; k < B; k++)
-                if (s0 + k < d.n && ic_valid(a[k], b[k])) {
-                    const double dx = a[k] - mx, dy = b[k] - my;
-                    sxy += dx * dy; sxx += dx * dx; syy += dy * dy;
-                }
-        }
-        if (sxx > 0.0 && syy > 0.0) out = sxy / (sqrt(sxx) * sqrt(syy));
     }
-    ic[t] = out;
+    double *o = part + ((int64_t)blockIdx.y * d.len + t) * 3;
+    o[0] = a0; o[1] = a1; o[2] = a2;
+}
+template <int PASS>
+__global__ __launch_bounds__(64) void ic_combine_kernel(const double *part, int64_t nblk, int64_t len, double *means, double *ic, int32_t *n_valid) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= len) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t k = 0; k < nblk; k++) {
+        const double *o = part + (k * len + t) * 3;
+        a0 += o[0]; a1 += o[1]; a2 += o[2];
+    }
+    if (PASS == 0) { // a0 = n (a sum of small integers: exact), means
+        means[t * 3] = a0;
+        means[t * 3 + 1] = a0 > 0.0 ? a1 / a0 : 0.0;
+        means[t * 3 + 2] = a0 > 0.0 ? a2 / a0 : 0.0;
+        if (n_valid) n_valid[t] = (int32_t)a0;
+    } else {
+        const double n = means[t * 3];
+        ic[t] = (n >= 2.0 && a1 > 0.0 && a2 > 0.0) ? a0 / (sqrt(a1) * sqrt(a2)) : pq_null();
+    }
 }
 
 // [n][stride] -> day-major [len][n] keys (+inf where the pair is invalid), symbol ids, per-day valid counts
@@ -168,7 +177,15 @@ pq_status pq_factor_ic(pq_ctx *ctx, const pq_batch *b, const double *factor, con
     if (b->len == 0) return PQ_OK;
     const Dims d = dims_of(b);
     if (method == 0 || b->n_series == 0) {
-        hipLaunchKernelGGL(ic_pearson_kernel, dim3((unsigned)((d.len + 63) / 64)), dim3(64), 0, ctx->stream, factor, fwd_return, d, ic, n_valid);
+        const int64_t nblk = (d.n + IC_BLOCK - 1) / IC_BLOCK > 0 ? (d.n + IC_BLOCK - 1) / IC_BLOCK : 1;
+        const size_t part_bytes = (size_t)nblk * (size_t)d.len * 24, means_bytes = (size_t)d.len * 24;
+        PQ_TRY(pq_ws_reserve(ctx, part_bytes + means_bytes));
+        double *part = (double *)ctx->ws, *means = (double *)((unsigned char *)ctx->ws + part_bytes);
+        const dim3 gp((unsigned)((d.len + 63) / 64), (unsigned)nblk), gc((unsigned)((d.len + 63) / 64));
+        hipLaunchKernelGGL(ic_partial_kernel<0>, gp, dim3(64), 0, ctx->stream, factor, fwd_return, d, (const double *)nullptr, part);
+        hipLaunchKernelGGL(ic_combine_kernel<0>, gc, dim3(64), 0, ctx->stream, part, nblk, d.len, means, ic, n_valid);
+        hipLaunchKernelGGL(ic_partial_kernel<1>, gp, dim3(64), 0, ctx->stream, factor, fwd_return, d, (const double *)means, part);
+        hipLaunchKernelGGL(ic_combine_kernel<1>, gc, dim3(64), 0, ctx->stream, part, nblk, d.len, means, ic, n_valid);
         PQ_HIP_TRY(hipGetLastError());
         return PQ_OK;
     }

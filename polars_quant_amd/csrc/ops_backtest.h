@@ -534,21 +534,30 @@ struct ChannelSigOp {
     }
 };
 
-// get_performance_metrics: per-day sum over the symbols (ascending, one day per thread: coalesced across days), then the
-// day-to-day columns; beta needs ordered sums over the days and is done by one thread (T is a few thousand).
-static __global__ __launch_bounds__(64) void portfolio_sum_kernel(const double *tv, Dims d, double *out) {
+// get_performance_metrics: per-day sum over the symbols (blocks of 256, one (day, block) per thread: coalesced across days),
+// then the day-to-day columns; beta needs ordered sums over the days and is done by one thread (T is a few thousand).
+constexpr int PORTFOLIO_BLOCK = 256; // = oracle PQO_SUM_BLOCK: the per-day sum is defined over blocks of symbols
+static __global__ __launch_bounds__(64) void portfolio_partial_kernel(const double *tv, Dims d, double *part) {
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= d.len) return;
+    const int64_t s_lo = (int64_t)blockIdx.y * PORTFOLIO_BLOCK, s_hi = s_lo + PORTFOLIO_BLOCK < d.n ? s_lo + PORTFOLIO_BLOCK : d.n;
     double pv = 0.0;
-    int64_t s = 0;
-    for (; s + 32 <= d.n; s += 32) { // 32 independent loads in flight, then the adds in ascending symbol order
+    int64_t s = s_lo;
+    for (; s + 32 <= s_hi; s += 32) { // 32 independent loads in flight, then the adds in ascending symbol order
         double v[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) v[k] = tv[(s + k) * d.stride + t];
 #pragma unroll
         for (int k = 0; k < 32; k++) pv += v[k];
     }
-    for (; s < d.n; s++) pv += tv[s * d.stride + t];
+    for (; s < s_hi; s++) pv += tv[s * d.stride + t];
+    part[(int64_t)blockIdx.y * d.len + t] = pv;
+}
+static __global__ __launch_bounds__(64) void portfolio_combine_kernel(const double *part, int64_t nblk, int64_t len, double *out) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= len) return;
+    double pv = 0.0;
+    for (int64_t k = 0; k < nblk; k++) pv += part[k * len + t];
     out[t * PQ_PORTFOLIO_COLS] = pv;
 }
 static __global__ __launch_bounds__(256) void portfolio_metrics_kernel(int64_t T, double initial_total, const double *bm, double *out) {
