@@ -410,6 +410,44 @@ def test_factor_ic_matches_oracle(pq, oracle, data):
     assert set(out) == {"rolling_ic", "rolling_ir"}
 
 
+def test_error_paths_leave_the_context_usable(pq, oracle, data):
+    """Argument errors come back as status codes with a message (PqError), never as a launch; the context keeps working."""
+    import ctypes as C
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import Batch, LevParams, check, lib
+    x = torch.from_numpy(data["close"]).cuda()
+    n, TT = x.shape
+    L, h = lib(), api.ctx(0)
+    b = Batch(n, TT, TT)
+    out = torch.empty_like(x)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    with pytest.raises(pq.PqError, match="null pointer"):
+        check(L.pq_sma(h, C.byref(b), None, C.c_int64(5), vp(out)))
+    with pytest.raises(pq.PqError):
+        check(L.pq_sma(h, C.byref(Batch(n, TT, TT - 1)), vp(x), C.c_int64(5), vp(out)))      # stride < len
+    ic = torch.empty(TT, dtype=torch.float64, device="cuda")
+    with pytest.raises(pq.PqError, match="method"):
+        check(L.pq_factor_ic(h, C.byref(b), vp(x), vp(x), 7, vp(ic), None))
+    u8 = torch.zeros((n, TT), dtype=torch.uint8, device="cuda")
+    with pytest.raises(pq.PqError, match="mode"):
+        check(L.pq_channel_signals(h, C.byref(b), vp(x), vp(x), vp(x), 5, vp(u8), vp(u8)))
+    prm = LevParams(100000.0, 1.0, 1.0, 0.3, 0.06, 0.0003, 5.0, 0.0)
+    i32 = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    with pytest.raises(pq.PqError, match="all eight"):
+        check(L.pq_backtest_leveraged(h, C.byref(b), vp(x), vp(u8), vp(u8), None, C.byref(prm), vp(out), vp(out), vp(out), 4, None,
+                                      vp(i32), None, None, None, None, None, None, None, None))
+    # a call that cannot be recorded fails inside a suite; after the abort the context computes again
+    check(L.pq_suite_begin(h, C.byref(b)))
+    with pytest.raises(pq.PqError, match="recorded"):
+        check(L.pq_factor_ic(h, C.byref(b), vp(x), vp(x), 0, vp(ic), None))
+    check(L.pq_suite_abort(h))
+    with pytest.raises(TypeError):
+        api.call("sma", x, timeperiod=5, bogus=1)
+    (got,) = api.call("sma", x, timeperiod=5)
+    (exp,) = oracle.call("sma", data["close"], timeperiod=5)
+    assert_same("sma-after-errors", got.cpu().numpy(), exp)
+
+
 def test_numpy_and_arrow_roundtrip(pq, oracle, data):
     import pyarrow as pa
     x = data["close"][0].copy()
