@@ -114,6 +114,9 @@ pq_status pq_aroon(pq_ctx *, const pq_batch *, const double *high, const double 
                    double *aroon_up, double *aroon_down);                                                       /* :70 */
 pq_status pq_aroonosc(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
                       double *out);                                                             /* momentum.py:40 */
+/* AROON and AROONOSC of the same timeperiod from one window scan (multi-output form, like pq_dmi_all) */
+pq_status pq_aroon_all(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
+                       double *aroon_up, double *aroon_down, double *aroonosc);
 pq_status pq_bop(pq_ctx *, const pq_batch *, const double *open, const double *high, const double *low,
                  const double *close, double *out);                                                             /* :113 */
 pq_status pq_cci(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,

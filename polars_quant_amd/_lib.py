@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
                           [C.c_int64 if k == I else C.c_double for _, k, _ in params] + [vp] * len(outs)
         L.pq_dmi_all.restype = C.c_int32
         L.pq_dmi_all.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+        L.pq_aroon_all.restype = C.c_int32
+        L.pq_aroon_all.argtypes = [vp, C.POINTER(Batch), vp, vp, C.c_int64, vp, vp, vp]
         L.pq_ht_all.restype = C.c_int32
         L.pq_ht_all.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp, vp, vp, vp]
         L.pq_cdl.restype = C.c_int32

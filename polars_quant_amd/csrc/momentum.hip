@@ -37,6 +37,11 @@ pq_status pq_aroonosc(pq_ctx *ctx, const pq_batch *b, const double *h, const dou
     AroonOp<1> op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<2>{{h, l}}, OutColsT<AroonOp<1>, double>{{out}});
 }
+pq_status pq_aroon_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *up, double *dn, double *osc) {
+    CHK("pq_aroon_all", h && l && up && dn && osc);
+    AroonOp<2> op{}; op.p = p;
+    return launch_row(ctx, b, op, InCols<2>{{h, l}}, OutColsT<AroonOp<2>, double>{{up, dn, osc}});
+}
 pq_status pq_willr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                    double *out) {
     CHK("pq_willr", h && l && c && out);

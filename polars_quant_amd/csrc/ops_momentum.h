@@ -36,10 +36,10 @@ struct BopOp { // momentum.rs:113-135
         y[0] = (diff == 0.0) ? 0.0 : (r.in[3][t] - r.in[0][t]) / diff;
     }
 };
-template <int MODE> // 0: (up, down)  1: up - down (AROONOSC, decision D-6)   momentum.rs:70-110
+template <int MODE> // 0: (up, down)  1: up - down (AROONOSC, decision D-6)  2: (up, down, up - down) in one scan   momentum.rs:70-110
 struct AroonOp {
-    static constexpr int ROW_ID = 14 + MODE;
-    static constexpr int NIN = 2, NOUT = (MODE == 0 ? 2 : 1);
+    static constexpr int ROW_ID = MODE == 2 ? 17 : 14 + MODE;
+    static constexpr int NIN = 2, NOUT = (MODE == 0 ? 2 : (MODE == 1 ? 1 : 3));
     typedef double OutT;
     int64_t p;
     __device__ void eval(const Row<2> &r, int64_t t, double (&y)[NOUT]) {
@@ -54,7 +54,9 @@ struct AroonOp {
             if (l <= min_val) { min_val = l; min_idx = j - start; }
         }
         double up = ((double)max_idx / (double)p) * 100.0, dn = ((double)min_idx / (double)p) * 100.0;
-        if (MODE == 0) { y[0] = up; y[NOUT - 1] = dn; } else y[0] = up - dn;
+        if (MODE == 0) { y[0] = up; y[NOUT - 1] = dn; }
+        else if (MODE == 1) y[0] = up - dn;
+        else { y[0] = up; y[NOUT > 1 ? 1 : 0] = dn; y[NOUT - 1] = up - dn; }
     }
 };
 struct WillrOp { // momentum.rs:630-662

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
 struct RowJob { int kind; alignas(8) unsigned char blob[ROW_JOB_BLOB]; };
 #define ROW_OPS(X)                                                                                                   \
     X(PriceOp<0>) X(PriceOp<1>) X(PriceOp<2>) X(PriceOp<3>) X(TrangeOp) X(TrendlineOp) X(TrendmodeOp) X(LagOp<0>) X(LagOp<1>) \
-    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(WillrOp)
+    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(AroonOp<2>) X(WillrOp)
 __global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJob *jobs, int njobs, Dims d, int64_t s0) {
     const int64_t s = s0 + blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;

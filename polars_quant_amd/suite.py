@@ -69,6 +69,11 @@ class Suite:
             o = self.out
             check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
                                *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
+        elif name == "aroon_all":  # AROON + AROONOSC (both timeperiod=14 by default) from one window scan
+            o = self.out
+            check(L.pq_aroon_all(h, C.byref(b), C.c_void_p(ohlcv["high"].data_ptr()), C.c_void_p(ohlcv["low"].data_ptr()), 14,
+                                 C.c_void_p(o["aroon"][0].data_ptr()), C.c_void_p(o["aroon"][1].data_ptr()),
+                                 C.c_void_p(o["aroonosc"][0].data_ptr())))
         elif name == "ht_all":    # the Hilbert pipeline evaluated once for dcperiod / dcphase / phasor / sine
             o = self.out
             outs = [o["ht_dcperiod"][0], o["ht_dcphase"][0], o["ht_phasor"][0], o["ht_phasor"][1], o["ht_sine"][0], o["ht_sine"][1]]
@@ -84,7 +89,8 @@ class Suite:
                                            *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in outs]))
 
     FUSED = {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"),
-             "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine")}
+             "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"),
+             "aroon_all": ("aroon", "aroonosc")}
 
     def tasks(self, fused: bool = False):
         """every function of the suite; fused=True replaces the users of a shared core by the multi-output call"""

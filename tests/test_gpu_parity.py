@@ -558,3 +558,10 @@ def test_fused_multi_output_calls(pq, oracle, data):
            oracle.call("ht_phasor", data["close"]) + oracle.call("ht_sine", data["close"]))
     for i, (t, e) in enumerate(zip(outs, exp)):
         assert_same(f"ht_all[{i}]", t.cpu().numpy(), e, exact=False)
+    outs = [torch.empty((N_SYM, T), dtype=torch.float64, device="cuda") for _ in range(3)]
+    for p in (14, 3, 0):
+        check(lib().pq_aroon_all(api.ctx(0), C.byref(b), C.c_void_p(g["high"].data_ptr()), C.c_void_p(g["low"].data_ptr()), p,
+                                 *[C.c_void_p(t.data_ptr()) for t in outs]))
+        exp = oracle.call("aroon", data["high"], data["low"], timeperiod=p) + oracle.call("aroonosc", data["high"], data["low"], timeperiod=p)
+        for i, (t, e) in enumerate(zip(outs, exp)):
+            assert_same(f"aroon_all[{i}](p={p})", t.cpu().numpy(), e)
