@@ -114,6 +114,22 @@ pq_status pq_aroon(pq_ctx *, const pq_batch *, const double *high, const double 
                    double *aroon_up, double *aroon_down);                                                       /* :70 */
 pq_status pq_aroonosc(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
                       double *out);                                                             /* momentum.py:40 */
+/* Multi-output forms: several reference functions over the same inputs evaluated as ONE job (one in-tile, one walk); every
+ * output column is bit-identical to the single function's.  A DataFrame query that asks for several of them
+ * (df.with_columns([EMA, DEMA, TEMA, TRIX, ...])) maps onto these like common-subexpression elimination. */
+pq_status pq_ema_all(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *ema, double *dema, double *tema,
+                     double *trix);
+pq_status pq_atr_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, int64_t timeperiod,
+                     double *atr, double *natr);
+pq_status pq_dm_pair(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod, double *plus_dm,
+                     double *minus_dm);
+pq_status pq_ad_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, const double *volume,
+                    int64_t fastperiod, int64_t slowperiod, double *ad, double *adosc);
+pq_status pq_macd_pair(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod, int64_t signalperiod,
+                       int64_t macdfix_signalperiod, double *macd, double *macdsignal, double *macdhist, double *fix_macd,
+                       double *fix_signal, double *fix_hist);
+pq_status pq_apo_ppo(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod, int64_t matype,
+                     double *apo, double *ppo);
 /* AROON and AROONOSC of the same timeperiod from one window scan (multi-output form, like pq_dmi_all) */
 pq_status pq_aroon_all(pq_ctx *, const pq_batch *, const double *high, const double *low, int64_t timeperiod,
                        double *aroon_up, double *aroon_down, double *aroonosc);

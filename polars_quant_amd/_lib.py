@@ -64,6 +64,12 @@ def lib() -> C.CDLL:
                           [C.c_int64 if k == I else C.c_double for _, k, _ in params] + [vp] * len(outs)
         L.pq_dmi_all.restype = C.c_int32
         L.pq_dmi_all.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+        for nm, args in (("pq_ema_all", [vp, C.c_int64, vp, vp, vp, vp]), ("pq_atr_all", [vp, vp, vp, C.c_int64, vp, vp]),
+                         ("pq_dm_pair", [vp, vp, C.c_int64, vp, vp]), ("pq_ad_all", [vp, vp, vp, vp, C.c_int64, C.c_int64, vp, vp]),
+                         ("pq_macd_pair", [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp]),
+                         ("pq_apo_ppo", [vp, C.c_int64, C.c_int64, C.c_int64, vp, vp])):
+            getattr(L, nm).restype = C.c_int32
+            getattr(L, nm).argtypes = [vp, C.POINTER(Batch)] + args
         L.pq_aroon_all.restype = C.c_int32
         L.pq_aroon_all.argtypes = [vp, C.POINTER(Batch), vp, vp, C.c_int64, vp, vp, vp]
         L.pq_ht_all.restype = C.c_int32

@@ -111,4 +111,59 @@ pq_status pq_ht_all(pq_ctx *ctx, const pq_batch *b, const double *real, double *
     return launch_seq(ctx, b, HtAllOp{}, InCols<1>{{real}}, OutCols<6>{{dcperiod, dcphase, inphase, quadrature, sine, leadsine}});
 }
 
+// ---- multi-output forms: several reference functions over the same inputs as ONE job (bit-identical columns) ----
+pq_status pq_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *ema, double *dema, double *tema, double *trix) {
+    CHK("pq_ema_all", real && ema && dema && tema && trix);
+    EmaAllOp op{};
+    op.a.a.p = p; op.a.b.p = p; op.b.a.p = p; op.b.b.p = p;
+    InCols<1> in{{real}}; OutCols<4> o{{ema, dema, tema, trix}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_ema(ctx, b, real, p, ema)); PQ_TRY(pq_dema(ctx, b, real, p, dema)); PQ_TRY(pq_tema(ctx, b, real, p, tema));
+    return pq_trix(ctx, b, real, p, trix);
+}
+pq_status pq_atr_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *atr, double *natr) {
+    CHK("pq_atr_all", h && l && c && atr && natr);
+    AtrAllOp op{}; op.a.p = p; op.b.p = p;
+    InCols<3> in{{h, l, c}}; OutCols<2> o{{atr, natr}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_atr(ctx, b, h, l, c, p, atr));
+    return pq_natr(ctx, b, h, l, c, p, natr);
+}
+pq_status pq_dm_pair(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *plus_dm, double *minus_dm) {
+    CHK("pq_dm_pair", h && l && plus_dm && minus_dm);
+    DmPairOp op{}; op.a.p = p; op.b.p = p;
+    InCols<2> in{{h, l}}; OutCols<2> o{{plus_dm, minus_dm}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_plus_dm(ctx, b, h, l, p, plus_dm));
+    return pq_minus_dm(ctx, b, h, l, p, minus_dm);
+}
+pq_status pq_ad_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, const double *v, int64_t fast,
+                    int64_t slow, double *ad, double *adosc) {
+    CHK("pq_ad_all", h && l && c && v && ad && adosc);
+    AdAllOp op{}; op.a.fast = op.a.slow = 0; op.b.fast = fast; op.b.slow = slow;
+    InCols<4> in{{h, l, c, v}}; OutCols<2> o{{ad, adosc}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_ad(ctx, b, h, l, c, v, ad));
+    return pq_adosc(ctx, b, h, l, c, v, fast, slow, adosc);
+}
+pq_status pq_macd_pair(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t sig, int64_t fix_sig,
+                       double *macd, double *signal, double *hist, double *fmacd, double *fsignal, double *fhist) {
+    CHK("pq_macd_pair", real && macd && signal && hist && fmacd && fsignal && fhist);
+    MacdPairOp op{};
+    op.a.fast = fast; op.a.slow = slow; op.a.sig = sig; op.b.fast = 12; op.b.slow = 26; op.b.sig = fix_sig; // momentum.py:90-92
+    InCols<1> in{{real}}; OutCols<6> o{{macd, signal, hist, fmacd, fsignal, fhist}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_macd(ctx, b, real, fast, slow, sig, macd, signal, hist));
+    return pq_macdfix(ctx, b, real, fix_sig, fmacd, fsignal, fhist);
+}
+pq_status pq_apo_ppo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype, double *apo, double *ppo) {
+    CHK("pq_apo_ppo", real && apo && ppo);
+    ApoPpoOp op{};
+    op.a.fast = fast; op.a.slow = slow; op.a.matype = matype; op.b.fast = fast; op.b.slow = slow; op.b.matype = matype;
+    InCols<1> in{{real}}; OutCols<2> o{{apo, ppo}};
+    if (Ma2::supports(matype) && seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_apo(ctx, b, real, fast, slow, matype, apo));
+    return pq_ppo(ctx, b, real, fast, slow, matype, ppo);
+}
+
 } // extern "C"

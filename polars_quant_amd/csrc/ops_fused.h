@@ -409,3 +409,52 @@ struct MavpBlockOp {
         y[0] = sel;
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two SEQ ops over the SAME input columns as one job: one in-tile, one walk, the outputs side by side.  The sub-ops keep
+// their own state machines (bit-identical results); what is shared is the tile traffic, the per-tile hand-off and the
+// workgroup -- the expensive parts for short jobs.  Nests: Fuse2<ID, Fuse2<0, A, B>, Fuse2<0, C, D>>.
+template <int ID, class A, class B>
+struct Fuse2 {
+    static_assert(A::NIN == B::NIN, "fused ops must read the same input columns");
+    static_assert(!IsMasked<A>::value && !IsMasked<B>::value && !HasFinish<A>::value && !HasFinish<B>::value, "not fusable");
+    static_assert(NTap<A>::value == 0 || HasRings<A>::value, "tap-only ops cannot be fused");
+    static_assert(NTap<B>::value == 0 || HasRings<B>::value, "tap-only ops cannot be fused");
+    static constexpr int NIN = A::NIN, NOUT = A::NOUT + B::NOUT;
+    static constexpr int SEQ_ID = ID;
+    static constexpr bool LDS_ONLY = true; // (the gather driver's tap plumbing is per op)
+    A a;
+    B b;
+    __host__ __device__ int64_t ring_slots() const {
+        int64_t n = 0;
+        if constexpr (HasRings<A>::value) n += a.ring_slots();
+        if constexpr (HasRings<B>::value) n += b.ring_slots();
+        return n;
+    }
+    __device__ void init(const Row<NIN> &) {}
+    __device__ void init_lds(const Row<NIN> &r, RingAlloc &ra) {
+        if constexpr (HasRings<A>::value) a.init_lds(r, ra); else a.init(r);
+        if constexpr (HasRings<B>::value) b.init_lds(r, ra); else b.init(r);
+        row = r;
+    }
+    Row<NIN> row; // the ring-free sub-ops' step() takes it
+    __device__ void step(const Row<NIN> &, int64_t, const double (&)[NIN], double (&y)[NOUT]) {
+#pragma unroll
+        for (int k = 0; k < NOUT; k++) y[k] = pq_null();
+    }
+    __device__ void step_lds(int64_t t, const double (&x)[NIN], double (&y)[NOUT]) {
+        double ya[A::NOUT], yb[B::NOUT];
+        if constexpr (HasRings<A>::value) a.step_lds(t, x, ya); else a.step(row, t, x, ya);
+        if constexpr (HasRings<B>::value) b.step_lds(t, x, yb); else b.step(row, t, x, yb);
+#pragma unroll
+        for (int k = 0; k < A::NOUT; k++) y[k] = ya[k];
+#pragma unroll
+        for (int k = 0; k < B::NOUT; k++) y[A::NOUT + k] = yb[k];
+    }
+};
+typedef Fuse2<90, Fuse2<0, EmaOp, DemaOp>, Fuse2<0, TemaOp, TrixOp>> EmaAllOp; // ema, dema, tema, trix of one timeperiod
+typedef Fuse2<91, AtrOp<false>, AtrOp<true>> AtrAllOp;                          // atr, natr
+typedef Fuse2<92, DmRawOp<true>, DmRawOp<false>> DmPairOp;                      // plus_dm, minus_dm
+typedef Fuse2<93, AdOp<false>, AdOp<true>> AdAllOp;                             // ad, adosc
+typedef Fuse2<94, MacdOp, MacdOp> MacdPairOp;                                   // macd, macdfix
+typedef Fuse2<95, MaDiffOp<0>, MaDiffOp<1>> ApoPpoOp;                           // apo, ppo

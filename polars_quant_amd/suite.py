@@ -69,6 +69,23 @@ class Suite:
             o = self.out
             check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
                                *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
+        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo"):
+            # multi-output forms: the listed functions share their inputs and (default) parameters -> one job
+            o, P = self.out, lambda k: C.c_void_p(ohlcv[k].data_ptr())
+            O = lambda n, i=0: C.c_void_p(o[n][i].data_ptr())
+            if name == "ema_all":
+                check(L.pq_ema_all(h, C.byref(b), P("close"), 30, O("ema"), O("dema"), O("tema"), O("trix")))
+            elif name == "atr_all":
+                check(L.pq_atr_all(h, C.byref(b), P("high"), P("low"), P("close"), 14, O("atr"), O("natr")))
+            elif name == "dm_pair":
+                check(L.pq_dm_pair(h, C.byref(b), P("high"), P("low"), 14, O("plus_dm"), O("minus_dm")))
+            elif name == "ad_all":
+                check(L.pq_ad_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 3, 10, O("ad"), O("adosc")))
+            elif name == "macd_pair":
+                check(L.pq_macd_pair(h, C.byref(b), P("close"), 12, 26, 9, 9, O("macd", 0), O("macd", 1), O("macd", 2),
+                                     O("macdfix", 0), O("macdfix", 1), O("macdfix", 2)))
+            else:
+                check(L.pq_apo_ppo(h, C.byref(b), P("close"), 12, 26, 0, O("apo"), O("ppo")))
         elif name == "aroon_all":  # AROON + AROONOSC (both timeperiod=14 by default) from one window scan
             o = self.out
             check(L.pq_aroon_all(h, C.byref(b), C.c_void_p(ohlcv["high"].data_ptr()), C.c_void_p(ohlcv["low"].data_ptr()), 14,
@@ -90,7 +107,9 @@ class Suite:
 
     FUSED = {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"),
              "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"),
-             "aroon_all": ("aroon", "aroonosc")}
+             "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), "atr_all": ("atr", "natr"),
+             "dm_pair": ("plus_dm", "minus_dm"), "ad_all": ("ad", "adosc"), "apo_ppo": ("apo", "ppo")}
+    # (pq_macd_pair exists too, but its six output tiles would raise the LDS charge of the whole 14..28 KB grid)
 
     def tasks(self, fused: bool = False):
         """every function of the suite; fused=True replaces the users of a shared core by the multi-output call"""

@@ -558,6 +558,31 @@ def test_fused_multi_output_calls(pq, oracle, data):
            oracle.call("ht_phasor", data["close"]) + oracle.call("ht_sine", data["close"]))
     for i, (t, e) in enumerate(zip(outs, exp)):
         assert_same(f"ht_all[{i}]", t.cpu().numpy(), e, exact=False)
+    # Fuse2 forms: every column equals the single function's
+    g2 = {k: torch.from_numpy(data[k]).cuda() for k in ("open", "high", "low", "close", "volume")}
+    P = lambda k: C.c_void_p(g2[k].data_ptr())
+    mk = lambda n: [torch.empty((N_SYM, T), dtype=torch.float64, device="cuda") for _ in range(n)]
+    V = lambda ts: [C.c_void_p(t.data_ptr()) for t in ts]
+    cases = []
+    for p in (30, 3, 1):
+        o = mk(4); check(lib().pq_ema_all(api.ctx(0), C.byref(b), P("close"), p, *V(o)))
+        cases.append((f"ema_all(p={p})", o, [oracle.call(n, data["close"], timeperiod=p)[0] for n in ("ema", "dema", "tema", "trix")]))
+    o = mk(2); check(lib().pq_atr_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), 14, *V(o)))
+    cases.append(("atr_all", o, [oracle.call(n, data["high"], data["low"], data["close"], timeperiod=14)[0] for n in ("atr", "natr")]))
+    o = mk(2); check(lib().pq_dm_pair(api.ctx(0), C.byref(b), P("high"), P("low"), 14, *V(o)))
+    cases.append(("dm_pair", o, [oracle.call(n, data["high"], data["low"], timeperiod=14)[0] for n in ("plus_dm", "minus_dm")]))
+    o = mk(2); check(lib().pq_ad_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), P("volume"), 3, 10, *V(o)))
+    cases.append(("ad_all", o, [oracle.call("ad", data["high"], data["low"], data["close"], data["volume"])[0],
+                                oracle.call("adosc", data["high"], data["low"], data["close"], data["volume"], fastperiod=3, slowperiod=10)[0]]))
+    o = mk(6); check(lib().pq_macd_pair(api.ctx(0), C.byref(b), P("close"), 5, 13, 4, 9, *V(o)))
+    cases.append(("macd_pair", o, list(oracle.call("macd", data["close"], fastperiod=5, slowperiod=13, signalperiod=4)) +
+                  list(oracle.call("macdfix", data["close"], signalperiod=9))))
+    for mt in (0, 1):
+        o = mk(2); check(lib().pq_apo_ppo(api.ctx(0), C.byref(b), P("close"), 12, 26, mt, *V(o)))
+        cases.append((f"apo_ppo(mt={mt})", o, [oracle.call(n, data["close"], fastperiod=12, slowperiod=26, matype=mt)[0] for n in ("apo", "ppo")]))
+    for label, got, exp in cases:
+        for i, (t_, e) in enumerate(zip(got, exp)):
+            assert_same(f"{label}[{i}]", t_.cpu().numpy(), e)
     outs = [torch.empty((N_SYM, T), dtype=torch.float64, device="cuda") for _ in range(3)]
     for p in (14, 3, 0):
         check(lib().pq_aroon_all(api.ctx(0), C.byref(b), C.c_void_p(g["high"].data_ptr()), C.c_void_p(g["low"].data_ptr()), p,
