@@ -156,6 +156,18 @@ pq_status pq_macd_pair(pq_ctx *ctx, const pq_batch *b, const double *real, int64
     PQ_TRY(pq_macd(ctx, b, real, fast, slow, sig, macd, signal, hist));
     return pq_macdfix(ctx, b, real, fix_sig, fmacd, fsignal, fhist);
 }
+pq_status pq_stoch_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk, int64_t slowk,
+                       int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, int64_t fastd, int64_t fastd_mt, double *slowk_out,
+                       double *slowd_out, double *fastk_out, double *fastd_out) {
+    CHK("pq_stoch_all", h && l && c && slowk_out && slowd_out && fastk_out && fastd_out);
+    StochAllOp op{};
+    op.fastk = fastk; op.slowk = slowk; op.slowk_mt = slowk_mt; op.slowd = slowd; op.slowd_mt = slowd_mt; op.fastd = fastd; op.fastd_mt = fastd_mt;
+    InCols<3> in{{h, l, c}}; OutCols<4> o{{slowk_out, slowd_out, fastk_out, fastd_out}};
+    if (Ma2::supports(slowk_mt) && Ma2::supports(slowd_mt) && Ma2::supports(fastd_mt) && seq_can_lds(b, op, in, o))
+        return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_stoch(ctx, b, h, l, c, fastk, slowk, slowk_mt, slowd, slowd_mt, slowk_out, slowd_out));
+    return pq_stochf(ctx, b, h, l, c, fastk, fastd, fastd_mt, fastk_out, fastd_out);
+}
 pq_status pq_apo_ppo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t matype, double *apo, double *ppo) {
     CHK("pq_apo_ppo", real && apo && ppo);
     ApoPpoOp op{};

@@ -170,6 +170,31 @@ struct StochOp {
     }
 };
 
+// STOCH and STOCHF of the same fastk_period in one walk: the rolling-extrema core (the expensive part) is evaluated once;
+// slowk/slowd and fastd keep their own moving averages, so every column is bit-identical to the single function's.
+struct StochAllOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int NIN = 3, NOUT = 4; // -> slowk, slowd, fastk, fastd
+    static constexpr int SEQ_ID = 96;
+    int64_t fastk, slowk, slowk_mt, slowd, slowd_mt, fastd, fastd_mt;
+    FastkCore fk;
+    Ma2 mk, md, mf;
+    __host__ __device__ int64_t ring_slots() const {
+        return FastkCore::slots(fastk) + Ma2::slots(slowk_mt, slowk) + Ma2::slots(slowd_mt, slowd) + Ma2::slots(fastd_mt, fastd);
+    }
+    __device__ void init(const Row<3> &) {}
+    __device__ void init_lds(const Row<3> &r, RingAlloc &ra) {
+        fk.init(fastk, ra);
+        mk.init(slowk_mt, slowk, r.len, ra); md.init(slowd_mt, slowd, r.len, ra); mf.init(fastd_mt, fastd, r.len, ra);
+    }
+    __device__ void step(const Row<3> &, int64_t, const double (&)[3], double (&y)[4]) { y[0] = y[1] = y[2] = y[3] = pq_null(); }
+    __device__ void step_lds(int64_t, const double (&x)[3], double (&y)[4]) {
+        const double k = fk.step(x[0], x[1], x[2]);
+        const double a = mk.step(k);
+        y[0] = a; y[1] = md.step(a); y[2] = k; y[3] = mf.step(k);
+    }
+};
+
 struct StochRsiOp {
     static constexpr bool LDS_ONLY = true; // momentum.py:197-205
     static constexpr int NIN = 1, NOUT = 2;
@@ -458,3 +483,4 @@ typedef Fuse2<92, DmRawOp<true>, DmRawOp<false>> DmPairOp;                      
 typedef Fuse2<93, AdOp<false>, AdOp<true>> AdAllOp;                             // ad, adosc
 typedef Fuse2<94, MacdOp, MacdOp> MacdPairOp;                                   // macd, macdfix
 typedef Fuse2<95, MaDiffOp<0>, MaDiffOp<1>> ApoPpoOp;                           // apo, ppo
+typedef Fuse2<97, SarextOp, SarextOp> SarPairOp;                                // sar, sarext

@@ -136,8 +136,8 @@ struct pq_suite {
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(HtOp<4>) X(BtMacdOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
-    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp) X(StochOp<0>)
-static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == 74 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
+    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
+static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == 74 || kind == 96 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
 
 // V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
@@ -238,6 +238,7 @@ static int job_cost(int kind) {
     case 76: return 260;                       // stochrsi
     case SEQ_ID_BACKTEST: case SEQ_ID_BACKTEST + 1: case 62: return 250;
     case 74: case 78: case 80: case 77: return 235; // stoch, dm family, cci
+    case 96: return 260;                       // stoch + stochf
     case 26: case 27: case 28: return 200;
     case 75: return 200;                       // stochf
     case 24: return 180;                       // ultosc

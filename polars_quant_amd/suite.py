@@ -69,7 +69,7 @@ class Suite:
             o = self.out
             check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
                                *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
-        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo"):
+        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all"):
             # multi-output forms: the listed functions share their inputs and (default) parameters -> one job
             o, P = self.out, lambda k: C.c_void_p(ohlcv[k].data_ptr())
             O = lambda n, i=0: C.c_void_p(o[n][i].data_ptr())
@@ -81,6 +81,9 @@ class Suite:
                 check(L.pq_dm_pair(h, C.byref(b), P("high"), P("low"), 14, O("plus_dm"), O("minus_dm")))
             elif name == "ad_all":
                 check(L.pq_ad_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 3, 10, O("ad"), O("adosc")))
+            elif name == "stoch_all":
+                check(L.pq_stoch_all(h, C.byref(b), P("high"), P("low"), P("close"), 5, 3, 0, 3, 0, 3, 0, O("stoch", 0), O("stoch", 1),
+                                     O("stochf", 0), O("stochf", 1)))
             elif name == "macd_pair":
                 check(L.pq_macd_pair(h, C.byref(b), P("close"), 12, 26, 9, 9, O("macd", 0), O("macd", 1), O("macd", 2),
                                      O("macdfix", 0), O("macdfix", 1), O("macdfix", 2)))
@@ -109,6 +112,8 @@ class Suite:
              "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"),
              "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), "atr_all": ("atr", "natr"),
              "dm_pair": ("plus_dm", "minus_dm"), "ad_all": ("ad", "adosc"), "apo_ppo": ("apo", "ppo")}
+    # pq_stoch_all (STOCH + STOCHF, 199 VGPRs -> the register-heavy kernel) is NOT used here: beside the Hilbert job it makes that
+    # chain the critical path (+6 % per step, measured); it pays when STOCH/STOCHF are asked for on their own
     # (pq_macd_pair exists too, but its six output tiles would raise the LDS charge of the whole 14..28 KB grid)
 
     def tasks(self, fused: bool = False):

@@ -580,6 +580,12 @@ def test_fused_multi_output_calls(pq, oracle, data):
     for mt in (0, 1):
         o = mk(2); check(lib().pq_apo_ppo(api.ctx(0), C.byref(b), P("close"), 12, 26, mt, *V(o)))
         cases.append((f"apo_ppo(mt={mt})", o, [oracle.call(n, data["close"], fastperiod=12, slowperiod=26, matype=mt)[0] for n in ("apo", "ppo")]))
+    for fk, sk, skm, sd, sdm, fd, fdm in ((5, 3, 0, 3, 0, 3, 0), (14, 3, 1, 5, 0, 4, 1)):
+        o = mk(4); check(lib().pq_stoch_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), fk, sk, skm, sd, sdm, fd, fdm, *V(o)))
+        cases.append((f"stoch_all({fk},{sk},{skm},{sd},{sdm},{fd},{fdm})", o,
+                      list(oracle.call("stoch", data["high"], data["low"], data["close"], fastk_period=fk, slowk_period=sk, slowk_matype=skm,
+                                       slowd_period=sd, slowd_matype=sdm)) +
+                      list(oracle.call("stochf", data["high"], data["low"], data["close"], fastk_period=fk, fastd_period=fd, fastd_matype=fdm))))
     for label, got, exp in cases:
         for i, (t_, e) in enumerate(zip(got, exp)):
             assert_same(f"{label}[{i}]", t_.cpu().numpy(), e)
