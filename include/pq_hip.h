@@ -128,6 +128,10 @@ pq_status pq_ad_all(pq_ctx *, const pq_batch *, const double *high, const double
 pq_status pq_macd_pair(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod, int64_t signalperiod,
                        int64_t macdfix_signalperiod, double *macd, double *macdsignal, double *macdhist, double *fix_macd,
                        double *fix_signal, double *fix_hist);
+pq_status pq_sar_pair(pq_ctx *, const pq_batch *, const double *high, const double *low, double acceleration, double maximum,
+                      double startvalue, double offsetonreverse, double accelerationinitlong, double accelerationlong,
+                      double accelerationmaxlong, double accelerationinitshort, double accelerationshort,
+                      double accelerationmaxshort, double *sar, double *sarext);
 /* STOCH + STOCHF of one fastk_period: the rolling extrema are evaluated once */
 pq_status pq_stoch_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, int64_t fastk_period,
                        int64_t slowk_period, int64_t slowk_matype, int64_t slowd_period, int64_t slowd_matype, int64_t fastd_period,

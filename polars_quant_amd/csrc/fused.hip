@@ -156,6 +156,20 @@ pq_status pq_macd_pair(pq_ctx *ctx, const pq_batch *b, const double *real, int64
     PQ_TRY(pq_macd(ctx, b, real, fast, slow, sig, macd, signal, hist));
     return pq_macdfix(ctx, b, real, fix_sig, fmacd, fsignal, fhist);
 }
+pq_status pq_sar_pair(pq_ctx *ctx, const pq_batch *b, const double *high, const double *low, double accel, double maxv, double startvalue,
+                      double offsetonreverse, double ai_long, double a_long, double am_long, double ai_short, double a_short,
+                      double am_short, double *sar, double *sarext) {
+    CHK("pq_sar_pair", high && low && sar && sarext);
+    SarPairOp op{};
+    op.a.ext = false; op.a.startvalue = 0.0; op.a.offset = 0.0;
+    op.a.ai_long = op.a.a_long = op.a.ai_short = op.a.a_short = accel; op.a.am_long = op.a.am_short = maxv;
+    op.b.ext = true; op.b.startvalue = startvalue; op.b.offset = offsetonreverse;
+    op.b.ai_long = ai_long; op.b.a_long = a_long; op.b.am_long = am_long; op.b.ai_short = ai_short; op.b.a_short = a_short; op.b.am_short = am_short;
+    InCols<2> in{{high, low}}; OutCols<2> o{{sar, sarext}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_sar(ctx, b, high, low, accel, maxv, sar));
+    return pq_sarext(ctx, b, high, low, startvalue, offsetonreverse, ai_long, a_long, am_long, ai_short, a_short, am_short, sarext);
+}
 pq_status pq_stoch_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk, int64_t slowk,
                        int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, int64_t fastd, int64_t fastd_mt, double *slowk_out,
                        double *slowd_out, double *fastk_out, double *fastd_out) {

@@ -580,6 +580,13 @@ def test_fused_multi_output_calls(pq, oracle, data):
     for mt in (0, 1):
         o = mk(2); check(lib().pq_apo_ppo(api.ctx(0), C.byref(b), P("close"), 12, 26, mt, *V(o)))
         cases.append((f"apo_ppo(mt={mt})", o, [oracle.call(n, data["close"], fastperiod=12, slowperiod=26, matype=mt)[0] for n in ("apo", "ppo")]))
+    o = mk(2); check(lib().pq_sar_pair(api.ctx(0), C.byref(b), P("high"), P("low"), C.c_double(0.02), C.c_double(0.2), C.c_double(0.0),
+                                         C.c_double(0.01), C.c_double(0.02), C.c_double(0.02), C.c_double(0.2), C.c_double(0.03),
+                                         C.c_double(0.03), C.c_double(0.3), *V(o)))
+    cases.append(("sar_pair", o, [oracle.call("sar", data["high"], data["low"], acceleration=0.02, maximum=0.2)[0],
+                                  oracle.call("sarext", data["high"], data["low"], startvalue=0.0, offsetonreverse=0.01, accelerationinitlong=0.02,
+                                              accelerationlong=0.02, accelerationmaxlong=0.2, accelerationinitshort=0.03,
+                                              accelerationshort=0.03, accelerationmaxshort=0.3)[0]]))
     for fk, sk, skm, sd, sdm, fd, fdm in ((5, 3, 0, 3, 0, 3, 0), (14, 3, 1, 5, 0, 4, 1)):
         o = mk(4); check(lib().pq_stoch_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), fk, sk, skm, sd, sdm, fd, fdm, *V(o)))
         cases.append((f"stoch_all({fk},{sk},{skm},{sd},{sdm},{fd},{fdm})", o,
