@@ -128,6 +128,10 @@ pq_status pq_ad_all(pq_ctx *, const pq_batch *, const double *high, const double
 pq_status pq_macd_pair(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod, int64_t signalperiod,
                        int64_t macdfix_signalperiod, double *macd, double *macdsignal, double *macdhist, double *fix_macd,
                        double *fix_signal, double *fix_hist);
+/* the volume family over (high, low, close, volume): MFI + AD + ADOSC + OBV as one job (4 in / 4 out: MFI's own LDS need) */
+pq_status pq_volume_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, const double *volume,
+                        int64_t mfi_timeperiod, int64_t adosc_fastperiod, int64_t adosc_slowperiod, double *mfi, double *ad,
+                        double *adosc, double *obv);
 pq_status pq_sar_pair(pq_ctx *, const pq_batch *, const double *high, const double *low, double acceleration, double maximum,
                       double startvalue, double offsetonreverse, double accelerationinitlong, double accelerationlong,
                       double accelerationmaxlong, double accelerationinitshort, double accelerationshort,

@@ -69,7 +69,8 @@ def lib() -> C.CDLL:
                          ("pq_macd_pair", [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp]),
                          ("pq_apo_ppo", [vp, C.c_int64, C.c_int64, C.c_int64, vp, vp]),
                          ("pq_stoch_all", [vp, vp, vp] + [C.c_int64] * 7 + [vp] * 4),
-                         ("pq_sar_pair", [vp, vp] + [C.c_double] * 10 + [vp, vp])):
+                         ("pq_sar_pair", [vp, vp] + [C.c_double] * 10 + [vp, vp]),
+                         ("pq_volume_all", [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp])):
             getattr(L, nm).restype = C.c_int32
             getattr(L, nm).argtypes = [vp, C.POINTER(Batch)] + args
         L.pq_aroon_all.restype = C.c_int32

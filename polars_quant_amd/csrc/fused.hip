@@ -170,6 +170,17 @@ pq_status pq_sar_pair(pq_ctx *ctx, const pq_batch *b, const double *high, const 
     PQ_TRY(pq_sar(ctx, b, high, low, accel, maxv, sar));
     return pq_sarext(ctx, b, high, low, startvalue, offsetonreverse, ai_long, a_long, am_long, ai_short, a_short, am_short, sarext);
 }
+pq_status pq_volume_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, const double *v, int64_t mfi_p,
+                        int64_t fast, int64_t slow, double *mfi, double *ad, double *adosc, double *obv) {
+    CHK("pq_volume_all", h && l && c && v && mfi && ad && adosc && obv);
+    VolumeAllOp op{};
+    op.a.p = mfi_p; op.b.a.a.fast = op.b.a.a.slow = 0; op.b.a.b.fast = fast; op.b.a.b.slow = slow;
+    InCols<4> in{{h, l, c, v}}; OutCols<4> o{{mfi, ad, adosc, obv}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_mfi(ctx, b, h, l, c, v, mfi_p, mfi)); PQ_TRY(pq_ad(ctx, b, h, l, c, v, ad));
+    PQ_TRY(pq_adosc(ctx, b, h, l, c, v, fast, slow, adosc));
+    return pq_obv(ctx, b, c, v, obv);
+}
 pq_status pq_stoch_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk, int64_t slowk,
                        int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, int64_t fastd, int64_t fastd_mt, double *slowk_out,
                        double *slowd_out, double *fastk_out, double *fastd_out) {

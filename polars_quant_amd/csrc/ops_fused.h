@@ -477,6 +477,19 @@ struct Fuse2 {
         for (int k = 0; k < B::NOUT; k++) y[A::NOUT + k] = yb[k];
     }
 };
+// A ring-free op that reads a SUBSET (I0, I1) of a wider job's input columns
+template <int NIN_, class Op, int I0, int I1>
+struct Pick2 {
+    static_assert(Op::NIN == 2 && !HasRings<Op>::value && NTap<Op>::value == 0, "Pick2 wraps a plain two-input op");
+    static constexpr int NIN = NIN_, NOUT = Op::NOUT;
+    Op op;
+    Row<2> rr;
+    __device__ void init(const Row<NIN> &r) { rr.in[0] = r.in[I0]; rr.in[1] = r.in[I1]; rr.len = r.len; op.init(rr); }
+    __device__ void step(const Row<NIN> &, int64_t t, const double (&x)[NIN], double (&y)[NOUT]) {
+        const double xx[2] = {x[I0], x[I1]};
+        op.step(rr, t, xx, y);
+    }
+};
 typedef Fuse2<90, Fuse2<0, EmaOp, DemaOp>, Fuse2<0, TemaOp, TrixOp>> EmaAllOp; // ema, dema, tema, trix of one timeperiod
 typedef Fuse2<91, AtrOp<false>, AtrOp<true>> AtrAllOp;                          // atr, natr
 typedef Fuse2<92, DmRawOp<true>, DmRawOp<false>> DmPairOp;                      // plus_dm, minus_dm
@@ -484,3 +497,4 @@ typedef Fuse2<93, AdOp<false>, AdOp<true>> AdAllOp;                             
 typedef Fuse2<94, MacdOp, MacdOp> MacdPairOp;                                   // macd, macdfix
 typedef Fuse2<95, MaDiffOp<0>, MaDiffOp<1>> ApoPpoOp;                           // apo, ppo
 typedef Fuse2<97, SarextOp, SarextOp> SarPairOp;                                // sar, sarext
+typedef Fuse2<98, MfiOp, Fuse2<0, AdAllOp, Pick2<4, ObvOp, 2, 3>>> VolumeAllOp; // mfi, ad, adosc, obv: 4 in / 4 out, MFI's LDS

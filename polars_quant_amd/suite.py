@@ -69,7 +69,7 @@ class Suite:
             o = self.out
             check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
                                *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
-        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all", "sar_pair"):
+        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all", "sar_pair", "volume_all"):
             # multi-output forms: the listed functions share their inputs and (default) parameters -> one job
             o, P = self.out, lambda k: C.c_void_p(ohlcv[k].data_ptr())
             O = lambda n, i=0: C.c_void_p(o[n][i].data_ptr())
@@ -81,6 +81,9 @@ class Suite:
                 check(L.pq_dm_pair(h, C.byref(b), P("high"), P("low"), 14, O("plus_dm"), O("minus_dm")))
             elif name == "ad_all":
                 check(L.pq_ad_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 3, 10, O("ad"), O("adosc")))
+            elif name == "volume_all":
+                check(L.pq_volume_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 14, 3, 10, O("mfi"), O("ad"), O("adosc"),
+                                      O("obv")))
             elif name == "sar_pair":   # Python-wrapper defaults: every parameter 0.0 (overlap.py:115-157)
                 check(L.pq_sar_pair(h, C.byref(b), P("high"), P("low"), *([C.c_double(0.0)] * 10), O("sar"), O("sarext")))
             elif name == "stoch_all":
@@ -113,8 +116,8 @@ class Suite:
     FUSED = {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"),
              "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"),
              "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), "atr_all": ("atr", "natr"),
-             "dm_pair": ("plus_dm", "minus_dm"), "ad_all": ("ad", "adosc"), "apo_ppo": ("apo", "ppo"),
-             "sar_pair": ("sar", "sarext")}
+             "dm_pair": ("plus_dm", "minus_dm"), "apo_ppo": ("apo", "ppo"),
+             "sar_pair": ("sar", "sarext"), "volume_all": ("mfi", "ad", "adosc", "obv")}
     # pq_stoch_all (STOCH + STOCHF, 199 VGPRs -> the register-heavy kernel) is NOT used here: beside the Hilbert job it makes that
     # chain the critical path (+6 % per step, measured); it pays when STOCH/STOCHF are asked for on their own
     # (pq_macd_pair exists too, but its six output tiles would raise the LDS charge of the whole 14..28 KB grid)
@@ -123,7 +126,13 @@ class Suite:
         """every function of the suite; fused=True replaces the users of a shared core by the multi-output call"""
         names = list(SPEC)
         if fused:
-            covered = {n for v in self.FUSED.values() for n in v}
+            import os
+            skip = set(filter(None, os.environ.get("PQ_SUITE_UNFUSE", "").split(",")))   # A/B runs: keep these as separate calls
+            fused_map = {k: v for k, v in self.FUSED.items() if k not in skip}
+            covered = {n for v in fused_map.values() for n in v}
+            return [n for n in names if n not in covered] + list(fused_map) + ["cdl_all", "backtest_macd_cross"]
+        if False:
+            covered = set()
             names = [n for n in names if n not in covered] + list(self.FUSED)
         return names + ["cdl_all", "backtest_macd_cross"]
 

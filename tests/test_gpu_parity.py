@@ -587,6 +587,10 @@ def test_fused_multi_output_calls(pq, oracle, data):
                                   oracle.call("sarext", data["high"], data["low"], startvalue=0.0, offsetonreverse=0.01, accelerationinitlong=0.02,
                                               accelerationlong=0.02, accelerationmaxlong=0.2, accelerationinitshort=0.03,
                                               accelerationshort=0.03, accelerationmaxshort=0.3)[0]]))
+    o = mk(4); check(lib().pq_volume_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), P("volume"), 14, 3, 10, *V(o)))
+    hlcv = [data[k] for k in ("high", "low", "close", "volume")]
+    cases.append(("volume_all", o, [oracle.call("mfi", *hlcv, timeperiod=14)[0], oracle.call("ad", *hlcv)[0],
+                                    oracle.call("adosc", *hlcv, fastperiod=3, slowperiod=10)[0], oracle.call("obv", data["close"], data["volume"])[0]]))
     for fk, sk, skm, sd, sdm, fd, fdm in ((5, 3, 0, 3, 0, 3, 0), (14, 3, 1, 5, 0, 4, 1)):
         o = mk(4); check(lib().pq_stoch_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), fk, sk, skm, sd, sdm, fd, fdm, *V(o)))
         cases.append((f"stoch_all({fk},{sk},{skm},{sd},{sdm},{fd},{fdm})", o,
