@@ -128,6 +128,11 @@ pq_status pq_ad_all(pq_ctx *, const pq_batch *, const double *high, const double
 pq_status pq_macd_pair(pq_ctx *, const pq_batch *, const double *real, int64_t fastperiod, int64_t slowperiod, int64_t signalperiod,
                        int64_t macdfix_signalperiod, double *macd, double *macdsignal, double *macdhist, double *fix_macd,
                        double *fix_signal, double *fix_hist);
+/* Wilder's directional system over (high, low, close): DX, +DI, -DI, ADX, ADXR and ATR, NATR of one timeperiod as one job */
+pq_status pq_dm_system_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, int64_t timeperiod,
+                           double *dx, double *plus_di, double *minus_di, double *adx, double *adxr, double *atr, double *natr);
+/* the two up/down-move oscillators of one timeperiod as one job */
+pq_status pq_cmo_rsi(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *cmo, double *rsi);
 /* the volume family over (high, low, close, volume): MFI + AD + ADOSC + OBV as one job (4 in / 4 out: MFI's own LDS need) */
 pq_status pq_volume_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, const double *volume,
                         int64_t mfi_timeperiod, int64_t adosc_fastperiod, int64_t adosc_slowperiod, double *mfi, double *ad,

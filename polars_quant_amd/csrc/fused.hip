@@ -181,6 +181,23 @@ pq_status pq_volume_all(pq_ctx *ctx, const pq_batch *b, const double *h, const d
     PQ_TRY(pq_adosc(ctx, b, h, l, c, v, fast, slow, adosc));
     return pq_obv(ctx, b, c, v, obv);
 }
+pq_status pq_dm_system_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *dx,
+                           double *plus_di, double *minus_di, double *adx, double *adxr, double *atr, double *natr) {
+    CHK("pq_dm_system_all", h && l && c && dx && plus_di && minus_di && adx && adxr && atr && natr);
+    DmiAtrOp op{}; op.a.p = p; op.b.a.p = p; op.b.b.p = p;
+    InCols<3> in{{h, l, c}}; OutCols<7> o{{dx, plus_di, minus_di, adx, adxr, atr, natr}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_dmi_all(ctx, b, h, l, c, p, dx, plus_di, minus_di, adx, adxr));
+    return pq_atr_all(ctx, b, h, l, c, p, atr, natr);
+}
+pq_status pq_cmo_rsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *cmo, double *rsi) {
+    CHK("pq_cmo_rsi", real && cmo && rsi);
+    CmoRsiOp op{}; op.a.p = p; op.b.p = p;
+    InCols<1> in{{real}}; OutCols<2> o{{cmo, rsi}};
+    if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_cmo(ctx, b, real, p, cmo));
+    return pq_rsi(ctx, b, real, p, rsi);
+}
 pq_status pq_stoch_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t fastk, int64_t slowk,
                        int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, int64_t fastd, int64_t fastd_mt, double *slowk_out,
                        double *slowd_out, double *fastk_out, double *fastd_out) {

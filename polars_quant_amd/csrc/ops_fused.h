@@ -497,4 +497,6 @@ typedef Fuse2<93, AdOp<false>, AdOp<true>> AdAllOp;                             
 typedef Fuse2<94, MacdOp, MacdOp> MacdPairOp;                                   // macd, macdfix
 typedef Fuse2<95, MaDiffOp<0>, MaDiffOp<1>> ApoPpoOp;                           // apo, ppo
 typedef Fuse2<97, SarextOp, SarextOp> SarPairOp;                                // sar, sarext
+typedef Fuse2<99, DmAllOp<true>, AtrAllOp> DmiAtrOp;                             // dx, +di, -di, adx, adxr, atr, natr
+typedef Fuse2<89, CmoOp, RsiOp> CmoRsiOp;                                       // cmo, rsi
 typedef Fuse2<98, MfiOp, Fuse2<0, AdAllOp, Pick2<4, ObvOp, 2, 3>>> VolumeAllOp; // mfi, ad, adosc, obv: 4 in / 4 out, MFI's LDS

@@ -134,7 +134,7 @@ struct pq_suite {
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<0>) X(MavpBlockOp<1>) X(MavpSma16Op)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(HtOp<4>) X(BtMacdOp)                                     \
-    X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp)
+    X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
     X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
 static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == 74 || kind == 96 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
@@ -236,6 +236,8 @@ static int job_cost(int kind) {
     case 94: case 95: case 93: return 120;     // macd pair, apo + ppo, ad + adosc
     case 97: return 150;                       // sar + sarext
     case 98: return 300;                       // mfi + ad + adosc + obv
+    case 99: return 260;                       // dm family + atr + natr
+    case 89: return 130;                       // cmo + rsi
     case 91: case 92: return 85;               // atr + natr, +dm / -dm
     case 76: return 260;                       // stochrsi
     case SEQ_ID_BACKTEST: case SEQ_ID_BACKTEST + 1: case 62: return 250;

@@ -69,7 +69,7 @@ class Suite:
             o = self.out
             check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
                                *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
-        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all", "sar_pair", "volume_all"):
+        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all", "sar_pair", "volume_all", "dm_system_all", "cmo_rsi"):
             # multi-output forms: the listed functions share their inputs and (default) parameters -> one job
             o, P = self.out, lambda k: C.c_void_p(ohlcv[k].data_ptr())
             O = lambda n, i=0: C.c_void_p(o[n][i].data_ptr())
@@ -81,6 +81,11 @@ class Suite:
                 check(L.pq_dm_pair(h, C.byref(b), P("high"), P("low"), 14, O("plus_dm"), O("minus_dm")))
             elif name == "ad_all":
                 check(L.pq_ad_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 3, 10, O("ad"), O("adosc")))
+            elif name == "dm_system_all":
+                check(L.pq_dm_system_all(h, C.byref(b), P("high"), P("low"), P("close"), 14, O("dx"), O("plus_di"), O("minus_di"), O("adx"),
+                                         O("adxr"), O("atr"), O("natr")))
+            elif name == "cmo_rsi":
+                check(L.pq_cmo_rsi(h, C.byref(b), P("close"), 14, O("cmo"), O("rsi")))
             elif name == "volume_all":
                 check(L.pq_volume_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 14, 3, 10, O("mfi"), O("ad"), O("adosc"),
                                       O("obv")))
@@ -113,9 +118,9 @@ class Suite:
             check(getattr(L, "pq_" + name)(h, C.byref(b), *[C.c_void_p(self._col(ohlcv, c).data_ptr()) for c in cols],
                                            *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in outs]))
 
-    FUSED = {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"),
+    FUSED = {"dm_system_all": ("dx", "plus_di", "minus_di", "adx", "adxr", "atr", "natr"), "cmo_rsi": ("cmo", "rsi"),
              "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"),
-             "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), "atr_all": ("atr", "natr"),
+             "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), 
              "dm_pair": ("plus_dm", "minus_dm"), "apo_ppo": ("apo", "ppo"),
              "sar_pair": ("sar", "sarext"), "volume_all": ("mfi", "ad", "adosc", "obv")}
     # pq_stoch_all (STOCH + STOCHF, 199 VGPRs -> the register-heavy kernel) is NOT used here: beside the Hilbert job it makes that

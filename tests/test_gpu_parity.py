@@ -587,6 +587,11 @@ def test_fused_multi_output_calls(pq, oracle, data):
                                   oracle.call("sarext", data["high"], data["low"], startvalue=0.0, offsetonreverse=0.01, accelerationinitlong=0.02,
                                               accelerationlong=0.02, accelerationmaxlong=0.2, accelerationinitshort=0.03,
                                               accelerationshort=0.03, accelerationmaxshort=0.3)[0]]))
+    o = mk(7); check(lib().pq_dm_system_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), 14, *V(o)))
+    cases.append(("dm_system_all", o, [oracle.call(n, data["high"], data["low"], data["close"], timeperiod=14)[0]
+                                       for n in ("dx", "plus_di", "minus_di", "adx", "adxr", "atr", "natr")]))
+    o = mk(2); check(lib().pq_cmo_rsi(api.ctx(0), C.byref(b), P("close"), 14, *V(o)))
+    cases.append(("cmo_rsi", o, [oracle.call(n, data["close"], timeperiod=14)[0] for n in ("cmo", "rsi")]))
     o = mk(4); check(lib().pq_volume_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), P("volume"), 14, 3, 10, *V(o)))
     hlcv = [data[k] for k in ("high", "low", "close", "volume")]
     cases.append(("volume_all", o, [oracle.call("mfi", *hlcv, timeperiod=14)[0], oracle.call("ad", *hlcv)[0],
