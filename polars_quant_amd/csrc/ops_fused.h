@@ -175,6 +175,7 @@ struct StochOp {
 struct StochAllOp {
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 3, NOUT = 4; // -> slowk, slowd, fastk, fastd
+    static constexpr int ALG_COLS = 5 + 5;  // stoch, stochf
     static constexpr int SEQ_ID = 96;
     int64_t fastk, slowk, slowk_mt, slowd, slowd_mt, fastd, fastd_mt;
     FastkCore fk;
@@ -260,6 +261,7 @@ template <bool ALL> // ALL: the five columns; else adxr alone
 struct DmAllOp {
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 3, NOUT = ALL ? 5 : 1;
+    static constexpr int ALG_COLS = ALL ? 5 * 4 : 4; // dx, plus_di, minus_di, adx, adxr: five (3 in, 1 out) calls
     static constexpr int SEQ_ID = ALL ? 78 : 80;
     int64_t p;
     DmOp<2> core; // carries the three RMAs + the ADX RMA
@@ -286,6 +288,7 @@ struct DmAllOp {
 // cycle.rs: the shared Hilbert pipeline once for ht_dcperiod, ht_dcphase, ht_phasor and ht_sine
 struct HtAllOp {
     static constexpr int NIN = 1, NOUT = 6; // dcperiod, dcphase, inphase, quadrature, sine, leadsine
+    static constexpr int ALG_COLS = 2 + 2 + 3 + 3; // ht_dcperiod, ht_dcphase, ht_phasor, ht_sine
     static constexpr int SEQ_ID = 79;
     HtOp<0> core;
     __device__ void init(const Row<1> &r) { core.init(r); }
@@ -446,6 +449,7 @@ struct Fuse2 {
     static_assert(NTap<A>::value == 0 || HasRings<A>::value, "tap-only ops cannot be fused");
     static_assert(NTap<B>::value == 0 || HasRings<B>::value, "tap-only ops cannot be fused");
     static constexpr int NIN = A::NIN, NOUT = A::NOUT + B::NOUT;
+    static constexpr int ALG_COLS = AlgCols<A>::value + AlgCols<B>::value; // the calls it replaces
     static constexpr int SEQ_ID = ID;
     static constexpr bool LDS_ONLY = true; // (the gather driver's tap plumbing is per op)
     A a;
@@ -482,6 +486,7 @@ template <int NIN_, class Op, int I0, int I1>
 struct Pick2 {
     static_assert(Op::NIN == 2 && !HasRings<Op>::value && NTap<Op>::value == 0, "Pick2 wraps a plain two-input op");
     static constexpr int NIN = NIN_, NOUT = Op::NOUT;
+    static constexpr int ALG_COLS = AlgCols<Op>::value;
     Op op;
     Row<2> rr;
     __device__ void init(const Row<NIN> &r) { rr.in[0] = r.in[I0]; rr.in[1] = r.in[I1]; rr.len = r.len; op.init(rr); }

@@ -74,6 +74,12 @@ struct Dims {
 };
 static inline Dims dims_of(const pq_batch *b) { return Dims{b->n_series, b->len, b->stride}; }
 
+// Algorithmic column transfers a job is credited with (8 bytes per f64 column and row PER REFERENCE CALL): a plain
+// op is one call (NIN + NOUT); multi-output forms declare / sum the calls they replace.
+template <class Op, class = void>
+struct AlgCols { static constexpr int value = Op::NIN + Op::NOUT; };
+template <class Op>
+struct AlgCols<Op, decltype((void)Op::ALG_COLS)> { static constexpr int value = Op::ALG_COLS; };
 template <class Op, class = void>
 struct HasFinish { static constexpr bool value = false; }; // void finish(double *const *outp, const Dims &, int64_t s): per-series epilogue
 template <class Op>
@@ -533,7 +539,8 @@ __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK) void seq_kernel(Op
 // ---- recording hooks (implemented in suite.hip)
 // a recordable SEQ op carries `static constexpr int SEQ_ID` = its switch case in the job grid (suite.hip)
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write = nullptr);
+                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write = nullptr,
+                      int alg_cols = 0);
 struct RowThunk { // type-erased ROW launch for replay
     int kind = -1; // Op::ROW_ID when the op can run inside the fused row_jobs_kernel of a suite (blob = RowBlob<Op>), else -1
     void (*launch)(const void *blob, hipStream_t stream);
@@ -585,7 +592,7 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
             void *extra = nullptr;
             if constexpr (HasFinish<Op>::value) extra = op.finish_writes();
             return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0,
-                               SeqTile<Op>::BYTES, extra);
+                               SeqTile<Op>::BYTES, extra, AlgCols<Op>::value);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");
             return PQ_ERR_UNSUPPORTED;

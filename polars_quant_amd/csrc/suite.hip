@@ -18,6 +18,7 @@
 
 struct SeqJob { // device-visible
     int kind, nin, nout, cost;
+    int alg_cols;                  // f64 column transfers credited (per reference call)
     unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
     double *ring_ws;               // non-null: rings in global memory, [tile][slot][lane]
     unsigned long long ring_stride; // doubles per 64-symbol tile
@@ -298,13 +299,14 @@ static pq_status same_batch(Recorder &r, const pq_batch *b) {
 }
 
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write) {
+                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write, int alg_cols) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
     if (nin > 6 || nout > 8) { pq_set_error("internal: SEQ job has too many columns"); return PQ_ERR_UNSUPPORTED; }
     SeqJob j;
     memset(&j, 0, sizeof j);
     j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind); j.lds_bytes = (unsigned)lds_bytes; j.tile_bytes = (unsigned)tile_bytes;
+    j.alg_cols = alg_cols > 0 ? alg_cols : nin + nout;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
     memcpy(j.op, op, op_bytes);
@@ -422,10 +424,11 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             st.n_jobs++;
             if (j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1) { st.alg_bytes += 32.0 * rows + 64.0 * r.b.n_series; continue; }
             if (j.kind == 62) st.alg_bytes += 64.0 * r.b.n_series; // + the summary row
-            st.alg_bytes += 8.0 * rows * j.nin;
             const bool masked = (j.kind == 12) || (j.kind >= 100) || j.kind == 81 || j.kind == 82 || j.kind == 83;
+            if (!masked) { st.alg_bytes += 8.0 * rows * j.alg_cols; continue; }
+            st.alg_bytes += 8.0 * rows * j.nin; // jobs that share one output column row-disjointly: the column counts once
             for (int k = 0; k < j.nout; k++) {
-                if (masked) { if (masked_seen[g][j.out[k]]++) continue; }
+                if (masked_seen[g][j.out[k]]++) continue;
                 st.alg_bytes += 8.0 * rows;
             }
         }
