@@ -123,9 +123,10 @@ class Suite:
              "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), 
              "dm_pair": ("plus_dm", "minus_dm"), "apo_ppo": ("apo", "ppo"),
              "sar_pair": ("sar", "sarext"), "volume_all": ("mfi", "ad", "adosc", "obv")}
+    # pq_macd_pair is NOT used here either: six output tiles (27.6 KB) would raise the LDS charge of its whole grid, and on 4-row
+    # tiles it measured +3 % per step.
     # pq_stoch_all (STOCH + STOCHF, 199 VGPRs -> the register-heavy kernel) is NOT used here: beside the Hilbert job it makes that
     # chain the critical path (+6 % per step, measured); it pays when STOCH/STOCHF are asked for on their own
-    # (pq_macd_pair exists too, but its six output tiles would raise the LDS charge of the whole 14..28 KB grid)
 
     def tasks(self, fused: bool = False):
         """every function of the suite; fused=True replaces the users of a shared core by the multi-output call"""
