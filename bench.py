@@ -27,15 +27,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 
 
 def make_inputs(n_sym: int, T: int, seed: int, device):
-    """SURVEY 8(d) generator, evaluated on the device (same integer hash + f64 arithmetic as oracle/backtest.c)."""
-    from oracle import pq_oracle as oracle  # generator only: synthetic inputs, not part of the measured path
-    d = oracle.gen_ohlcv(seed, n_sym, T, 0)
+    """SURVEY 8(d) synthetic OHLCV (polars_quant_amd/synthetic.py: bit-identical to the generator the tests use)."""
+    from polars_quant_amd.synthetic import gen_ohlcv
+    d = gen_ohlcv(seed, n_sym, T, 0)
     return {k: torch.from_numpy(v).to(device) for k, v in d.items()}
 
 
 def cpu_baseline(sample_syms: int, T: int):
-    from oracle import pq_oracle as oracle
-    d = oracle.gen_ohlcv(SEED, sample_syms, T, 0)
+    from oracle import pq_oracle as oracle   # the ONLY use of oracle/ here: the timed CPU baseline leg
+    from polars_quant_amd.synthetic import gen_ohlcv
+    d = gen_ohlcv(SEED, sample_syms, T, 0)
     # the GPU box allots 16 host cores per GPU (and caps worker pools there); use at most that many
     cores = min(len(os.sched_getaffinity(0)), 16)
     oracle.suite_bench({k: v[:8] for k, v in d.items()}, cores)  # spin up the OpenMP team

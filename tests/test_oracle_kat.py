@@ -431,6 +431,15 @@ def test_sar_basic(oracle):
     assert v[5] == 13.0  # reversal on the crash bar: sar jumps to the extreme point
 
 
+def test_product_generator_matches_oracle_generator(oracle):
+    # bench.py takes its inputs from polars_quant_amd.synthetic (no oracle on the measured path): same bits as pqo_gen_ohlcv
+    from polars_quant_amd.synthetic import gen_ohlcv
+    for mode in (0, 1):
+        a, b = oracle.gen_ohlcv(0x5EED0002, 97, 311, mode), gen_ohlcv(0x5EED0002, 97, 311, mode)
+        for k in a:
+            assert (a[k].view(np.uint64) == b[k].view(np.uint64)).all(), (mode, k)
+
+
 def test_generator_reproducible(oracle):
     a = oracle.gen_ohlcv(0x5EED0001, 3, 50)
     b = oracle.gen_ohlcv(0x5EED0001, 3, 50)
