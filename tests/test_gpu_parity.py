@@ -410,6 +410,19 @@ def test_factor_ic_matches_oracle(pq, oracle, data):
     assert set(out) == {"rolling_ic", "rolling_ir"}
 
 
+def test_randomised_parity_sweep(pq, oracle):
+    """800 random (function, shape, parameters, null pattern) cases with a fixed seed (scripts/fuzz_parity.py, in-process).
+    Shapes 1..139 x 1..259 (ragged tiles, series shorter than the windows), periods in {0, 1, .., T-1, T, T+1}, all matypes."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("fuzz_parity", Path(__file__).resolve().parent.parent / "scripts" / "fuzz_parity.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    msgs = []
+    n_bad = mod.sweep(21, 800, log=lambda *a: msgs.append(" ".join(str(x) for x in a)))
+    assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
+
+
 def test_error_paths_leave_the_context_usable(pq, oracle, data):
     """Argument errors come back as status codes with a message (PqError), never as a launch; the context keeps working."""
     import ctypes as C
