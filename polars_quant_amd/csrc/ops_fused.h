@@ -307,8 +307,12 @@ struct HtAllOp {
         if (dc_phase > 315.0) dc_phase -= 360.0;
         y[1] = dc_phase;
         y[2] = i1; y[3] = q1;
-        y[4] = sin(ph * PQ_PI / 180.0);
-        y[5] = sin((ph + 45.0) * PQ_PI / 180.0);
+        // one sincos instead of two sin calls: sin(x + pi/4) = (sin x + cos x) / sqrt(2), within the 1e-12 budget of these
+        // outputs (absolute error ~1e-16; the single-output pq_ht_sine keeps the reference's two calls)
+        double sn, cs;
+        sincos(ph * PQ_PI / 180.0, &sn, &cs);
+        y[4] = sn;
+        y[5] = (sn + cs) * 0.70710678118654752440;
     }
 };
 
