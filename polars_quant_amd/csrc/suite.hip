@@ -379,7 +379,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
             std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
             for (size_t k : idx) {
-                if (early < 0.5 * total) { early += weight(p.rows[k]); continue; }
+                if (early < 0.5 * total) { early += weight(p.rows[k]); continue; } // (0 -> 6.1 ms, 0.7 -> same as 0.5)
                 p.row_late[k] = 1; // 1 + chain 0
             }
         }
