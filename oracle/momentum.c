@@ -236,6 +236,19 @@ void pqo_rocr100(const double *v, int64_t n, int64_t p, double *out) {
     pqo_fill_null(out, n);
     for (int64_t i = (p < 0 ? 0 : p); i < n; i++) { double pr = v[i - p]; if (pr != 0.0) out[i] = (v[i] / pr) * 100.0; }
 }
+/* README.md:46-75 `returns(df, price_col, period, method)` (README-only, no source; decision D-13): method 0 "simple" =
+ * (p[t] - p[t-period]) / p[t-period], method 1 "log" = ln(p[t] / p[t-period]); null for t < period and where either price
+ * is null (a Polars shift/arithmetic expression: nulls propagate, a zero denominator follows IEEE-754).  period <= 0 or an
+ * unknown method -> all null.  Pinned by the reference-held vector README.md:75. */
+void pqo_returns(const double *v, int64_t n, int64_t period, int64_t method, double *out) {
+    pqo_fill_null(out, n);
+    if (period <= 0 || (method != 0 && method != 1)) return;
+    for (int64_t i = period; i < n; i++) {
+        double c = v[i], pr = v[i - period];
+        if (pqo_isnull(c) || pqo_isnull(pr)) continue;
+        out[i] = method == 0 ? (c - pr) / pr : log(c / pr);
+    }
+}
 /* momentum.rs:507-541 */
 void pqo_rsi(const double *v, int64_t n, int64_t p, double *out) {
     double *ups = (double *)calloc((size_t)(n > 0 ? n : 1), 8), *downs = (double *)calloc((size_t)(n > 0 ? n : 1), 8);

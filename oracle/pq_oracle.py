@@ -103,6 +103,11 @@ SPEC = {
     "ht_trendmode": (["real"], [], [("ht_trendmode", "i4")]),
 }
 
+# functions outside talib.* that share the (inputs, params, outputs) calling shape; not part of the indicator suite
+EXTRA = {
+    "returns": (["real"], [("period", I, 1), ("method", I, 0)], [("return", "f8")]),  # README.md:46-75 (D-13); 0 simple, 1 log
+}
+
 PATTERN_NAMES = [
     "cdl2crows", "cdl3blackcrows", "cdl3inside", "cdl3linestrike", "cdl3outside", "cdl3starsinsouth",
     "cdl3whitesoldiers", "cdlabandonedbaby", "cdladvanceblock", "cdlbelthold", "cdlbreakaway",
@@ -152,7 +157,7 @@ def call(name: str, *inputs, **params):
     """Run oracle function `name` on [T] or [N, T] float64 inputs; returns tuple of outputs."""
     if name in PATTERN_NAMES:
         return (pattern(name, *inputs, **params),)
-    cols, pspec, outs = SPEC[name]
+    cols, pspec, outs = SPEC[name] if name in SPEC else EXTRA[name]
     assert len(inputs) == len(cols), f"{name} wants {cols}"
     arrs = [_as2d(x) for x in inputs]
     squeeze = arrs[0][1]
@@ -348,4 +353,4 @@ def suite_bench(ohlcv: dict, threads: int = 0) -> float:
 def input_cols(name):
     if name in PATTERN_NAMES:
         return ["open", "high", "low", "close"]
-    return SPEC[name][0]
+    return (SPEC[name] if name in SPEC else EXTRA[name])[0]

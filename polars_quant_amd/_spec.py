@@ -92,6 +92,12 @@ SPEC = {
     "ht_trendmode": (["real"], [], [("ht_trendmode", "i4")], NB),
 }
 
+# functions outside talib.* with the same calling shape (not part of the indicator suite)
+EXTRA = {
+    # README.md:46-75 returns(df, price_col, period, method): method 0 "simple", 1 "log" (decision D-13)
+    "returns": (["real"], [("period", I, 1), ("method", I, 0)], [("return", "f8")], NC),
+}
+
 PATTERN_NAMES = [
     "cdl2crows", "cdl3blackcrows", "cdl3inside", "cdl3linestrike", "cdl3outside", "cdl3starsinsouth",
     "cdl3whitesoldiers", "cdlabandonedbaby", "cdladvanceblock", "cdlbelthold", "cdlbreakaway",

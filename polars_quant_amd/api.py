@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import Batch, BtParams, NullsNotAllowed, PqError, check, lib
-from ._spec import BT_DEFAULTS, I, NB, PATTERN_NAMES, PATTERN_PEN_DEFAULT, SPEC, SUMMARY_KEYS
+from ._spec import BT_DEFAULTS, EXTRA, I, NB, PATTERN_NAMES, PATTERN_PEN_DEFAULT, SPEC, SUMMARY_KEYS
 
 NULL = np.array([_lib.NULL_BITS], dtype=np.uint64).view(np.float64)[0]
 
@@ -142,7 +142,7 @@ def call(name: str, *inputs, check_nulls: bool = False, **params):
     """Run indicator `name` (lower-case plugin name, e.g. "ema") -> tuple of outputs."""
     if name in PATTERN_NAMES:
         return (cdl(name, *inputs, **params),)
-    cols, pspec, outs, fam = SPEC[name]
+    cols, pspec, outs, fam = SPEC[name] if name in SPEC else EXTRA[name]
     if len(inputs) != len(cols):
         raise TypeError(f"{name}() takes inputs {cols}")
     conv = [_to_device(x) for x in inputs]

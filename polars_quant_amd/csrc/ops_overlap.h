@@ -20,6 +20,8 @@ struct SmaOp { // overlap.rs:871-937
     __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
     __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { c.init(p, r.len); w = ra.make(p); }
     __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.step_ring(w, x[0]); }
+    __device__ bool steady(int64_t) const { return c.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.fast_ring(w, x[0]); }
 };
 
 struct EmaOp { // overlap.rs:660-730
@@ -29,6 +31,8 @@ struct EmaOp { // overlap.rs:660-730
     EmaCore c;
     __device__ void init(const Row<1> &r) { c.init(p, r.len); }
     __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.step(x[0]); }
+    __device__ bool steady(int64_t) const { return c.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.fast(x[0]); }
 };
 
 struct BbandsOp { // overlap.rs:47-116
@@ -82,6 +86,17 @@ struct BbandsOp { // overlap.rs:47-116
         double sd = sqrt(fmax(variance, 0.0));
         y[0] = mean + up * sd; y[1] = mean; y[2] = mean - dn * sd;
     }
+    __device__ bool steady(int64_t) const { return !dead && count >= p; } // full window: count stays at p
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
+        const double v = x[0];
+        sum += v; sum_sq += v * v;
+        const double old = w.swap(v);
+        sum -= old; sum_sq -= old * old;
+        double mean = sum / (double)p;
+        double variance = (sum_sq / (double)p) - mean * mean;
+        double sd = sqrt(fmax(variance, 0.0));
+        y[0] = mean + up * sd; y[1] = mean; y[2] = mean - dn * sd;
+    }
 };
 
 struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
@@ -110,6 +125,12 @@ struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
             y[0] = 2.0 * e0 - e1;
         }
     }
+    __device__ bool steady(int64_t) const { return !dead && count >= 2 * p - 1; } // every later valid row is the last branch
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        e0 = fma(alpha, x[0] - e0, e0);
+        e1 = fma(alpha, e0 - e1, e1);
+        y[0] = 2.0 * e0 - e1;
+    }
 };
 
 struct TemaOp { // overlap.rs:1177-1311
@@ -137,6 +158,13 @@ struct TemaOp { // overlap.rs:1177-1311
         if (count < 3 * p - 2) { s2 += e1; return; }
         if (count == 3 * p - 2) { s2 += e1; e2 = s2 / (double)p; }
         else e2 = fma(alpha, e1 - e2, e2);
+        y[0] = 3.0 * e0 - 3.0 * e1 + e2;
+    }
+    __device__ bool steady(int64_t) const { return !dead && count >= 3 * p - 2; }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        e0 = fma(alpha, x[0] - e0, e0);
+        e1 = fma(alpha, e0 - e1, e1);
+        e2 = fma(alpha, e1 - e2, e2);
         y[0] = 3.0 * e0 - 3.0 * e1 + e2;
     }
 };
@@ -175,6 +203,16 @@ struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e
         if (count == 5 * p - 4) { s4 += e3; e4 = s4 / (double)p; s5 = e4; return; }
         e4 = fma(alpha, e3 - e4, e4);
         if (count < 6 * p - 5) { s5 += e4; return; }
+        e5 = fma(alpha, e4 - e5, e5);
+        y[0] = fma(c1, e5, fma(c2, e4, fma(c3, e3, c4 * e2)));
+    }
+    __device__ bool steady(int64_t) const { return !dead && count >= 6 * p - 5; }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        e0 = fma(alpha, x[0] - e0, e0);
+        e1 = fma(alpha, e0 - e1, e1);
+        e2 = fma(alpha, e1 - e2, e2);
+        e3 = fma(alpha, e2 - e3, e3);
+        e4 = fma(alpha, e3 - e4, e4);
         e5 = fma(alpha, e4 - e5, e5);
         y[0] = fma(c1, e5, fma(c2, e4, fma(c3, e3, c4 * e2)));
     }
@@ -225,6 +263,13 @@ struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
         double old = w.swap(v);
         if (count < p) return;
         if (count > p) { numerator -= ((double)p) * old; count -= 1; }
+        y[0] = numerator / denominator;
+    }
+    __device__ bool steady(int64_t) const { return !dead && count >= p; } // full window: count stays at p
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        numerator += ((double)(p + 1)) * x[0]; // the general path multiplies by (double)count after its increment to p + 1
+        const double old = w.swap(x[0]);
+        numerator -= ((double)p) * old;
         y[0] = numerator / denominator;
     }
 };
@@ -316,6 +361,21 @@ struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
         double sc = sc_sqrt * sc_sqrt;
         if (c2 < p) { c2 += 1; sum2 += v; return; }
         if (c2 == p) { c2 += 1; kama = sum2 / (double)p; y[0] = kama; return; }
+        kama = fma(sc, v - kama, kama);
+        y[0] = kama;
+    }
+    // count saturated at p, the popped diff is a p-lag diff (k = j-p+1 >= p), pass 2 seeded (c2 > p): j and c2 stop mattering
+    __device__ bool steady(int64_t) const { return !dead && count >= p && j >= 2 * p - 1 && c2 > p; }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        const double v = x[0];
+        const double xa = w.get((int)p), xk = w.get((int)p - 1), xc = w.get((int)(2 * p - 1));
+        double diff_abs = fabs(v - xa);
+        double popped = fabs(xk - xc);
+        sum += diff_abs - popped;
+        double er = diff_abs / sum;
+        w.push(v);
+        double sc_sqrt = er * (2.0 / 3.0 - 2.0 / 31.0) + 2.0 / 31.0;
+        double sc = sc_sqrt * sc_sqrt;
         kama = fma(sc, v - kama, kama);
         y[0] = kama;
     }

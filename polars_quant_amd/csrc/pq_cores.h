@@ -39,6 +39,12 @@ struct EmaCore {
         ema = fma(alpha, v - ema, ema);
         return ema;
     }
+    // steady state (see HasFast in pq_dev.h): seeded, so every valid row is the recurrence; count is only compared with p
+    __device__ bool steady() const { return !dead && count >= p; }
+    __device__ double fast(double v) {
+        ema = fma(alpha, v - ema, ema);
+        return ema;
+    }
 };
 
 // Walks a series forward over its valid (non-null) rows: used to pop "the oldest value still in
@@ -132,6 +138,17 @@ struct SmaCore {
         }
         return sum * denom;
     }
+    __device__ bool steady() const { return !dead && count >= p; } // full window: count stays at p
+    __device__ double fast_ring(Ring &w, double v) {
+        sum += v;
+        sum -= w.swap(v);
+        return sum * denom;
+    }
+    __device__ double fast_old(double v, double old) {
+        sum += v;
+        sum -= old;
+        return sum * denom;
+    }
 };
 
 // D-1 calc_rma (Wilder) over a null-free slice: None for i < p-1, seed = mean(x[0..p)) at i = p-1,
@@ -162,6 +179,11 @@ struct RmaCore {
             r = sum / pf;
             return r;
         }
+        r = (r * pm1 + x) / pf;
+        return r;
+    }
+    __device__ bool steady(int64_t i) const { return !dead && i >= p; }
+    __device__ double fast(double x) {
         r = (r * pm1 + x) / pf;
         return r;
     }

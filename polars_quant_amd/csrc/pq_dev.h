@@ -111,6 +111,25 @@ struct IsMasked { static constexpr bool value = false; };
 template <class Op>
 struct IsMasked<Op, decltype((void)Op::MASKED)> { static constexpr bool value = Op::MASKED; };
 
+// Steady-state fast path (optional).  An op that declares
+//   __device__ bool steady(int64_t t0) const;        // per lane: from row t0 on every row takes the op's steady-state path
+//   __device__ void step_fast(int64_t t, const double (&x)[NIN], double (&y)[NOUT]);
+// gets whole tiles walked by step_fast -- straight-line code, unrolled, no per-row warm-up / null branching -- whenever
+// steady() holds on every lane of the wave and (unless FAST_NULL_OK) no input value of the tile is NULL.  step_fast must
+// leave the op's state exactly as the general step would (same arithmetic in the same order), so the two can alternate.
+template <class Op, class = void>
+struct HasFast { static constexpr bool value = false; };
+template <class Op>
+struct HasFast<Op, decltype((void)&Op::steady)> { static constexpr bool value = true; };
+template <class Op, class = void>
+struct FastNullOk { static constexpr bool value = false; }; // true: the op never looks at null flags (N-B family)
+template <class Op>
+struct FastNullOk<Op, decltype((void)Op::FAST_NULL_OK)> { static constexpr bool value = Op::FAST_NULL_OK; };
+template <class Op, class = void>
+struct FastUnroll { static constexpr int value = 2; };      // rows per unrolled fast-loop iteration
+template <class Op>
+struct FastUnroll<Op, decltype((void)Op::FAST_UNROLL)> { static constexpr int value = Op::FAST_UNROLL; };
+
 template <class Op, class = void>
 struct NTap { static constexpr int value = 0; };
 template <class Op>
@@ -438,6 +457,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
         PQ_PROF_T(c0);
+        bool maybe_null = false; // some value moved by this lane has NULL's low word (exact enough: a false alarm only costs the general path)
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
@@ -445,10 +465,47 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 double *q = reinterpret_cast<double *>(co_row[i] + k * TB);
                 q[0] = buf[k][i].x;
                 q[1] = buf[k][i].y;
+                if constexpr (HasFast<Op>::value && !FastNullOk<Op>::value)
+                    maybe_null |= (unsigned)__double2loint(buf[k][i].x) == (unsigned)(PQ_NULL_BITS & 0xffffffffu) ||
+                                  (unsigned)__double2loint(buf[k][i].y) == (unsigned)(PQ_NULL_BITS & 0xffffffffu);
             }
         if (it + PF < nt) prefetch(buf, t0 + PF * K);
         lds_fence();
         PQ_PROF_T(c1);
+        if constexpr (HasFast<Op>::value) {
+            // steady state on the whole wave and a null-free tile: straight-line rows
+            if (__builtin_amdgcn_ballot_w64(maybe_null || !op.steady(t0)) == 0) {
+                constexpr int FU = FastUnroll<Op>::value < K ? FastUnroll<Op>::value : K;
+                static_assert(K % FU == 0, "FAST_UNROLL must divide the tile height");
+#pragma unroll 1
+                for (int j0 = 0; j0 < K; j0 += FU) {
+                    double xs[FU][NIN], ys[FU][NOUT];
+#pragma unroll
+                    for (int u = 0; u < FU; u++)
+#pragma unroll
+                        for (int k = 0; k < NIN; k++) xs[u][k] = *reinterpret_cast<const double *>(my_row + k * TB + (j0 + u) * 8);
+#pragma unroll
+                    for (int u = 0; u < FU; u++) op.step_fast(t0 + j0 + u, xs[u], ys[u]);
+#pragma unroll
+                    for (int u = 0; u < FU; u++) {
+                        if constexpr (MASKED) {
+#pragma unroll
+                            for (int k = 0; k < NOUT; k++)
+                                if (live && !pq_isskip(ys[u][k])) outp[k][s * d.stride + t0 + j0 + u] = ys[u][k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NOUT; k++) *reinterpret_cast<double *>(my_row + k * TB + (j0 + u) * 8) = ys[u][k];
+                        }
+                    }
+                }
+                lds_fence();
+                if constexpr (!MASKED) {
+                    __builtin_amdgcn_s_barrier(); // A
+                    __builtin_amdgcn_s_barrier(); // B
+                }
+                return;
+            }
+        }
         // one row at a time, NOT unrolled: every job of a suite grid runs different code, and K copies of each
         // op body would thrash the instruction cache; the next row's inputs are read from LDS ahead of the step
         double xn[NIN];
