@@ -154,6 +154,7 @@ __device__ __forceinline__ void backtest_body(const BtArgs &a, const Dims &d, in
 struct BtMacdOp {
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int SEQ_ID = 62;
+    static constexpr int COST_NS = 635;
     pq_bt_params prm;
     int64_t fast, slow, sig;
     double *summary; // [n][8], nullable
@@ -176,6 +177,25 @@ struct BtMacdOp {
         bool buy = ok && (prev_m <= prev_s) && (m > g);
         bool sell = ok && (prev_m >= prev_s) && (m < g);
         prev_m = m; prev_s = g;
+        trade_row(px, buy, sell, y);
+    }
+    static constexpr bool HAS_FAST = true;
+    // the three EMAs seeded and the previous row's macd / signal known: the signal rule needs no null tests
+    __device__ bool steady(int64_t t0) const {
+        return t0 > 0 && ef.steady() && es.steady() && eg.steady() && !pq_isnull(prev_m) && !pq_isnull(prev_s);
+    }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
+        const double px = x[0];
+        const double f = ef.fast(px), sl = es.fast(px);
+        const double m = f - sl;
+        const double g = eg.fast(m);
+        const bool buy = (prev_m <= prev_s) && (m > g);
+        const bool sell = (prev_m >= prev_s) && (m < g);
+        prev_m = m; prev_s = g;
+        trade_row(px, buy, sell, y);
+    }
+    // vectorized.rs:130-194 for one row + the running parts of calculate_summary (metrics.rs:26-49)
+    __device__ __forceinline__ void trade_row(double px, bool buy, bool sell, double (&y)[3]) {
         double eq;
         if (pq_isnull(px)) px = __longlong_as_double(0x7FF8000000000000LL); // null -> NaN (vectorized.rs:70-78)
         if (isnan(px) || px <= 0.0) { // vectorized.rs:141-144: state untouched

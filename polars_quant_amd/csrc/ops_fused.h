@@ -22,6 +22,8 @@ struct Ma2 {
         else { s.init(p, n); w = ra.make(p); }
     }
     __device__ double step(double v) { return kind ? e.step(v) : s.step_ring(w, v); }
+    __device__ bool steady() const { return kind ? e.steady() : s.steady(); }
+    __device__ double fast(double v) { return kind ? e.fast(v) : s.fast_ring(w, v); }
 };
 
 // Two moving averages of the SAME input: when both are SMAs they share one ring (depth = the longer period; the shorter
@@ -54,12 +56,21 @@ struct Ma2Pair {
         yb = b.s.step_old(v, ob);
         w.push(v);
     }
+    __device__ bool steady() const { return shared ? (a.s.steady() && b.s.steady()) : (a.steady() && b.steady()); }
+    __device__ void fast(double v, double &ya, double &yb) {
+        if (!shared) { ya = a.fast(v); yb = b.fast(v); return; }
+        const double oa = w.get(pa), ob = w.get(pb);
+        ya = a.s.fast_old(v, oa);
+        yb = b.s.fast_old(v, ob);
+        w.push(v);
+    }
 };
 
 struct TrimaOp {
     static constexpr bool LDS_ONLY = true; // overlap.rs:1313-1326: sma(sma(x, k1), k2)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 70;
+    static constexpr int COST_NS = 150;
     int64_t k1, k2;
     SmaCore a, b;
     Ring wa, wb;
@@ -68,6 +79,9 @@ struct TrimaOp {
     __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { a.init(k1, r.len); b.init(k2, r.len); wa = ra.make(k1); wb = ra.make(k2); }
     __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[1]) { y[0] = pq_null(); }
     __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = b.step_ring(wb, a.step_ring(wa, x[0])); }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return a.steady() && b.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = b.fast_ring(wb, a.fast_ring(wa, x[0])); }
 };
 
 template <int MODE> // 0 APO, 1 PPO (decision D-6)
@@ -75,6 +89,7 @@ struct MaDiffOp {
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 71 + MODE;
+    static constexpr int COST_NS = 250;
     int64_t fast, slow, matype;
     Ma2Pair fs;
     __host__ __device__ int64_t ring_slots() const { return Ma2Pair::slots(matype, fast, matype, slow); }
@@ -88,12 +103,21 @@ struct MaDiffOp {
         if (MODE == 0) y[0] = a - b;
         else y[0] = (b == 0.0) ? pq_null() : (a - b) / b * 100.0;
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return fs.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        double a, b;
+        fs.fast(x[0], a, b);
+        if (MODE == 0) y[0] = a - b;
+        else { const double v = (a - b) / b * 100.0; y[0] = (b == 0.0) ? pq_null() : v; }
+    }
 };
 
 struct MacdextOp {
     static constexpr bool LDS_ONLY = true; // momentum.py:83-88
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int SEQ_ID = 73;
+    static constexpr int COST_NS = 338;
     int64_t fast, fastmt, slow, slowmt, sig, sigmt;
     Ma2Pair fs;
     Ma2 g;
@@ -110,6 +134,15 @@ struct MacdextOp {
         double d = g.step(m); // N-A: a null macd row is skipped by the signal MA
         y[0] = m; y[1] = d;
         y[2] = (pq_isnull(m) || pq_isnull(d)) ? pq_null() : m - d;
+    }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return fs.steady() && g.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
+        double a, b;
+        fs.fast(x[0], a, b);
+        const double m = a - b;
+        const double d = g.fast(m);
+        y[0] = m; y[1] = d; y[2] = m - d;
     }
 };
 
@@ -142,6 +175,14 @@ struct FastkCore {
         if (rows < k || nulls_h || nulls_l || pq_isnull(c)) return pq_null();
         return (c - lmin) * 100.0 / (hmax - lmin);
     }
+    // full frame without a null row: the flag rings are all zero and stay so (their position is irrelevant then), rows
+    // is only compared with k
+    __device__ bool steady() const { return k > 0 && rows >= k && nulls_h == 0 && nulls_l == 0; }
+    __device__ double fast(double h, double l, double c) {
+        const double hmax = mx.step_ring2(hc, hs, h);
+        const double lmin = mn.step_ring2(lc, ls, l);
+        return (c - lmin) * 100.0 / (hmax - lmin);
+    }
 };
 
 template <int MODE> // 0 STOCH -> (slowk, slowd); 1 STOCHF -> (fastk, fastd)     momentum.py:178-195
@@ -149,6 +190,8 @@ struct StochOp {
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 3, NOUT = 2; // high, low, close
     static constexpr int SEQ_ID = 74 + MODE;
+    static constexpr int COST_NS = MODE == 0 ? 637 : 579;
+    static constexpr bool HEAVY = MODE == 0; // three MA cores behind the rolling extrema: > 168 VGPRs
     int64_t fastk, p1, mt1, p2, mt2; // STOCH: slowk/slowd MA params; STOCHF: (p1, mt1) = fastd, second MA unused
     FastkCore fk;
     Ma2 m1, m2;
@@ -168,6 +211,14 @@ struct StochOp {
         if (MODE == 0) { y[0] = a; y[1] = m2.step(a); }
         else { y[0] = k; y[1] = a; }
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return fk.steady() && m1.steady() && (MODE != 0 || m2.steady()); }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[2]) {
+        const double k = fk.fast(x[0], x[1], x[2]);
+        const double a = m1.fast(k);
+        if (MODE == 0) { y[0] = a; y[1] = m2.fast(a); }
+        else { y[0] = k; y[1] = a; }
+    }
 };
 
 // STOCH and STOCHF of the same fastk_period in one walk: the rolling-extrema core (the expensive part) is evaluated once;
@@ -177,6 +228,8 @@ struct StochAllOp {
     static constexpr int NIN = 3, NOUT = 4; // -> slowk, slowd, fastk, fastd
     static constexpr int ALG_COLS = 5 + 5;  // stoch, stochf
     static constexpr int SEQ_ID = 96;
+    static constexpr int COST_NS = 800;
+    static constexpr bool HEAVY = true;
     int64_t fastk, slowk, slowk_mt, slowd, slowd_mt, fastd, fastd_mt;
     FastkCore fk;
     Ma2 mk, md, mf;
@@ -194,12 +247,20 @@ struct StochAllOp {
         const double a = mk.step(k);
         y[0] = a; y[1] = md.step(a); y[2] = k; y[3] = mf.step(k);
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return fk.steady() && mk.steady() && md.steady() && mf.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[4]) {
+        const double k = fk.fast(x[0], x[1], x[2]);
+        const double a = mk.fast(k);
+        y[0] = a; y[1] = md.fast(a); y[2] = k; y[3] = mf.fast(k);
+    }
 };
 
 struct StochRsiOp {
     static constexpr bool LDS_ONLY = true; // momentum.py:197-205
     static constexpr int NIN = 1, NOUT = 2;
     static constexpr int SEQ_ID = 76;
+    static constexpr int COST_NS = 618;
     int64_t p, fastk, fastd, fastd_mt;
     RsiOp rsi;
     FastkCore fk;
@@ -216,12 +277,23 @@ struct StochRsiOp {
         y[0] = k;
         y[1] = m.step(k);
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B (the RSI core)
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return rsi.steady(t0) && fk.steady() && m.steady(); }
+    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[2]) {
+        double rv[1];
+        rsi.step_fast(i, x, rv);
+        const double k = fk.fast(rv[0], rv[0], rv[0]);
+        y[0] = k;
+        y[1] = m.fast(k);
+    }
 };
 
 struct CciOp {
     static constexpr bool LDS_ONLY = true; // momentum.rs:138-178 in one walk: sma(tp) + mean absolute deviation over the same window (oldest first)
     static constexpr int NIN = 3, NOUT = 1;
     static constexpr int SEQ_ID = 77;
+    __host__ int cost_ns() const { return 320 + 40 * (int)(p > 0 ? (p < 1000 ? p : 1000) : 0); } // O(p) mean-deviation loop per row
     int64_t p;
     double sum, denom;
     bool dead;
@@ -254,6 +326,26 @@ struct CciOp {
             y[0] = (tp - avg) / (0.015 * mean_dev);
         }
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return !dead && t0 >= p; }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[1]) {
+        const double tp = (x[0] + x[1] + x[2]) / 3.0;
+        sum += tp;
+        sum -= w.swap(tp);
+        const double avg = sum * denom;
+        double mean_dev = 0.0;
+        for (int b0 = (int)p; b0 >= 1; b0 -= 8) { // oldest to newest, the reference's summation order
+            double v8[8];
+            w.get8<-1>(b0, v8);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (b0 - u >= 1) mean_dev += fabs(v8[u] - avg);
+        }
+        const double md = mean_dev / (double)p;
+        const double v = (tp - avg) / (0.015 * md);
+        y[0] = (mean_dev != 0.0) ? v : pq_null();
+    }
 };
 
 // momentum.rs:668-727 calc_dm once for all five of its users: dx, plus_di (= dx, quirk Q-PDI), minus_di, adx, adxr
@@ -263,6 +355,7 @@ struct DmAllOp {
     static constexpr int NIN = 3, NOUT = ALL ? 5 : 1;
     static constexpr int ALG_COLS = ALL ? 5 * 4 : 4; // dx, plus_di, minus_di, adx, adxr: five (3 in, 1 out) calls
     static constexpr int SEQ_ID = ALL ? 78 : 80;
+    static constexpr int COST_NS = 550;
     int64_t p;
     DmOp<2> core; // carries the three RMAs + the ADX RMA
     Ring wadx;
@@ -283,6 +376,18 @@ struct DmAllOp {
         if (p > 1) wadx.push(adx);
         y[NOUT - 1] = adxr;
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    // the ADX ring holds the last p-1 values: all of them are non-null once 2p rows have passed
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return p > 0 && core.steady(t0) && t0 >= 2 * p; }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[NOUT]) {
+        double dx, mdi;
+        const double adx = core.fast_all(x, dx, mdi);
+        if (ALL) { y[0] = dx; y[1 % NOUT] = dx; y[2 % NOUT] = mdi; y[3 % NOUT] = adx; }
+        const double prev = (p == 1) ? adx : wadx.get((int)(p - 1));
+        if (p > 1) wadx.push(adx);
+        y[NOUT - 1] = (adx + prev) * 0.5;
+    }
 };
 
 // cycle.rs: the shared Hilbert pipeline once for ht_dcperiod, ht_dcphase, ht_phasor and ht_sine
@@ -290,16 +395,23 @@ struct HtAllOp {
     static constexpr int NIN = 1, NOUT = 6; // dcperiod, dcphase, inphase, quadrature, sine, leadsine
     static constexpr int ALG_COLS = 2 + 2 + 3 + 3; // ht_dcperiod, ht_dcphase, ht_phasor, ht_sine
     static constexpr int SEQ_ID = 79;
+    static constexpr int COST_NS = 885;
+    static constexpr bool HEAVY = true;
     HtOp<0> core;
     __device__ void init(const Row<1> &r) { core.init(r); }
-    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[6]) {
+    static constexpr bool FAST_NULL_OK = true;
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return core.steady(t0); }
+    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[6]) { row<true>(i, x, y); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[6]) { row<false>(i, x, y); }
+    template <bool FAST>
+    __device__ __forceinline__ void row(int64_t i, const double (&x)[1], double (&y)[6]) {
         double yp[1];
-        Row<1> dummy; dummy.in[0] = nullptr; dummy.len = 0;
-        core.step(dummy, i, x, yp); // advances the pipeline, emits the smoothed period
+        core.template row<FAST>(i, x, yp); // advances the pipeline, emits the smoothed period
         y[0] = yp[0];
 #pragma unroll
         for (int k = 1; k < 6; k++) y[k] = pq_null();
-        if (core.dead || i < 31) return;
+        if (!FAST && (core.dead || i < 31)) return;
         const double i1 = core.i1[0], q1 = core.q1[0];
         double ph = (i1 != 0.0) ? atan(q1 / i1) * 180.0 / PQ_PI : 0.0; // cycle.rs:130-134 == :294-298
         double dc_phase = ph + 90.0;
@@ -326,6 +438,7 @@ struct MavpSma16Op {
     static constexpr bool MASKED = true;
     static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0), periods
     static constexpr int SEQ_ID = 83;
+    static constexpr int COST_NS = 835; // sixteen running sums per row
     int lo, hi, minp, maxp, n;
     Ring w;
     const double *tab; // 1/P for P = lo .. lo+15 (shared by the wave)
@@ -373,6 +486,35 @@ struct MavpSma16Op {
         const double res = asel * tab[mine ? pi - lo : 0];
         y[0] = mine ? (ok ? res : pq_null()) : pq_skip();
     }
+    static constexpr bool FAST_NULL_OK = true; // N-0: nulls become 0.0 in the row body
+    static constexpr int FAST_UNROLL = 1;
+    // every candidate window is full (c = t+1 > lo+15) and the output gate t >= maxp-1 is open; candidates beyond `hi` or
+    // longer than the series carry garbage here that is never selected (pi is clamped into [minp, maxp] and `mine` tests
+    // [lo, hi]) and that the general path resets to 0.0 on its next row
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 >= lo + 16 && t0 >= maxp - 1 && lo > 0; }
+    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) {
+        const double v = n0(x[0]);
+        const int64_t p64 = (int64_t)n0(x[1]);
+        const int pi = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
+        double asel = 0.0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            double old[8];
+            w.get8<1>(lo + 8 * g, old);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double a = (s[8 * g + u] + v) - old[u];
+                s[8 * g + u] = a;
+                asel = (lo + 8 * g + u == pi) ? a : asel;
+            }
+        }
+        w.push(v);
+        const bool mine = pi >= lo && pi <= hi;
+        const bool ok = pi > 0 && n >= pi;
+        const double res = asel * tab[mine ? pi - lo : 0];
+        y[0] = mine ? (ok ? res : pq_null()) : pq_skip();
+    }
 };
 
 // MAVP for the single-core MA types (SMA: matype 0/7/other, EMA: matype 1): a job advances up to EIGHT candidate
@@ -385,6 +527,7 @@ struct MavpBlockOp {
     static constexpr bool MASKED = true;
     static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0), periods
     static constexpr int SEQ_ID = 81 + KIND;
+    static constexpr int COST_NS = 800;
     int lo, hi, minp, maxp, n;
     Ring w, st;
     const double *tab; // SMA: 1/P ; EMA: 2/(P+1)
@@ -455,6 +598,8 @@ struct Fuse2 {
     static constexpr int NIN = A::NIN, NOUT = A::NOUT + B::NOUT;
     static constexpr int ALG_COLS = AlgCols<A>::value + AlgCols<B>::value; // the calls it replaces
     static constexpr int SEQ_ID = ID;
+    __host__ int cost_ns() const { return (3 * (OpCost<A>::get(a) + OpCost<B>::get(b))) / 4; } // one walk, shared tile traffic
+    static constexpr bool HEAVY = IsHeavy<A>::value || IsHeavy<B>::value;
     static constexpr bool LDS_ONLY = true; // (the gather driver's tap plumbing is per op)
     A a;
     B b;
@@ -484,13 +629,28 @@ struct Fuse2 {
 #pragma unroll
         for (int k = 0; k < B::NOUT; k++) y[A::NOUT + k] = yb[k];
     }
+    static constexpr bool FAST_NULL_OK = FastNullOk<A>::value && FastNullOk<B>::value;
+    static constexpr int FAST_UNROLL = FastUnroll<A>::value < FastUnroll<B>::value ? FastUnroll<A>::value : FastUnroll<B>::value;
+    static constexpr bool HAS_FAST = HasFast<A>::value && HasFast<B>::value; // steady / step_fast are instantiated only then
+    __device__ bool steady(int64_t t0) const { return a.steady(t0) && b.steady(t0); }
+    __device__ void step_fast(int64_t t, const double (&x)[NIN], double (&y)[NOUT]) {
+        double ya[A::NOUT], yb[B::NOUT];
+        a.step_fast(t, x, ya);
+        b.step_fast(t, x, yb);
+#pragma unroll
+        for (int k = 0; k < A::NOUT; k++) y[k] = ya[k];
+#pragma unroll
+        for (int k = 0; k < B::NOUT; k++) y[A::NOUT + k] = yb[k];
+    }
 };
+
 // A ring-free op that reads a SUBSET (I0, I1) of a wider job's input columns
 template <int NIN_, class Op, int I0, int I1>
 struct Pick2 {
     static_assert(Op::NIN == 2 && !HasRings<Op>::value && NTap<Op>::value == 0, "Pick2 wraps a plain two-input op");
     static constexpr int NIN = NIN_, NOUT = Op::NOUT;
     static constexpr int ALG_COLS = AlgCols<Op>::value;
+    static constexpr int COST_NS = OpCostStatic<Op>::value;
     Op op;
     Row<2> rr;
     __device__ void init(const Row<NIN> &r) { rr.in[0] = r.in[I0]; rr.in[1] = r.in[I1]; rr.len = r.len; op.init(rr); }
@@ -498,7 +658,15 @@ struct Pick2 {
         const double xx[2] = {x[I0], x[I1]};
         op.step(rr, t, xx, y);
     }
+    static constexpr bool FAST_NULL_OK = FastNullOk<Op>::value;
+    static constexpr bool HAS_FAST = HasFast<Op>::value;
+    __device__ bool steady(int64_t t0) const { return op.steady(t0); }
+    __device__ void step_fast(int64_t t, const double (&x)[NIN], double (&y)[NOUT]) {
+        const double xx[2] = {x[I0], x[I1]};
+        op.step_fast(t, xx, y);
+    }
 };
+
 typedef Fuse2<90, Fuse2<0, EmaOp, DemaOp>, Fuse2<0, TemaOp, TrixOp>> EmaAllOp; // ema, dema, tema, trix of one timeperiod
 typedef Fuse2<91, AtrOp<false>, AtrOp<true>> AtrAllOp;                          // atr, natr
 typedef Fuse2<92, DmRawOp<true>, DmRawOp<false>> DmPairOp;                      // plus_dm, minus_dm

@@ -44,6 +44,7 @@ template <bool NATR> // volatility.rs:18-31 / :34-48: calc_ema(trange, 2p-1) [/ 
 struct AtrOp {
     static constexpr int NIN = 3, NOUT = 1;
     static constexpr int SEQ_ID = 40 + (NATR ? 1 : 0);
+    static constexpr int COST_NS = 200;
     int64_t p;
     EmaCore e;
     double pc;
@@ -56,6 +57,15 @@ struct AtrOp {
         if (NATR) y[0] = (pq_isnull(a) || pq_isnull(x[2])) ? pq_null() : a / x[2] * 100.0;
         else y[0] = a;
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 > 0 && e.steady() && !pq_isnull(pc); }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[1]) {
+        const double tr = true_range(x[0], x[1], pc);
+        pc = x[2];
+        const double a = e.fast(tr);
+        if (NATR) y[0] = a / x[2] * 100.0;
+        else y[0] = a;
+    }
 };
 
 // ---------------------------------------------------------------- volume.rs
@@ -63,6 +73,7 @@ template <bool OSC> // volume.rs:100-126 calc_ad (quirk Q-AD); OSC: volume.rs:34
 struct AdOp {
     static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume
     static constexpr int SEQ_ID = 42 + (OSC ? 1 : 0);
+    static constexpr int COST_NS = OSC ? 350 : 250;
     int64_t fast, slow;
     double sum, sum2;
     EmaCore ef, es;
@@ -81,10 +92,23 @@ struct AdOp {
         double f = ef.step(adl), s = es.step(adl);
         y[0] = (pq_isnull(f) || pq_isnull(s)) ? pq_null() : f - s;
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return !OSC || (ef.steady() && es.steady()); }
+    __device__ void step_fast(int64_t, const double (&x)[4], double (&y)[1]) {
+        const double diff = x[0] - x[1];
+        const double add = sum + (2.0 * x[2] - x[1] - x[0]) / diff * x[3]; // unused (and possibly inf / nan) on flat bars
+        sum = (diff == 0.0) ? sum : add;
+        const double ad = (diff == 0.0) ? 0.0 : sum;
+        if (!OSC) { y[0] = ad; return; }
+        sum2 += ad;
+        const double f = ef.fast(sum2), s = es.fast(sum2);
+        y[0] = f - s;
+    }
 };
 struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
     static constexpr int NIN = 2, NOUT = 1; // close, volume
     static constexpr int SEQ_ID = 44;
+    static constexpr int COST_NS = 120;
     double sum, pc;
     __device__ void init(const Row<2> &) { sum = 0.0; pc = pq_null(); }
     __device__ void step(const Row<2> &, int64_t t, const double (&x)[2], double (&y)[1]) {
@@ -94,6 +118,15 @@ struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
         double c_diff = prev - x[0];
         if (c_diff > 0.0) sum += x[1];
         else if (c_diff < 0.0) sum -= x[1];
+        y[0] = sum;
+    }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 > 0 && !pq_isnull(pc); }
+    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) {
+        const double c_diff = pc - x[0];
+        pc = x[0];
+        const double up = sum + x[1], dn = sum - x[1];
+        sum = (c_diff > 0.0) ? up : ((c_diff < 0.0) ? dn : sum);
         y[0] = sum;
     }
 };
@@ -107,6 +140,8 @@ template <int MODE>
 struct HtOp {
     static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
     static constexpr int SEQ_ID = 45 + MODE;
+    static constexpr int COST_NS = 880;
+    static constexpr bool HEAVY = MODE != 2; // ~230 live VGPRs (four 7-deep delay lines); the phasor form fits the light kernel
     double fastlimit, slowlimit; // MODE 4
     double rl[4];                // real[i], real[i-1], real[i-2], real[i-3]
     double sm[7];                // smooth[i] ... smooth[i-6]
@@ -128,17 +163,23 @@ struct HtOp {
         i2 = q2 = re = im = period = smooth_period = 0.0;
         mama = fama = prev_phase = 0.0;
     }
-    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[NOUT]) {
+    static constexpr bool FAST_NULL_OK = true; // N-B (MODE 4: N-0, nulls become 0.0 in the row body itself)
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return !dead && t0 >= 32; } // every warm-up test of the row body is past
+    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<true>(i, x, y); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<false>(i, x, y); }
+    template <bool FAST> // FAST: i >= 32 and !dead are known
+    __device__ __forceinline__ void row(int64_t i, const double (&x)[1], double (&y)[NOUT]) {
 #pragma unroll
         for (int k = 0; k < NOUT; k++) y[k] = pq_null();
-        if (dead) return;
+        if (!FAST && dead) return;
         double v = (MODE == 4) ? n0m(x[0]) : x[0];
         rl[3] = rl[2]; rl[2] = rl[1]; rl[1] = rl[0]; rl[0] = v;
         // cycle.rs:462-470 calc_smooth (0 for i < 3)
-        double s = (i >= 3) ? (4.0 * rl[0] + 3.0 * rl[1] + 2.0 * rl[2] + rl[3]) * 0.1 : 0.0;
+        double s = (FAST || i >= 3) ? (4.0 * rl[0] + 3.0 * rl[1] + 2.0 * rl[2] + rl[3]) * 0.1 : 0.0;
         push7(sm, s);
-        if (i < 6) return;
-        double prev_period = (i > 6) ? period : 6.0;
+        if (!FAST && i < 6) return;
+        double prev_period = (FAST || i > 6) ? period : 6.0;
         double adj = 0.075 * prev_period + 0.54;
         double detrend_curr = (0.0962 * sm[0] + 0.5769 * sm[2] - 0.5769 * sm[4] - 0.0962 * sm[6]) * adj;
         push7(detrend, detrend_curr);
@@ -161,9 +202,9 @@ struct HtOp {
         period = 0.2 * period + 0.8 * prev_period;
         if (MODE == 0) {
             smooth_period = 0.33 * period + 0.67 * smooth_period;
-            if (i >= 31) y[0] = smooth_period;
+            if (FAST || i >= 31) y[0] = smooth_period;
         } else if (MODE == 1) {
-            if (i >= 31) {
+            if (FAST || i >= 31) {
                 double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
                 dc_phase += 90.0;
                 if (i1[0] < 0.0) dc_phase += 180.0;
@@ -171,9 +212,9 @@ struct HtOp {
                 y[0] = dc_phase;
             }
         } else if (MODE == 2) {
-            if (i >= 31) { y[0] = i1[0]; y[NOUT - 1] = q1[0]; }
+            if (FAST || i >= 31) { y[0] = i1[0]; y[NOUT - 1] = q1[0]; }
         } else if (MODE == 3) {
-            if (i >= 31) {
+            if (FAST || i >= 31) {
                 double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
                 y[0] = sin(dc_phase * PQ_PI / 180.0);
                 y[NOUT - 1] = sin((dc_phase + 45.0) * PQ_PI / 180.0);
@@ -189,7 +230,7 @@ struct HtOp {
             double ha = 0.5 * alpha;
             fama = ha * mama + (1.0 - ha) * fama;
             prev_phase = phase;
-            if (i >= 31) { y[0] = mama; y[NOUT - 1] = fama; }
+            if (FAST || i >= 31) { y[0] = mama; y[NOUT - 1] = fama; }
         }
     }
 };

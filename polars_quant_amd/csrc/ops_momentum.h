@@ -141,6 +141,7 @@ struct BinOp {
 struct CmoOp { // momentum.rs:181-223: rolling SUMS of up/down moves; the lagged terms are recomputed
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 20;
+    static constexpr int COST_NS = 220;
     static constexpr int NTAP = 2;
     static constexpr int TAP_COL[2] = {0, 0};
     int64_t p;
@@ -190,11 +191,31 @@ struct CmoOp { // momentum.rs:181-223: rolling SUMS of up/down moves; the lagged
             y[0] = (total == 0.0) ? 0.0 : 100.0 * (su - sd) / total;
         }
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B: no null handling in the row body
+    __device__ static void updown_sel(double curr, double prv, double &u, double &d) { // updown() with selects
+        const double diff = curr - prv;
+        u = (diff > 0.0) ? diff : 0.0;
+        d = (diff > 0.0) ? 0.0 : -diff;
+    }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return p > 0 && t0 >= p + 2; } // the lagged pair is rows >= 1
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        double u, d, ou, od;
+        updown_sel(x[0], prev, u, d);
+        prev = x[0];
+        su += u; sd += d;
+        updown_sel(w.get((int)p), w.get((int)p + 1), ou, od);
+        su -= ou; sd -= od;
+        w.push(x[0]);
+        const double total = su + sd;
+        y[0] = (total == 0.0) ? 0.0 : 100.0 * (su - sd) / total;
+    }
 };
 
 struct RsiOp { // momentum.rs:507-541
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 21;
+    static constexpr int COST_NS = 250;
     int64_t p;
     RmaCore au, ad;
     double prev;
@@ -208,11 +229,24 @@ struct RsiOp { // momentum.rs:507-541
         if (b == 0.0) y[0] = 100.0;
         else { double rs = a / b; y[0] = 100.0 - (100.0 / (1.0 + rs)); }
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 >= 1 && au.steady(t0) && ad.steady(t0); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        double u, d;
+        CmoOp::updown_sel(x[0], prev, u, d);
+        prev = x[0];
+        const double a = au.fast(u), b = ad.fast(d);
+        const double rs = a / b;
+        const double v = 100.0 - (100.0 / (1.0 + rs));
+        y[0] = (b == 0.0) ? 100.0 : v;
+    }
 };
 
 struct MacdOp { // momentum.rs:250-283 (quirk Q-MACD: signal = EMA(dif with None -> 0.0))
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int SEQ_ID = 22;
+    static constexpr int COST_NS = 261;
     int64_t fast, slow, sig;
     EmaCore ef, es, eg;
     __device__ void init(const Row<1> &r) { ef.init(fast, r.len); es.init(slow, r.len); eg.init(sig, r.len); }
@@ -223,11 +257,21 @@ struct MacdOp { // momentum.rs:250-283 (quirk Q-MACD: signal = EMA(dif with None
         y[0] = dif; y[1] = dea;
         y[2] = (!pq_isnull(dif) && !pq_isnull(dea)) ? dif - dea : pq_null();
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return ef.steady() && es.steady() && eg.steady(); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
+        const double f = ef.fast(x[0]), s = es.fast(x[0]);
+        const double dif = f - s;
+        const double dea = eg.fast(dif);
+        y[0] = dif; y[1] = dea; y[2] = dif - dea;
+    }
 };
 
 struct TrixOp { // momentum.rs:544-569 (quirk Q-TRIX)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 23;
+    static constexpr int COST_NS = 200;
     int64_t p;
     EmaCore e1, e2, e3;
     double prev3;
@@ -240,11 +284,23 @@ struct TrixOp { // momentum.rs:544-569 (quirk Q-TRIX)
         if (i >= 1 && !pq_isnull(c) && !pq_isnull(prev3) && prev3 != 0.0) y[0] = (c - prev3) / prev3 * 100.0;
         prev3 = c;
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 >= 1 && e1.steady() && e2.steady() && e3.steady() && !pq_isnull(prev3); }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        const double a = e1.fast(x[0]);
+        const double b = e2.fast(a);
+        const double c = e3.fast(b);
+        const double v = (c - prev3) / prev3 * 100.0;
+        y[0] = (prev3 != 0.0) ? v : pq_null();
+        prev3 = c;
+    }
 };
 
 struct UltoscOp { // momentum.rs:572-627
     static constexpr int NIN = 3, NOUT = 1; // high, low, close
     static constexpr int SEQ_ID = 24;
+    static constexpr int COST_NS = 517;
     static constexpr int TILE_K = 4; // 4-row tiles: 36.4 KB instead of 42.5 KB with the default periods, i.e. 4 workgroups per CU
     static constexpr int NTAP = 12; // per window: high, low, close at i-p and close at i-p-1
     static constexpr int TAP_COL[12] = {0, 1, 2, 2, 0, 1, 2, 2, 0, 1, 2, 2};
@@ -309,11 +365,33 @@ struct UltoscOp { // momentum.rs:572-627
         wb.push(bp); wt.push(tr);
         if (ok) y[0] = 100.0 * (4.0 * a[0] + 2.0 * a[1] + a[2]) / 7.0;
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return p1 > 0 && p2 > 0 && p3 > 0 && t0 >= 1 && t0 >= pmax(); }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[1]) {
+        double bp, tr;
+        bptr(x[0], x[1], x[2], prev_c, bp, tr);
+        prev_c = x[2];
+        const int64_t ps[3] = {p1, p2, p3};
+        double a[3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            sb[k] += bp; st[k] += tr;
+            sb[k] -= wb.get((int)ps[k]); st[k] -= wt.get((int)ps[k]);
+            a[k] = sb[k] / st[k];
+            ok = ok && st[k] != 0.0;
+        }
+        wb.push(bp); wt.push(tr);
+        const double v = 100.0 * (4.0 * a[0] + 2.0 * a[1] + a[2]) / 7.0;
+        y[0] = ok ? v : pq_null();
+    }
 };
 
 struct MfiOp { // momentum.rs:286-342
     static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume
     static constexpr int SEQ_ID = 25;
+    static constexpr int COST_NS = 500;
     static constexpr int NTAP = 7; // high, low, close, volume at i-p; high, low, close at i-p-1
     static constexpr int TAP_COL[7] = {0, 1, 2, 3, 0, 1, 2};
     int64_t p;
@@ -375,6 +453,25 @@ struct MfiOp { // momentum.rs:286-342
         prev_tp = tp;
         if (p > 0) { wtp.push(tp); wmf.push(mf); }
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return p > 0 && t0 >= p + 1; } // the removed row q = i - p is >= 1
+    __device__ void step_fast(int64_t, const double (&x)[4], double (&y)[1]) {
+        const double tp = (x[0] + x[1] + x[2]) / 3.0;
+        const double mf = tp * x[3];
+        const double padd = pos + mf, nadd = neg + mf;
+        pos = (tp > prev_tp) ? padd : pos;
+        neg = (tp < prev_tp) ? nadd : neg;
+        const double tq = wtp.get((int)p), tq1 = wtp.get((int)p + 1), mq = wmf.get((int)p);
+        const double psub = pos - mq, nsub = neg - mq;
+        pos = (tq > tq1) ? psub : pos;
+        neg = (tq < tq1) ? nsub : neg;
+        const double mr = pos / neg;
+        const double v = 100.0 - (100.0 / (1.0 + mr));
+        y[0] = (neg == 0.0) ? 100.0 : v;
+        prev_tp = tp;
+        wtp.push(tp); wmf.push(mf);
+    }
 };
 
 // momentum.rs:668-727 calc_dm + its users.  MODE: 0 dx (also plus_di, quirk Q-PDI / D-5), 1 minus_di, 2 adx
@@ -382,6 +479,7 @@ template <int MODE>
 struct DmOp {
     static constexpr int NIN = 3, NOUT = 1; // high, low, close
     static constexpr int SEQ_ID = 26 + MODE;
+    static constexpr int COST_NS = 450;
     int64_t p;
     RmaCore rp, rm, rt, radx;
     double ph, pl, pc;
@@ -417,11 +515,38 @@ struct DmOp {
         else if (MODE == 1) y[0] = mdi;
         else y[0] = adx;
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    // all four Wilder averages seeded (the ADX one is fed z0(dx) on every row, so it is seeded at row p - 1 as well)
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 >= 1 && rp.steady(t0) && (MODE != 2 || radx.steady(t0)); }
+    __device__ double fast_all(const double (&x)[3], double &dx, double &mdi) {
+        const double up_move = x[0] - ph, down_move = pl - x[1];
+        const double p_dm = (up_move > down_move && up_move > 0.0) ? up_move : 0.0;
+        const double m_dm = (down_move > up_move && down_move > 0.0) ? down_move : 0.0;
+        const double tr = fmax(fmax(x[0] - x[1], fabs(x[0] - pc)), fabs(x[1] - pc));
+        ph = x[0]; pl = x[1]; pc = x[2];
+        const double sp = rp.fast(p_dm), sm = rm.fast(m_dm), st = rt.fast(tr);
+        const double pdi = 100.0 * sp / st, mdi_ = 100.0 * sm / st;
+        const double diff = fabs(pdi - mdi_), sum = pdi + mdi_;
+        const double dxv = 100.0 * diff / sum;
+        const bool ok = st != 0.0;
+        mdi = ok ? mdi_ : pq_null();
+        dx = ok ? ((sum == 0.0) ? 0.0 : dxv) : pq_null();
+        return (MODE == 2) ? radx.fast(ok ? ((sum == 0.0) ? 0.0 : dxv) : 0.0) : pq_null();
+    }
+    __device__ void step_fast(int64_t, const double (&x)[3], double (&y)[1]) {
+        double dx, mdi;
+        double adx = fast_all(x, dx, mdi);
+        if (MODE == 0) y[0] = dx;
+        else if (MODE == 1) y[0] = mdi;
+        else y[0] = adx;
+    }
 };
 template <bool PLUS> // momentum.rs:414-436 / :359-381
 struct DmRawOp {
     static constexpr int NIN = 2, NOUT = 1; // high, low
     static constexpr int SEQ_ID = 29 + (PLUS ? 0 : 1);
+    static constexpr int COST_NS = 120;
     int64_t p;
     RmaCore rr;
     double ph, pl;
@@ -436,10 +561,22 @@ struct DmRawOp {
         ph = x[0]; pl = x[1];
         y[0] = rr.step(i, d);
     }
+    static constexpr bool FAST_NULL_OK = true; // N-B
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return t0 >= 1 && rr.steady(t0); }
+    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) {
+        const double up_move = x[0] - ph, down_move = pl - x[1];
+        double d;
+        if (PLUS) d = (up_move > down_move && up_move > 0.0) ? up_move : 0.0;
+        else d = (down_move > up_move && down_move > 0.0) ? down_move : 0.0;
+        ph = x[0]; pl = x[1];
+        y[0] = rr.fast(d);
+    }
 };
 struct SmaTpOp { // momentum.rs:148-158: calc_sma(tp) on a null-free slice; the lagged tp is recomputed
     static constexpr int NIN = 3, NOUT = 1;
     static constexpr int SEQ_ID = 31;
+    static constexpr int COST_NS = 150;
     static constexpr int NTAP = 3;
     static constexpr int TAP_COL[3] = {0, 1, 2};
     int64_t p;

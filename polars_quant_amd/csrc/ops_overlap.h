@@ -7,6 +7,7 @@
 struct SmaOp { // overlap.rs:871-937
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 1;
+    static constexpr int COST_NS = 116;
     static constexpr int NTAP = 1;
     static constexpr int TAP_COL[1] = {0};
     int64_t p;
@@ -20,6 +21,7 @@ struct SmaOp { // overlap.rs:871-937
     __host__ __device__ int64_t ring_slots() const { return p > 0 ? p : 1; }
     __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { c.init(p, r.len); w = ra.make(p); }
     __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.step_ring(w, x[0]); }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return c.steady(); }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.fast_ring(w, x[0]); }
 };
@@ -27,10 +29,12 @@ struct SmaOp { // overlap.rs:871-937
 struct EmaOp { // overlap.rs:660-730
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 2;
+    static constexpr int COST_NS = 100;
     int64_t p;
     EmaCore c;
     __device__ void init(const Row<1> &r) { c.init(p, r.len); }
     __device__ void step(const Row<1> &, int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.step(x[0]); }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return c.steady(); }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.fast(x[0]); }
 };
@@ -38,6 +42,7 @@ struct EmaOp { // overlap.rs:660-730
 struct BbandsOp { // overlap.rs:47-116
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int SEQ_ID = 3;
+    static constexpr int COST_NS = 263;
     static constexpr int NTAP = 1;
     static constexpr int TAP_COL[1] = {0};
     int64_t p;
@@ -86,6 +91,7 @@ struct BbandsOp { // overlap.rs:47-116
         double sd = sqrt(fmax(variance, 0.0));
         y[0] = mean + up * sd; y[1] = mean; y[2] = mean - dn * sd;
     }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return !dead && count >= p; } // full window: count stays at p
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
         const double v = x[0];
@@ -102,6 +108,7 @@ struct BbandsOp { // overlap.rs:47-116
 struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 4;
+    static constexpr int COST_NS = 105;
     int64_t p, count;
     double alpha, e0, e1, s0, s1;
     bool dead;
@@ -125,6 +132,7 @@ struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
             y[0] = 2.0 * e0 - e1;
         }
     }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return !dead && count >= 2 * p - 1; } // every later valid row is the last branch
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
         e0 = fma(alpha, x[0] - e0, e0);
@@ -136,6 +144,7 @@ struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
 struct TemaOp { // overlap.rs:1177-1311
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 5;
+    static constexpr int COST_NS = 110;
     int64_t p, count;
     double alpha, e0, e1, e2, s0, s1, s2;
     bool dead;
@@ -160,6 +169,7 @@ struct TemaOp { // overlap.rs:1177-1311
         else e2 = fma(alpha, e1 - e2, e2);
         y[0] = 3.0 * e0 - 3.0 * e1 + e2;
     }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return !dead && count >= 3 * p - 2; }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
         e0 = fma(alpha, x[0] - e0, e0);
@@ -172,6 +182,7 @@ struct TemaOp { // overlap.rs:1177-1311
 struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e5 never seeded)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 6;
+    static constexpr int COST_NS = 106;
     int64_t p, count;
     double alpha, c1, c2, c3, c4;
     double e0, e1, e2, e3, e4, e5, s0, s1, s2, s3, s4, s5;
@@ -206,6 +217,7 @@ struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e
         e5 = fma(alpha, e4 - e5, e5);
         y[0] = fma(c1, e5, fma(c2, e4, fma(c3, e3, c4 * e2)));
     }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return !dead && count >= 6 * p - 5; }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
         e0 = fma(alpha, x[0] - e0, e0);
@@ -221,6 +233,7 @@ struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e
 struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 7;
+    static constexpr int COST_NS = 146;
     static constexpr int NTAP = 1;
     static constexpr int TAP_COL[1] = {0};
     int64_t p, count;
@@ -265,6 +278,7 @@ struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
         if (count > p) { numerator -= ((double)p) * old; count -= 1; }
         y[0] = numerator / denominator;
     }
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return !dead && count >= p; } // full window: count stays at p
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
         numerator += ((double)(p + 1)) * x[0]; // the general path multiplies by (double)count after its increment to p + 1
@@ -277,6 +291,7 @@ struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
 struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 8;
+    static constexpr int COST_NS = 178;
     static constexpr int NTAP = 3;
     static constexpr int TAP_COL[3] = {0, 0, 0};
     int64_t p;
@@ -365,6 +380,7 @@ struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
         y[0] = kama;
     }
     // count saturated at p, the popped diff is a p-lag diff (k = j-p+1 >= p), pass 2 seeded (c2 > p): j and c2 stop mattering
+    static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return !dead && count >= p && j >= 2 * p - 1 && c2 > p; }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
         const double v = x[0];
@@ -384,6 +400,7 @@ struct KamaOp { // overlap.rs:732-855, both passes fused into one walk
 struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires => cumulative min)
     static constexpr int NIN = 1, NOUT = 1;
     static constexpr int SEQ_ID = 9;
+    static constexpr int COST_NS = 246;
     int64_t p;
     RollExt<true> mx;
     double mn;
@@ -406,11 +423,20 @@ struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires =
         if (!any || v <= mn) { mn = v; any = true; }
         y[0] = (m + mn) / 2.0;
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return p > 0 && any; }
+    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+        const double v = x[0];
+        const double m = mx.step_ring2(wc, ws, v);
+        mn = (v <= mn) ? v : mn;
+        y[0] = (m + mn) / 2.0;
+    }
 };
 
 struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either input -> null (D-7)
     static constexpr int NIN = 2, NOUT = 1;
     static constexpr int SEQ_ID = 10;
+    static constexpr int COST_NS = 416;
     int64_t p;
     RollExt<true> mx;
     RollExt<false> mn;
@@ -435,6 +461,13 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
         if (!pq_isnull(x[1])) lm = mn.step_ring2(wlc, wls, x[1]);
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
     }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t) const { return p > 0; }
+    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) {
+        const double hm = mx.step_ring2(whc, whs, x[0]);
+        const double lm = mn.step_ring2(wlc, wls, x[1]);
+        y[0] = (hm + lm) / 2.0;
+    }
 };
 
 // SAR / SAREXT (decision D-4: TA-Lib algorithm; nulls -> 0.0 as overlap.rs:445-450)
@@ -443,6 +476,7 @@ __device__ __forceinline__ double n0(double x) { return pq_isnull(x) ? 0.0 : x; 
 struct SarextOp {
     static constexpr int NIN = 2, NOUT = 1;
     static constexpr int SEQ_ID = 11;
+    static constexpr int COST_NS = 450;
     bool ext; // false: plain SAR (no offset, no negation)
     double startvalue, offset, ai_long, a_long, am_long, ai_short, a_short, am_short;
     double af_long, af_short, ep, sar, new_low, new_high;
@@ -466,6 +500,13 @@ struct SarextOp {
     __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
         y[0] = pq_null();
         if (r.len < 2 || t == 0) return;
+        row(x, y);
+    }
+    static constexpr bool HAS_FAST = true;
+    static constexpr bool FAST_NULL_OK = true; // N-0: nulls become 0.0 in the row body
+    __device__ bool steady(int64_t t0) const { return t0 >= 1; } // rows >= 1 exist, so the series has at least two
+    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) { row(x, y); }
+    __device__ __forceinline__ void row(const double (&x)[2], double (&y)[1]) {
         double prev_low = new_low, prev_high = new_high;
         new_high = n0(x[0]); new_low = n0(x[1]);
         if (is_long) {

@@ -230,7 +230,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d) {
         if (a.out[id] == nullptr) continue; // wave-uniform
         int lb;
         int v = cdl_eval(id, w, a.pen[id], &lb);
+#ifdef PQ_EXP_NOSTORE
+        if (v == 123456789) a.out[id][base + t] = v;
+#else
         __builtin_nontemporal_store((t >= lb) ? v : 0, &a.out[id][base + t]);
+#endif
     }
 }
 

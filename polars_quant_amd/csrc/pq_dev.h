@@ -112,6 +112,7 @@ template <class Op>
 struct IsMasked<Op, decltype((void)Op::MASKED)> { static constexpr bool value = Op::MASKED; };
 
 // Steady-state fast path (optional).  An op that declares
+//   static constexpr bool HAS_FAST = true;
 //   __device__ bool steady(int64_t t0) const;        // per lane: from row t0 on every row takes the op's steady-state path
 //   __device__ void step_fast(int64_t t, const double (&x)[NIN], double (&y)[NOUT]);
 // gets whole tiles walked by step_fast -- straight-line code, unrolled, no per-row warm-up / null branching -- whenever
@@ -120,7 +121,7 @@ struct IsMasked<Op, decltype((void)Op::MASKED)> { static constexpr bool value = 
 template <class Op, class = void>
 struct HasFast { static constexpr bool value = false; };
 template <class Op>
-struct HasFast<Op, decltype((void)&Op::steady)> { static constexpr bool value = true; };
+struct HasFast<Op, decltype((void)Op::HAS_FAST)> { static constexpr bool value = Op::HAS_FAST; };
 template <class Op, class = void>
 struct FastNullOk { static constexpr bool value = false; }; // true: the op never looks at null flags (N-B family)
 template <class Op>
@@ -129,6 +130,24 @@ template <class Op, class = void>
 struct FastUnroll { static constexpr int value = 2; };      // rows per unrolled fast-loop iteration
 template <class Op>
 struct FastUnroll<Op, decltype((void)Op::FAST_UNROLL)> { static constexpr int value = Op::FAST_UNROLL; };
+
+// Scheduling traits of a recordable op (suite.hip orders and groups jobs by them; nothing here is tied to a SEQ_ID):
+//   static constexpr int COST_NS = ...;        solo cost of one row of the tiled body in ns (measured on MI355X at 5000 x 2520,
+//                                              scripts/exp_solo.py); or, where the cost depends on a parameter,
+//   __host__ int cost_ns() const;              the same from the op's parameters
+//   static constexpr bool HEAVY = true;        needs more than the light job kernel's 168 VGPRs: runs in the 2-waves/SIMD kernel
+template <class Op, class = void>
+struct OpCostStatic { static constexpr int value = 60 + 40 * (Op::NIN + Op::NOUT); };
+template <class Op>
+struct OpCostStatic<Op, decltype((void)Op::COST_NS)> { static constexpr int value = Op::COST_NS; };
+template <class Op, class = void>
+struct OpCost { static int get(const Op &) { return OpCostStatic<Op>::value; } };
+template <class Op>
+struct OpCost<Op, decltype((void)&Op::cost_ns)> { static int get(const Op &op) { return op.cost_ns(); } };
+template <class Op, class = void>
+struct IsHeavy { static constexpr bool value = false; };
+template <class Op>
+struct IsHeavy<Op, decltype((void)Op::HEAVY)> { static constexpr bool value = Op::HEAVY; };
 
 template <class Op, class = void>
 struct NTap { static constexpr int value = 0; };
@@ -352,7 +371,10 @@ constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to th
 // wave 0's counter holds loads only and the prefetch is waited for exactly; wave 1 never waits on vmcnt at all.
 // Hand-off per tile: wave 0 finishes the out tile in LDS -> barrier A -> wave 1 pulls it into registers -> barrier B ->
 // wave 1 issues the global stores while wave 0 already overwrites LDS with the next input tile.
-constexpr int SEQ_LDS_BLOCK = 128;
+#ifndef PQ_SINGLE_WAVE
+#define PQ_SINGLE_WAVE 0 // experiment: one-wave workgroups, the compute wave stores its own out tiles
+#endif
+constexpr int SEQ_LDS_BLOCK = PQ_SINGLE_WAVE ? 64 : 128;
 #ifdef PQ_PROFILE_WAVES // experiment: where does the compute wave spend its cycles? [job][load wait+LDS fill, rows, hand-off, tiles]
 static __device__ unsigned long long pq_prof[128][4]; // indexed by Op::SEQ_ID
 template <class Op, class = void> struct ProfId { static constexpr int value = 0; };
@@ -368,8 +390,12 @@ template <class Op> struct ProfId<Op, decltype((void)Op::SEQ_ID)> { static const
 // (scripts/ubench/tilecopy2): 2.9 -> 4.3 TB/s of stores.
 typedef double pq_d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
+#ifdef PQ_EXP_NOSTORE // experiment: how much of the step is the output traffic?  (only a never-true store is left)
+    if (v.x == 1.2345e-300) *p = v.y;
+#else
     pq_d2v w = {v.x, v.y};
     __builtin_nontemporal_store(w, reinterpret_cast<pq_d2v *>(p));
+#endif
 }
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
@@ -397,7 +423,32 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #ifdef PQ_PROFILE_WAVES
     if (lane == 0) atomicAdd(&pq_prof[120 + (__builtin_amdgcn_s_getreg(2308) & 3)][wave], 1ULL); // SIMD id histogram per wave role
 #endif
-    if (wave == 1) { // ---------------------------------------------------------------- storer
+    // hand-off of a finished out tile: two-wave form = barriers A / B with the storer; one-wave form = this wave pulls the
+    // tile back into registers and issues the coalesced stores itself (they stay in flight under the next tile: the
+    // prefetched loads of the next tile were issued BEFORE them and vmcnt retires in issue order)
+    auto hand_off = [&](int64_t t0) {
+        if constexpr (MASKED) return;
+        if constexpr (PQ_SINGLE_WAVE) {
+            double2 v[NOUT][NI];
+#pragma unroll
+            for (int k = 0; k < NOUT; k++)
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
+                    v[k][i] = make_double2(q[0], q[1]);
+                }
+            lds_fence();
+#pragma unroll
+            for (int k = 0; k < NOUT; k++)
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+                    if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0, v[k][i]);
+        } else {
+            __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
+            __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
+        }
+    };
+    if (!PQ_SINGLE_WAVE && wave == 1) { // ---------------------------------------------------------------- storer
         if constexpr (!MASKED) {
             for (int64_t it = 0; it < nt; it++) {
                 __builtin_amdgcn_s_barrier(); // A: out tile `it` is complete
@@ -499,10 +550,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     }
                 }
                 lds_fence();
-                if constexpr (!MASKED) {
-                    __builtin_amdgcn_s_barrier(); // A
-                    __builtin_amdgcn_s_barrier(); // B
-                }
+                hand_off(t0);
                 return;
             }
         }
@@ -537,10 +585,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         }
         lds_fence();
         PQ_PROF_T(c2);
-        if constexpr (!MASKED) {
-            __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
-            __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
-        }
+        hand_off(t0);
         PQ_PROF_T(c3);
         PQ_PROF_ADD(0, c1 - c0); PQ_PROF_ADD(1, c2 - c1); PQ_PROF_ADD(2, c3 - c2); PQ_PROF_ADD(3, 1);
     };
@@ -566,7 +611,12 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     }
     if constexpr (HasFinish<Op>::value) {
         static_assert(!MASKED, "finish() is not supported for row-masked ops");
-        __builtin_amdgcn_s_barrier(); // C: wave 1's stores have been acknowledged
+        if constexpr (PQ_SINGLE_WAVE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store acknowledged
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        } else {
+            __builtin_amdgcn_s_barrier(); // C: wave 1's stores have been acknowledged
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (live) op.finish(outp, d, s);
     }
@@ -595,9 +645,18 @@ __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK) void seq_kernel(Op
 
 // ---- recording hooks (implemented in suite.hip)
 // a recordable SEQ op carries `static constexpr int SEQ_ID` = its switch case in the job grid (suite.hip)
-pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write = nullptr,
-                      int alg_cols = 0);
+struct SeqTraits { // what the scheduler needs to know about a recorded job
+    int kind;          // Op::SEQ_ID: the switch case of the job kernels
+    int cost;          // estimated solo duration of the job, microseconds
+    bool heavy;        // register-heavy kernel variant
+    bool masked;       // writes only some rows of its output column(s): several such jobs may share a column
+    size_t lds_bytes;  // 0 = run the gather body
+    size_t tile_bytes;
+    int alg_cols;      // f64 column transfers credited (per reference call)
+    double summary_bytes_per_series; // extra algorithmic bytes per series (the backtest's summary row)
+};
+pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const void *op, size_t op_bytes, const double *const *in,
+                      int nin, double *const *out, int nout, void *extra_write = nullptr);
 struct RowThunk { // type-erased ROW launch for replay
     int kind = -1; // Op::ROW_ID when the op can run inside the fused row_jobs_kernel of a suite (blob = RowBlob<Op>), else -1
     void (*launch)(const void *blob, hipStream_t stream);
@@ -648,8 +707,9 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
             static_assert(sizeof(Op) <= 1024, "SEQ op too large for a job slot");
             void *extra = nullptr;
             if constexpr (HasFinish<Op>::value) extra = op.finish_writes();
-            return rec_add_seq(ctx, b, Op::SEQ_ID, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, use_lds ? lds : 0,
-                               SeqTile<Op>::BYTES, extra, AlgCols<Op>::value);
+            SeqTraits tr{Op::SEQ_ID, (int)((double)OpCost<Op>::get(op) * (double)b->len * 1e-3), IsHeavy<Op>::value, IsMasked<Op>::value,
+                         use_lds ? lds : 0, (size_t)SeqTile<Op>::BYTES, AlgCols<Op>::value, HasFinish<Op>::value ? 64.0 : 0.0};
+            return rec_add_seq(ctx, b, tr, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, extra);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");
             return PQ_ERR_UNSUPPORTED;
@@ -682,7 +742,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> i
     typename Op::OutT y[Op::NOUT];
     op.eval(r, t, y);
 #pragma unroll
+#ifdef PQ_EXP_NOSTORE
+    for (int k = 0; k < Op::NOUT; k++) if (y[k] == (typename Op::OutT)123456789) out.p[k][s * d.stride + t] = y[k];
+#else
     for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][s * d.stride + t]); // written once, not re-read
+#endif
 }
 constexpr int ROW_JOB_BLOB = 184; // bytes of a fused-row job slot
 template <class Op, class = void>

@@ -17,7 +17,9 @@
 #include <vector>
 
 struct SeqJob { // device-visible
-    int kind, nin, nout, cost;
+    int kind, nin, nout, cost; // cost: estimated solo duration in microseconds (SeqTraits)
+    int heavy, masked;
+    double summary_bytes;
     int alg_cols;                  // f64 column transfers credited (per reference call)
     unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
     double *ring_ws;               // non-null: rings in global memory, [tile][slot][lane]
@@ -74,18 +76,8 @@ static const Plan &plan() {
     }();
     return *p;
 }
-static bool kind_is_heavy(int kind);
-static int job_cost(int kind);
-static int job_class(int kind, unsigned lds) {
-    const Plan &pl = plan();
-    const bool bt = kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1;
-    const int variant = (kind_is_heavy(kind) && (lds > 0 || bt)) ? 1 : (lds == 0 ? 2 : 0);
-    for (int c = 0; c < pl.ncls; c++)
-        if (pl.cls[c].variant == variant && (variant == 2 || (lds > pl.cls[c].lds_lo && lds <= pl.cls[c].lds_hi)) &&
-            job_cost(kind) <= pl.cls[c].max_cost)
-            return c;
-    return pl.ncls - 1;
-}
+struct SeqJob;
+static int job_class(const SeqJob &j);
 // Timed gate in front of a grid of short jobs (wall_clock64: 100 MHz).  Bounded: it only ever waits for time to pass.
 __global__ void gate_kernel(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
@@ -134,17 +126,29 @@ struct pq_suite {
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<0>) X(MavpBlockOp<1>) X(MavpSma16Op)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(HtOp<4>) X(BtMacdOp)                                     \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(BtMacdOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
-    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
-static bool kind_is_heavy(int kind) { return kind == 45 || kind == 46 || kind == 48 || kind == 79 || kind == 74 || kind == 96 || kind == SEQ_ID_BACKTEST || kind == SEQ_ID_BACKTEST + 1; }
+    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
+static int job_class(const SeqJob &j) { // grid (ClassDef) a job runs in
+    const Plan &pl = plan();
+    const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
+    const int variant = (j.heavy && (j.lds_bytes > 0 || bt)) ? 1 : (j.lds_bytes == 0 ? 2 : 0);
+    for (int c = 0; c < pl.ncls; c++)
+        if (pl.cls[c].variant == variant && (variant == 2 || (j.lds_bytes > pl.cls[c].lds_lo && j.lds_bytes <= pl.cls[c].lds_hi)) &&
+            j.cost <= pl.cls[c].max_cost)
+            return c;
+    return pl.ncls - 1;
+}
 
 // V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
 __device__ int g_noprio = 0; // experiment switch
 template <int V>
-__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+#ifndef PQ_LB0
+#define PQ_LB0 3 // waves per SIMD the light kernel is compiled for (168 VGPRs)
+#endif
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];
     const SeqJob &job = jobs[blockIdx.y];
     if (dbg && threadIdx.x == 0) atomicMin(&dbg[2 * blockIdx.y], wall_clock64()); // PQ_SUITE_DEBUG: first start / last end per job
@@ -157,9 +161,9 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
     const int64_t s = s0 + threadIdx.x;
     if (s0 >= d.n) return; // grid.x is padded to a multiple of 8 (see pq_suite_run)
     // long jobs are the critical path of the step: their waves win the issue arbitration against short jobs on the same SIMD
-    if (g_noprio) {} else if (job.cost >= 200) __builtin_amdgcn_s_setprio(3);
-    else if (job.cost >= 140) __builtin_amdgcn_s_setprio(2);
-    else if (job.cost >= 100) __builtin_amdgcn_s_setprio(1);
+    if (g_noprio) {} else if (job.cost >= 1800) __builtin_amdgcn_s_setprio(3);
+    else if (job.cost >= 1300) __builtin_amdgcn_s_setprio(2);
+    else if (job.cost >= 900) __builtin_amdgcn_s_setprio(1);
 #define X(OP)                                                                                                        \
     case OP::SEQ_ID: {                                                                                               \
         OP op;                                                                                                       \
@@ -168,6 +172,9 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
         else                                                                                                         \
             run_seq_lds(op, job.in, job.out, d, s0, jobs_lds, job.ring_ws ? job.ring_ws + blockIdx.x * job.ring_stride : nullptr); \
     } break;
+    // the two lists must agree with the ops' HEAVY trait (which is what job_class() looks at)
+#define XL(OP) static_assert(!IsHeavy<OP>::value, "light list holds an op marked HEAVY"); X(OP)
+#define XH(OP) static_assert(IsHeavy<OP>::value, "heavy list holds an op not marked HEAVY"); X(OP)
     if constexpr (V == 2) {
         if (s >= d.n) return; // gather bodies are per-lane work
         switch (job.kind) {   // wave-uniform
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
         }
     } else if constexpr (V == 1) {
         switch (job.kind) {
-            SEQ_OPS_HEAVY(X)
+            SEQ_OPS_HEAVY(XH)
         case SEQ_ID_BACKTEST: { // one series per lane of wave 0, no tiles
             BtArgs a;
             __builtin_memcpy(&a, job.op, sizeof(BtArgs));
@@ -192,10 +199,12 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? 3 : 2)
         }
     } else {
         switch (job.kind) {
-            SEQ_OPS_LIGHT(X)
+            SEQ_OPS_LIGHT(XL)
         default: break;
         }
     }
+#undef XL
+#undef XH
 #undef X
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
@@ -220,47 +229,6 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJob *jobs,
 #undef X
         default: break;
         }
-    }
-}
-
-// solo replay time of the job at the suite's default parameters, in 0.01 ms per 2520 rows (measured, scripts/exp_solo.py):
-// orders jobs inside a grid (longest first) and splits long from short jobs
-static int job_cost(int kind) {
-    switch (kind) {
-    case 79: return 300;                       // ht_all
-    case 45: case 46: case 47: case 48: return 250; // single Hilbert outputs
-    case 49: return 200;                       // mama
-    case 25: return 270;                       // mfi
-    case 81: case 82: return 260;              // eight MAVP periods per walk
-    case 83: return 270;                       // sixteen MAVP periods per walk
-    case 90: return 160;                       // ema + dema + tema + trix
-    case 94: case 95: case 93: return 120;     // macd pair, apo + ppo, ad + adosc
-    case 97: return 150;                       // sar + sarext
-    case 98: return 300;                       // mfi + ad + adosc + obv
-    case 99: return 260;                       // dm family + atr + natr
-    case 89: return 130;                       // cmo + rsi
-    case 91: case 92: return 85;               // atr + natr, +dm / -dm
-    case 76: return 260;                       // stochrsi
-    case SEQ_ID_BACKTEST: case SEQ_ID_BACKTEST + 1: case 62: return 250;
-    case 74: case 78: case 80: case 77: return 235; // stoch, dm family, cci
-    case 96: return 260;                       // stoch + stochf
-    case 26: case 27: case 28: return 200;
-    case 75: return 200;                       // stochf
-    case 24: return 180;                       // ultosc
-    case 10: return 150;                       // midprice
-    case 73: return 146;                       // macdext
-    case 43: case 11: case 8: return 110;      // adosc, sar/sarext, kama
-    case 21: case 23: return 102;              // rsi, trix
-    case 71: case 72: case 22: case 6: return 97; // apo/ppo, macd, t3
-    case 3: return 85;
-    case 20: return 80;
-    case 41: case 9: return 73;
-    case 42: case 70: case 5: return 67;
-    case 40: case 29: case 30: return 60;
-    case 7: case 4: return 52;
-    case 1: case 44: return 46;
-    case 2: return 39;
-    default: return 60;
     }
 }
 
@@ -298,15 +266,17 @@ static pq_status same_batch(Recorder &r, const pq_batch *b) {
     return PQ_OK;
 }
 
-pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, int kind, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, size_t lds_bytes, size_t tile_bytes, void *extra_write, int alg_cols) {
+pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const void *op, size_t op_bytes, const double *const *in,
+                      int nin, double *const *out, int nout, void *extra_write) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
     if (nin > 6 || nout > 8) { pq_set_error("internal: SEQ job has too many columns"); return PQ_ERR_UNSUPPORTED; }
     SeqJob j;
     memset(&j, 0, sizeof j);
-    j.kind = kind; j.nin = nin; j.nout = nout; j.cost = job_cost(kind); j.lds_bytes = (unsigned)lds_bytes; j.tile_bytes = (unsigned)tile_bytes;
-    j.alg_cols = alg_cols > 0 ? alg_cols : nin + nout;
+    j.kind = tr.kind; j.nin = nin; j.nout = nout; j.cost = tr.cost; j.heavy = tr.heavy; j.masked = tr.masked;
+    j.lds_bytes = (unsigned)tr.lds_bytes; j.tile_bytes = (unsigned)tr.tile_bytes;
+    j.alg_cols = tr.alg_cols > 0 ? tr.alg_cols : nin + nout;
+    j.summary_bytes = tr.summary_bytes_per_series;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
     memcpy(j.op, op, op_bytes);
@@ -322,7 +292,8 @@ pq_status rec_add_backtest(pq_ctx *ctx, const pq_batch *b, int kind, const BtArg
     PQ_TRY(same_batch(r, b));
     SeqJob j;
     memset(&j, 0, sizeof j);
-    j.kind = kind; j.cost = job_cost(kind);
+    j.kind = kind; j.heavy = 1;
+    j.cost = (int)(650.0 * (double)b->len * 1e-3); // per-lane scan with 8-byte accesses: ~650 ns per row solo
     memcpy(j.op, &a, sizeof a);
     const void *reads[4] = {a.price, a.buy, a.sell, a.bench};
     void *writes[4] = {a.position, a.cash, a.equity, a.summary};
@@ -379,8 +350,10 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
             std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
             for (size_t k : idx) {
-                if (early < 0.5 * total) { early += weight(p.rows[k]); continue; } // (0 -> 6.1 ms, 0.7 -> same as 0.5)
-                p.row_late[k] = 1; // 1 + chain 0
+                static const double frac = getenv("PQ_ROW_EARLY") ? atof(getenv("PQ_ROW_EARLY")) : 0.5;
+                static const int late_chain = getenv("PQ_ROW_LATE_CHAIN") ? atoi(getenv("PQ_ROW_LATE_CHAIN")) : 0;
+                if (early < frac * total) { early += weight(p.rows[k]); continue; } // (0 -> 6.1 ms, 0.7 -> same as 0.5)
+                p.row_late[k] = 1 + late_chain;
             }
         }
         if (p.seq.empty()) continue;
@@ -398,7 +371,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) {
-            int ca = job_class(a.kind, a.lds_bytes), cb = job_class(b.kind, b.lds_bytes);
+            int ca = job_class(a), cb = job_class(b);
             if (ca != cb) return ca < cb;
             return a.cost > b.cost;
         });
@@ -407,7 +380,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         for (int c = 0; c <= NCLS; c++) p.first[c] = 0;
         for (int c = 0; c < NCLS; c++) { p.lds[c] = 0; p.gs[c].alg_bytes = 0; p.gs[c].n_jobs = 0; }
         for (const SeqJob &j : p.seq) {
-            const int g = job_class(j.kind, j.lds_bytes);
+            const int g = job_class(j);
             p.first[g + 1]++;
             p.lds[g] = std::max(p.lds[g], j.lds_bytes);
             // algorithmic bytes: 8 B per f64 column and row; a column written row-disjointly by several masked
@@ -415,9 +388,8 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             GridStat &st = p.gs[g];
             st.n_jobs++;
             if (j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1) { st.alg_bytes += 32.0 * rows + 64.0 * r.b.n_series; continue; }
-            if (j.kind == 62) st.alg_bytes += 64.0 * r.b.n_series; // + the summary row
-            const bool masked = (j.kind == 12) || (j.kind >= 100) || j.kind == 81 || j.kind == 82 || j.kind == 83;
-            if (!masked) { st.alg_bytes += 8.0 * rows * j.alg_cols; continue; }
+            st.alg_bytes += j.summary_bytes * r.b.n_series; // + the summary row of an op with an epilogue
+            if (!j.masked) { st.alg_bytes += 8.0 * rows * j.alg_cols; continue; }
             st.alg_bytes += 8.0 * rows * j.nin; // jobs that share one output column row-disjointly: the column counts once
             for (int k = 0; k < j.nout; k++) {
                 if (masked_seen[g][j.out[k]]++) continue;
@@ -545,7 +517,7 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             for (size_t i = 0; i < p.seq.size(); i++) t0 = t[2 * i] < t0 ? t[2 * i] : t0;
             for (size_t i = 0; i < p.seq.size(); i++)
                 fprintf(stderr, "[pq suite] job %2zu kind=%3d class=%d lds=%6u  start %8.1f us  end %8.1f us\n", i, p.seq[i].kind,
-                        job_class(p.seq[i].kind, p.seq[i].lds_bytes), p.seq[i].lds_bytes, (double)(t[2 * i] - t0) / 100.0,
+                        job_class(p.seq[i]), p.seq[i].lds_bytes, (double)(t[2 * i] - t0) / 100.0,
                         (double)(t[2 * i + 1] - t0) / 100.0);
             if (p.d_wg) {
                 std::vector<unsigned long long> w(3 * (size_t)tiles * p.seq.size());
