@@ -346,6 +346,54 @@ struct CciOp {
         const double v = (tp - avg) / (0.015 * md);
         y[0] = (mean_dev != 0.0) ? v : pq_null();
     }
+    // Eight rows at a time.  The windows of eight consecutive rows overlap in all but seven values: W = the seven values the
+    // batch pushes out of the ring + the ring after the batch's pushes (p values, oldest first); row r sums W[r .. r+p-1],
+    // oldest to newest (the reference's order), so the p + 7 values are read from LDS once per batch instead of p per row and
+    // the eight running sums are independent chains.
+    static constexpr bool FAST_BATCH = true;
+    static constexpr int FAST_UNROLL = 8;
+    template <int N>
+    __device__ void steps_fast(int64_t, const double (&x)[N][3], double (&y)[N][1]) {
+        static_assert(N == 8, "CciOp::steps_fast is written for batches of eight rows");
+        double tp[8], old[8], avg[8], md[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) tp[r] = (x[r][0] + x[r][1] + x[r][2]) / 3.0;
+        w.swap_n<8>(tp, old);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            sum += tp[r];
+            sum -= old[r];
+            avg[r] = sum * denom;
+            md[r] = 0.0;
+        }
+        double W[15]; // W[b0 .. b0+14] of the concatenated window list
+#pragma unroll
+        for (int i = 0; i < 7; i++) W[i] = old[i + 1];
+        int k = w.pos; // after the pushes: the oldest ring slot
+        const int ip = (int)p;
+        for (int b0 = 0; b0 < ip; b0 += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { // ring entries b0+i (reads beyond the window are masked below)
+                W[7 + i] = w.base[k * 64];
+                k = (k + 1 == w.depth) ? 0 : k + 1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) { // window element b0+i of every row: W[r + i]
+                if (b0 + i < ip) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) md[r] += fabs(W[r + i] - avg[r]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) W[i] = W[i + 8];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const double m = md[r] / (double)p;
+            const double v = pq_keep((tp[r] - avg[r]) / (0.015 * m));
+            y[r][0] = (md[r] != 0.0) ? v : pq_null();
+        }
+    }
 };
 
 // momentum.rs:668-727 calc_dm once for all five of its users: dx, plus_di (= dx, quirk Q-PDI), minus_di, adx, adxr
@@ -443,11 +491,13 @@ struct MavpSma16Op {
     Ring w;
     const double *tab; // 1/P for P = lo .. lo+15 (shared by the wave)
     double s[16];
-    __host__ __device__ int64_t ring_slots() const { return (hi > 0 ? hi : 1) + 1; }
+    // the ring keeps lo + 23 values: the batched fast path pushes eight rows first and then reads the 23 values
+    // x[t-lo-15 .. t+7-lo] the sixteen candidates need for those rows (the oldest was pushed lo + 23 pushes ago)
+    __host__ __device__ int64_t ring_slots() const { return (lo > 0 ? lo : 1) + 23 + 1; }
     __device__ void init(const Row<2> &) {}
     __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
         n = (int)(r.len < 0x7fffffff ? r.len : 0x7fffffff);
-        w = ra.make(hi);
+        w = ra.make((lo > 0 ? lo : 1) + 23);
         double *t = ra.make_shared(16);
         const int k = threadIdx.x & 63;
         if (k < 16) t[k] = 1.0 / (double)(lo + k);
@@ -487,7 +537,7 @@ struct MavpSma16Op {
         y[0] = mine ? (ok ? res : pq_null()) : pq_skip();
     }
     static constexpr bool FAST_NULL_OK = true; // N-0: nulls become 0.0 in the row body
-    static constexpr int FAST_UNROLL = 1;
+    static constexpr int FAST_UNROLL = 8;
     // every candidate window is full (c = t+1 > lo+15) and the output gate t >= maxp-1 is open; candidates beyond `hi` or
     // longer than the series carry garbage here that is never selected (pi is clamped into [minp, maxp] and `mine` tests
     // [lo, hi]) and that the general path resets to 0.0 on its next row
@@ -514,6 +564,51 @@ struct MavpSma16Op {
         const bool ok = pi > 0 && n >= pi;
         const double res = asel * tab[mine ? pi - lo : 0];
         y[0] = mine ? (ok ? res : pq_null()) : pq_skip();
+    }
+    // Eight rows at a time: candidate P = lo+u subtracts x[t+r-P] at row t+r, so rows r = 0..7 and u = 0..15 touch only the
+    // 23 values X[i] = x[t - lo - 15 + i], i = r - u + 15: one LDS read each per batch (instead of 16 per row), and the
+    // sixteen running sums are independent chains of plain register arithmetic.
+    static constexpr bool FAST_BATCH = true;
+    template <int N>
+    __device__ void steps_fast(int64_t, const double (&x)[N][2], double (&y)[N][1]) {
+        static_assert(N == 8, "MavpSma16Op::steps_fast is written for batches of eight rows");
+        double v[8];
+        int pi[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            v[r] = n0(x[r][0]);
+            const int64_t p64 = (int64_t)n0(x[r][1]);
+            pi[r] = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
+        }
+        w.push_n<8>(v);
+        double X[23];
+        {   // X[i] was pushed (23 + lo - i) pushes ago (X[22 + lo] would be the newest, v[7])
+            int k = w.pos - (23 + lo);
+            k += (k < 0) ? w.depth : 0;
+#pragma unroll
+            for (int i = 0; i < 23; i++) {
+                X[i] = w.base[k * 64];
+                k = (k + 1 == w.depth) ? 0 : k + 1;
+            }
+        }
+        double asel[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) asel[r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) { // row-major: sixteen independent chains advance together
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                s[u] = (s[u] + v[r]) - X[r - u + 15];
+                asel[r] = (lo + u == pi[r]) ? s[u] : asel[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool mine = pi[r] >= lo && pi[r] <= hi;
+            const bool ok = pi[r] > 0 && n >= pi[r];
+            const double res = asel[r] * tab[mine ? pi[r] - lo : 0];
+            y[r][0] = mine ? (ok ? res : pq_null()) : pq_skip();
+        }
     }
 };
 

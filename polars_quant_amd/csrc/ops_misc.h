@@ -8,7 +8,6 @@ __device__ __forceinline__ double n0m(double x) { return pq_isnull(x) ? 0.0 : x;
 // ---------------------------------------------------------------- price.rs (N-C, ROW)
 template <int KIND> // 0 avgprice(o,h,l,c) 1 medprice(h,l) 2 typprice(h,l,c) 3 wclprice(h,l,c)
 struct PriceOp {
-    static constexpr int ROW_ID = 1 + KIND;
     static constexpr int NIN = (KIND == 0 ? 4 : (KIND == 1 ? 2 : 3)), NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<NIN> &r, int64_t t, double (&y)[1]) {
@@ -29,7 +28,6 @@ __device__ __forceinline__ double true_range(double h, double l, double pc) { //
     return fmax(fmax(h - l, fabs(h - pc)), fabs(l - pc));
 }
 struct TrangeOp { // volatility.rs:67-84 (ROW; row 0 null because pre_close = close.shift(1))
-    static constexpr int ROW_ID = 5;
     static constexpr int NIN = 3, NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {
@@ -236,7 +234,6 @@ struct HtOp {
 };
 // cycle.rs:310-374 / :377-448: pure functions of real[i-3..i] (the pipeline result is unused)
 struct TrendlineOp {
-    static constexpr int ROW_ID = 6;
     static constexpr int NIN = 1, NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<1> &r, int64_t i, double (&y)[1]) {
@@ -249,7 +246,6 @@ struct TrendlineOp {
     }
 };
 struct TrendmodeOp {
-    static constexpr int ROW_ID = 7;
     static constexpr int NIN = 1, NOUT = 1;
     typedef int32_t OutT;
     __device__ void eval(const Row<1> &r, int64_t i, int32_t (&y)[1]) {

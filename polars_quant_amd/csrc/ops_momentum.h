@@ -11,7 +11,6 @@ __device__ __forceinline__ double z0(double x) { return pq_isnull(x) ? 0.0 : x; 
 // ---------------------------------------------------------------- ROW ops (exact, order-free)
 template <int KIND> // 0 mom, 1 roc, 2 rocp, 3 rocr, 4 rocr100   (momentum.rs:384-397, :439-504)
 struct LagOp {
-    static constexpr int ROW_ID = 8 + KIND;
     static constexpr int NIN = 1, NOUT = 1;
     typedef double OutT;
     int64_t p;
@@ -28,7 +27,6 @@ struct LagOp {
     }
 };
 struct BopOp { // momentum.rs:113-135
-    static constexpr int ROW_ID = 13;
     static constexpr int NIN = 4, NOUT = 1;
     typedef double OutT;
     __device__ void eval(const Row<4> &r, int64_t t, double (&y)[1]) {
@@ -38,7 +36,6 @@ struct BopOp { // momentum.rs:113-135
 };
 template <int MODE> // 0: (up, down)  1: up - down (AROONOSC, decision D-6)  2: (up, down, up - down) in one scan   momentum.rs:70-110
 struct AroonOp {
-    static constexpr int ROW_ID = MODE == 2 ? 17 : 14 + MODE;
     static constexpr int NIN = 2, NOUT = (MODE == 0 ? 2 : (MODE == 1 ? 1 : 3));
     typedef double OutT;
     int64_t p;
@@ -60,7 +57,6 @@ struct AroonOp {
     }
 };
 struct WillrOp { // momentum.rs:630-662
-    static constexpr int ROW_ID = 16;
     static constexpr int NIN = 3, NOUT = 1;
     typedef double OutT;
     int64_t p;

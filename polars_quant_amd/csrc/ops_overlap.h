@@ -24,6 +24,17 @@ struct SmaOp { // overlap.rs:871-937
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return c.steady(); }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.fast_ring(w, x[0]); }
+    static constexpr bool FAST_BATCH = true;
+    static constexpr int FAST_UNROLL = 16;
+    template <int N>
+    __device__ void steps_fast(int64_t, const double (&x)[N][1], double (&y)[N][1]) {
+        double v[N], o[N];
+#pragma unroll
+        for (int u = 0; u < N; u++) v[u] = x[u][0];
+        c.fast_ring_n<N>(w, v, o);
+#pragma unroll
+        for (int u = 0; u < N; u++) y[u][0] = o[u];
+    }
 };
 
 struct EmaOp { // overlap.rs:660-730
@@ -37,6 +48,7 @@ struct EmaOp { // overlap.rs:660-730
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return c.steady(); }
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = c.fast(x[0]); }
+    static constexpr int FAST_UNROLL = 16;
 };
 
 struct BbandsOp { // overlap.rs:47-116
@@ -103,6 +115,28 @@ struct BbandsOp { // overlap.rs:47-116
         double sd = sqrt(fmax(variance, 0.0));
         y[0] = mean + up * sd; y[1] = mean; y[2] = mean - dn * sd;
     }
+    static constexpr bool FAST_BATCH = true;
+    static constexpr int FAST_UNROLL = 8;
+    template <int N>
+    __device__ void steps_fast(int64_t, const double (&x)[N][1], double (&y)[N][3]) {
+        double v[N], old[N], s1[N], s2[N];
+#pragma unroll
+        for (int u = 0; u < N; u++) v[u] = x[u][0];
+        w.swap_n<N>(v, old);
+#pragma unroll
+        for (int u = 0; u < N; u++) { // the running sums: the only loop-carried chain
+            sum += v[u]; sum_sq += v[u] * v[u];
+            sum -= old[u]; sum_sq -= old[u] * old[u];
+            s1[u] = sum; s2[u] = sum_sq;
+        }
+#pragma unroll
+        for (int u = 0; u < N; u++) { // per-row output arithmetic, independent across rows
+            double mean = s1[u] / (double)p;
+            double variance = (s2[u] / (double)p) - mean * mean;
+            double sd = sqrt(fmax(variance, 0.0));
+            y[u][0] = mean + up * sd; y[u][1] = mean; y[u][2] = mean - dn * sd;
+        }
+    }
 };
 
 struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
@@ -139,6 +173,7 @@ struct DemaOp { // overlap.rs:543-598 (bitmap branch, decision D-2)
         e1 = fma(alpha, e0 - e1, e1);
         y[0] = 2.0 * e0 - e1;
     }
+    static constexpr int FAST_UNROLL = 16;
 };
 
 struct TemaOp { // overlap.rs:1177-1311
@@ -177,6 +212,7 @@ struct TemaOp { // overlap.rs:1177-1311
         e2 = fma(alpha, e1 - e2, e2);
         y[0] = 3.0 * e0 - 3.0 * e1 + e2;
     }
+    static constexpr int FAST_UNROLL = 16;
 };
 
 struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e5 never seeded)
@@ -228,6 +264,7 @@ struct T3Op { // overlap.rs:939-1175 (output formula :1160-1166, decision D-3; e
         e5 = fma(alpha, e4 - e5, e5);
         y[0] = fma(c1, e5, fma(c2, e4, fma(c3, e3, c4 * e2)));
     }
+    static constexpr int FAST_UNROLL = 16;
 };
 
 struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
@@ -285,6 +322,23 @@ struct WmaOp { // overlap.rs:1328-1399 (quirk Q-WMA kept)
         const double old = w.swap(x[0]);
         numerator -= ((double)p) * old;
         y[0] = numerator / denominator;
+    }
+    static constexpr bool FAST_BATCH = true;
+    static constexpr int FAST_UNROLL = 16;
+    template <int N>
+    __device__ void steps_fast(int64_t, const double (&x)[N][1], double (&y)[N][1]) {
+        double v[N], old[N], nm[N];
+#pragma unroll
+        for (int u = 0; u < N; u++) v[u] = x[u][0];
+        w.swap_n<N>(v, old);
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            numerator += ((double)(p + 1)) * v[u];
+            numerator -= ((double)p) * old[u];
+            nm[u] = numerator;
+        }
+#pragma unroll
+        for (int u = 0; u < N; u++) y[u][0] = nm[u] / denominator;
     }
 };
 

@@ -144,6 +144,17 @@ struct SmaCore {
         sum -= w.swap(v);
         return sum * denom;
     }
+    template <int N>
+    __device__ void fast_ring_n(Ring &w, const double (&v)[N], double (&out)[N]) {
+        double old[N];
+        w.swap_n<N>(v, old);
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            sum += v[u];
+            sum -= old[u];
+            out[u] = sum * denom;
+        }
+    }
     __device__ double fast_old(double v, double old) {
         sum += v;
         sum -= old;

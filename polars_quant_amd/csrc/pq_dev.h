@@ -126,6 +126,25 @@ template <class Op, class = void>
 struct FastNullOk { static constexpr bool value = false; }; // true: the op never looks at null flags (N-B family)
 template <class Op>
 struct FastNullOk<Op, decltype((void)Op::FAST_NULL_OK)> { static constexpr bool value = Op::FAST_NULL_OK; };
+// An op may take the rows of the fast path in batches of N = FAST_UNROLL rows:
+//   template <int N> __device__ void steps_fast(int64_t t, const double (&x)[N][NIN], double (&y)[N][NOUT]);
+// which lets it issue all LDS traffic that depends only on the inputs (window pops) ahead of the dependent arithmetic and
+// exposes the row-independent output arithmetic (divisions, square roots) of N rows to the scheduler at once.
+template <class Op, class = void>
+struct HasFastBatch { static constexpr bool value = false; };
+template <class Op>
+struct HasFastBatch<Op, decltype((void)Op::FAST_BATCH)> { static constexpr bool value = Op::FAST_BATCH; };
+template <class Op, int N>
+__device__ __forceinline__ void fast_rows(Op &op, int64_t t, const double (&x)[N][Op::NIN], double (&y)[N][Op::NOUT]) {
+    if constexpr (HasFastBatch<Op>::value) op.template steps_fast<N>(t, x, y);
+    else {
+#pragma unroll
+        for (int u = 0; u < N; u++) op.step_fast(t + u, x[u], y[u]);
+    }
+}
+// keeps a speculatively computed value where it is: without it the compiler turns `cond ? expensive : other` into a branch
+// around the expensive part (a division), which splits the straight-line fast path into basic blocks
+__device__ __forceinline__ double pq_keep(double v) { asm volatile("" : "+v"(v)); return v; }
 template <class Op, class = void>
 struct FastUnroll { static constexpr int value = 2; };      // rows per unrolled fast-loop iteration
 template <class Op>
@@ -300,6 +319,35 @@ struct Ring { // per-lane circular buffer in LDS; slot k of lane l at base + (k*
         base[pos * 64] = v;
         pos = (pos + 1 == depth) ? 0 : pos + 1;
     }
+    // N swaps back to back: old[u] = value pushed `depth` pushes before v[u].  Only LDS traffic and integer address
+    // arithmetic (LDS executes a wave's operations in order, so a depth below N is fine too); nothing waits on a result.
+    template <int N>
+    __device__ void swap_n(const double (&v)[N], double (&old)[N]) {
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            old[u] = base[pos * 64];
+            base[pos * 64] = v[u];
+            pos = (pos + 1 == depth) ? 0 : pos + 1;
+        }
+    }
+    // the values that the next N pushes will overwrite (oldest first); requires depth >= N
+    template <int N>
+    __device__ void peek_n(double (&old)[N]) const {
+        int k = pos;
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            old[u] = base[k * 64];
+            k = (k + 1 == depth) ? 0 : k + 1;
+        }
+    }
+    template <int N>
+    __device__ void push_n(const double (&v)[N]) {
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            base[pos * 64] = v[u];
+            pos = (pos + 1 == depth) ? 0 : pos + 1;
+        }
+    }
     __device__ double swap(double v) { // store v, return the value pushed `depth` pushes ago
         double old = base[pos * 64];
         base[pos * 64] = v;
@@ -344,11 +392,7 @@ struct TileK<Op, decltype((void)Op::TILE_K)> { static constexpr int value = Op::
 template <class Op>
 struct SeqTile {
     static constexpr int K = TileK<Op>::value;   // rows per tile
-#ifdef PQ_DIRECT_STORES
-    static constexpr bool DIRECT = true;  // experiment: outputs by per-lane 8-byte stores, no output tiles
-#else
-    static constexpr bool DIRECT = IsMasked<Op>::value;
-#endif
+    static constexpr bool DIRECT = IsMasked<Op>::value; // row-masked outputs: per-lane 8-byte stores, no output tiles
     static constexpr int NT = DIRECT ? Op::NIN : (Op::NIN > Op::NOUT ? Op::NIN : Op::NOUT);
     static constexpr int ROWB = K * 8 + 8;                                 // LDS row pitch in bytes
     static constexpr int TILE_BYTES = 64 * ROWB;
@@ -362,8 +406,6 @@ static inline size_t seq_lds_bytes(const Op &op) {
 }
 constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to the gather body
 
-// ring_ws: nullptr = the rings live in LDS behind the tiles; else a global-memory region of this wave's own
-// ([slot][lane] exactly as in LDS) -- trades LDS footprint (occupancy) for L2 round trips
 // The LDS body runs in a 2-wavefront workgroup: wave 0 loads + computes, wave 1 only stores.  Reason: gfx950 counts loads
 // and stores in ONE counter (vmcnt), loads retire in order but stores do not, so a wave with stores in flight cannot wait
 // for a prefetched load without also waiting for every store it has issued (measured: a tile copy by one wave runs at
@@ -371,10 +413,7 @@ constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to th
 // wave 0's counter holds loads only and the prefetch is waited for exactly; wave 1 never waits on vmcnt at all.
 // Hand-off per tile: wave 0 finishes the out tile in LDS -> barrier A -> wave 1 pulls it into registers -> barrier B ->
 // wave 1 issues the global stores while wave 0 already overwrites LDS with the next input tile.
-#ifndef PQ_SINGLE_WAVE
-#define PQ_SINGLE_WAVE 0 // experiment: one-wave workgroups, the compute wave stores its own out tiles
-#endif
-constexpr int SEQ_LDS_BLOCK = PQ_SINGLE_WAVE ? 64 : 128;
+constexpr int SEQ_LDS_BLOCK = 128;
 #ifdef PQ_PROFILE_WAVES // experiment: where does the compute wave spend its cycles? [job][load wait+LDS fill, rows, hand-off, tiles]
 static __device__ unsigned long long pq_prof[128][4]; // indexed by Op::SEQ_ID
 template <class Op, class = void> struct ProfId { static constexpr int value = 0; };
@@ -399,7 +438,7 @@ __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
 }
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
-                                            int64_t tile_s0, unsigned char *lds, double *ring_ws = nullptr) {
+                                            int64_t tile_s0, unsigned char *lds) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
     constexpr int TB = SeqTile<Op>::TILE_BYTES;
     constexpr int CPL = K / 2;      // 16-byte chunks (lanes) per series segment
@@ -423,52 +462,49 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #ifdef PQ_PROFILE_WAVES
     if (lane == 0) atomicAdd(&pq_prof[120 + (__builtin_amdgcn_s_getreg(2308) & 3)][wave], 1ULL); // SIMD id histogram per wave role
 #endif
-    // hand-off of a finished out tile: two-wave form = barriers A / B with the storer; one-wave form = this wave pulls the
-    // tile back into registers and issues the coalesced stores itself (they stay in flight under the next tile: the
-    // prefetched loads of the next tile were issued BEFORE them and vmcnt retires in issue order)
-    auto hand_off = [&](int64_t t0) {
+    // hand-off of a finished out tile to the storer wave.  (Measured alternative: one-wave workgroups in which the compute
+    // wave pulls the tile back and issues the stores itself, with the next tile's loads issued before them -- 8.2 vs 5.5 ms
+    // per suite step: the wave's own stores hold up its vmcnt waits whatever the order.)
+    auto hand_off = [&](int64_t) {
         if constexpr (MASKED) return;
-        if constexpr (PQ_SINGLE_WAVE) {
-            double2 v[NOUT][NI];
-#pragma unroll
-            for (int k = 0; k < NOUT; k++)
-#pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
-                    v[k][i] = make_double2(q[0], q[1]);
-                }
-            lds_fence();
-#pragma unroll
-            for (int k = 0; k < NOUT; k++)
-#pragma unroll
-                for (int i = 0; i < NI; i++)
-                    if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0, v[k][i]);
-        } else {
-            __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
-            __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
-        }
+        __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
+        __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
     };
-    if (!PQ_SINGLE_WAVE && wave == 1) { // ---------------------------------------------------------------- storer
+    if (wave == 1) { // ---------------------------------------------------------------- storer
         if constexpr (!MASKED) {
-            for (int64_t it = 0; it < nt; it++) {
-                __builtin_amdgcn_s_barrier(); // A: out tile `it` is complete
-                lds_fence();
-                double2 v[NOUT][NI];
+            // Tunable: the storer can keep ACC consecutive out tiles in registers and issue their stores back to back (ACC * K * 8
+            // contiguous bytes per series within a few cycles).  In a pure tile copy 64-byte pieces scattered over 64 series run
+            // the write path at ~3.1 TB/s against ~3.7 (pairs) / ~4.3 TB/s (128-byte pieces and up), scripts/ubench/tilecopy3.hip.
+#ifndef PQ_STORER_ACC
+#define PQ_STORER_ACC 1 // 2 / 4: -1 % .. +4 % per suite step (A/B in one session): the microbenchmark's gain does not carry over
+#endif
+            constexpr int ACC = (NOUT * NI * 4 * PQ_STORER_ACC <= 136) ? PQ_STORER_ACC : 1; // registers of the (otherwise idle) storer wave
+            for (int64_t it = 0; it < nt; it += ACC) {
+                double2 v[ACC][NOUT][NI];
 #pragma unroll
-                for (int k = 0; k < NOUT; k++)
+                for (int a = 0; a < ACC; a++) {
+                    if (it + a < nt) {
+                        __builtin_amdgcn_s_barrier(); // A: out tile `it + a` is complete
+                        lds_fence();
 #pragma unroll
-                    for (int i = 0; i < NI; i++) { // two b64 reads: LDS rows are only 8-byte aligned
-                        const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
-                        v[k][i] = make_double2(q[0], q[1]);
+                        for (int k = 0; k < NOUT; k++)
+#pragma unroll
+                            for (int i = 0; i < NI; i++) { // two b64 reads: LDS rows are only 8-byte aligned
+                                const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
+                                v[a][k][i] = make_double2(q[0], q[1]);
+                            }
+                        lds_fence();
+                        __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
                     }
-                lds_fence();
-                __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
+                }
                 const int64_t t0 = it * K;
 #pragma unroll
                 for (int k = 0; k < NOUT; k++)
 #pragma unroll
                     for (int i = 0; i < NI; i++)
-                        if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0, v[k][i]);
+#pragma unroll
+                        for (int a = 0; a < ACC; a++)
+                            if (it + a < nt && tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0 + a * K, v[a][k][i]);
             }
             if constexpr (HasFinish<Op>::value) { // the epilogue of wave 0 reads what this wave stored
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store acknowledged
@@ -487,7 +523,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
     for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + srow * d.stride;
     if constexpr (HasRings<Op>::value) {
-        RingAlloc ra{(ring_ws ? ring_ws : reinterpret_cast<double *>(lds + SeqTile<Op>::BYTES)) + lane};
+        RingAlloc ra{reinterpret_cast<double *>(lds + SeqTile<Op>::BYTES) + lane};
         op.init_lds(r, ra);
     } else {
         op.init(r);
@@ -535,8 +571,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     for (int u = 0; u < FU; u++)
 #pragma unroll
                         for (int k = 0; k < NIN; k++) xs[u][k] = *reinterpret_cast<const double *>(my_row + k * TB + (j0 + u) * 8);
-#pragma unroll
-                    for (int u = 0; u < FU; u++) op.step_fast(t0 + j0 + u, xs[u], ys[u]);
+                    fast_rows<Op, FU>(op, t0 + j0, xs, ys);
 #pragma unroll
                     for (int u = 0; u < FU; u++) {
                         if constexpr (MASKED) {
@@ -550,7 +585,10 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     }
                 }
                 lds_fence();
+                PQ_PROF_T(f2);
                 hand_off(t0);
+                PQ_PROF_T(f3);
+                PQ_PROF_ADD(0, c1 - c0); PQ_PROF_ADD(1, f2 - c1); PQ_PROF_ADD(2, f3 - f2); PQ_PROF_ADD(3, 1);
                 return;
             }
         }
@@ -568,12 +606,8 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                 for (int k = 0; k < NIN; k++) xn[k] = *reinterpret_cast<const double *>(my_row + k * TB + (j + 1) * 8);
             }
-#ifdef PQ_EXP_NOCOMPUTE
-            for (int k = 0; k < NOUT; k++) y[k] = x[0] + (double)k; // experiment: memory pipeline only
-#else
             if constexpr (HasRings<Op>::value) op.step_lds(t0 + j, x, y);
             else op.step(r, t0 + j, x, y);
-#endif
             if constexpr (MASKED) {
 #pragma unroll
                 for (int k = 0; k < NOUT; k++)
@@ -611,12 +645,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     }
     if constexpr (HasFinish<Op>::value) {
         static_assert(!MASKED, "finish() is not supported for row-masked ops");
-        if constexpr (PQ_SINGLE_WAVE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store acknowledged
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        } else {
-            __builtin_amdgcn_s_barrier(); // C: wave 1's stores have been acknowledged
-        }
+        __builtin_amdgcn_s_barrier(); // C: wave 1's stores have been acknowledged
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (live) op.finish(outp, d, s);
     }
@@ -658,7 +687,6 @@ struct SeqTraits { // what the scheduler needs to know about a recorded job
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const void *op, size_t op_bytes, const double *const *in,
                       int nin, double *const *out, int nout, void *extra_write = nullptr);
 struct RowThunk { // type-erased ROW launch for replay
-    int kind = -1; // Op::ROW_ID when the op can run inside the fused row_jobs_kernel of a suite (blob = RowBlob<Op>), else -1
     void (*launch)(const void *blob, hipStream_t stream);
     unsigned char blob[1200];
     const void *reads[8];
@@ -748,11 +776,6 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> i
     for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][s * d.stride + t]); // written once, not re-read
 #endif
 }
-constexpr int ROW_JOB_BLOB = 184; // bytes of a fused-row job slot
-template <class Op, class = void>
-struct HasRowId { static constexpr bool value = false; };
-template <class Op>
-struct HasRowId<Op, decltype((void)Op::ROW_ID)> { static constexpr bool value = true; };
 template <class Op>
 struct RowBlob {
     Op op;
@@ -760,20 +783,6 @@ struct RowBlob {
     OutColsT<Op, typename Op::OutT> out;
     pq_batch b;
 };
-// one (series, row) of a recorded ROW op, evaluated from its blob (fused row_jobs_kernel)
-template <class Op>
-__device__ __forceinline__ void row_eval_blob(const unsigned char *blob, const Dims &d, int64_t s, int64_t t) {
-    RowBlob<Op> rb;
-    __builtin_memcpy(&rb, blob, sizeof rb);
-    Row<Op::NIN> r;
-    r.len = d.len;
-#pragma unroll
-    for (int k = 0; k < Op::NIN; k++) r.in[k] = rb.in.p[k] + s * d.stride;
-    typename Op::OutT y[Op::NOUT];
-    rb.op.eval(r, t, y);
-#pragma unroll
-    for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &rb.out.p[k][s * d.stride + t]);
-}
 template <class Op>
 static void row_launch_blob(const void *blob, hipStream_t stream) {
     const RowBlob<Op> &rb = *reinterpret_cast<const RowBlob<Op> *>(blob);
@@ -798,7 +807,6 @@ static inline pq_status launch_row(pq_ctx *ctx, const pq_batch *b, const Op &op,
         static_assert(sizeof(RowBlob<Op>) <= sizeof(RowThunk::blob), "ROW blob too large");
         RowThunk t;
         t.launch = &row_launch_blob<Op>;
-        if constexpr (HasRowId<Op>::value) t.kind = (sizeof(RowBlob<Op>) <= ROW_JOB_BLOB) ? Op::ROW_ID : -1;
         memcpy(t.blob, &rb, sizeof rb);
         t.n_reads = Op::NIN;
         for (int k = 0; k < Op::NIN; k++) t.reads[k] = in.p[k];

@@ -19,11 +19,10 @@
 struct SeqJob { // device-visible
     int kind, nin, nout, cost; // cost: estimated solo duration in microseconds (SeqTraits)
     int heavy, masked;
+    int cls;                   // CLS_*: the grid the job runs in (suite_finalize)
     double summary_bytes;
     int alg_cols;                  // f64 column transfers credited (per reference call)
     unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
-    double *ring_ws;               // non-null: rings in global memory, [tile][slot][lane]
-    unsigned long long ring_stride; // doubles per 64-symbol tile
     const double *in[6];
     double *out[8];
     alignas(8) unsigned char op[1024];
@@ -39,51 +38,23 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
 };
 // How the SEQ jobs of a phase are grouped into grids.  Facts that shape this (measured, scripts/wg_residency.py and
 // scripts/ubench/nstreams.hip):
-//  * every workgroup walks its 64 series for the whole step (0.4 .. 4 ms), so the step ends when the last-started long
-//    workgroup ends: long jobs must be placed first and the tail should consist of short jobs;
-//  * a launch has ONE dynamic-LDS size (every workgroup is charged the largest need in its grid), and a 40 KB workgroup
-//    loses every race for freed LDS against 10 KB ones;
+//  * every workgroup walks its 64 series for the whole step, so the step ends when the last-started long workgroup ends:
+//    the longest jobs must start at t = 0 and the tail should consist of short jobs;
+//  * a launch has ONE dynamic-LDS size (every workgroup is charged the largest need in its grid) and one register
+//    allocation, and a 40 KB workgroup loses every race for freed LDS against 10 KB ones;
 //  * HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): the caller's stream + 3 side streams run
-//    concurrently, any further stream is serialized behind another one; hipExtAnyOrderLaunch is a no-op on gfx9.
-// Plan "narrow" (4 queues):  light-register jobs > 28 KB on the caller's stream | the rest of the light jobs, longest first,
-// so the short small ones run in the tail | the register-heavy Hilbert jobs | ROW launches + gather-body fallbacks.
-// Plan "wide" (experiment, PQ_SUITE_PLAN=w with GPU_MAX_HW_QUEUES >= 8): five LDS size classes (160 KB / 3, 5, 6, 7, 11 per CU)
-// so that less LDS is charged than needed, the smallest (short jobs) held back by a timed gate.
-constexpr int NCLS = 8, NCHAIN = 7; // chain 0 = the caller's stream
-struct ClassDef { int variant; unsigned lds_lo, lds_hi; int chain, gate_us, max_cost; }; // variant 0 light, 1 heavy, 2 gather; LDS in (lo, hi]
-struct Plan { int ncls, nchain, row_chain; ClassDef cls[NCLS]; int chain_order[NCHAIN]; };
-static const Plan PLAN_NARROW_E = {5, 4, 3, // (experiment, no gain) the small short jobs (<= 14 KB, < 1.4 ms) follow the > 28 KB grid
-    {{0, 28 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 0, 14 * 1024, 0, 0, 139}, {0, 0, 28 * 1024, 1, 0, 1 << 30}, {1, 0, 1u << 30, 2, 0, 1 << 30},
-     {2, 0, 0, 3, 0, 1 << 30}},
-    {2, 0, 1, 3}};
-static const Plan PLAN_NARROW = {4, 4, 3, // default: the small short jobs sit at the end of the 14..28 KB grid
-    {{0, 28 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 0, 28 * 1024, 1, 0, 1 << 30}, {1, 0, 1u << 30, 2, 0, 1 << 30}, {2, 0, 0, 3, 0, 1 << 30}},
-    {2, 0, 1, 3}};
-static const Plan PLAN_FIVE = {5, 5, 3, // (experiment, needs GPU_MAX_HW_QUEUES >= 6; 8.0 vs 6.7 ms) the small short jobs as a fifth concurrent grid
-    {{0, 28 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 0, 14 * 1024, 4, 0, 139}, {0, 0, 28 * 1024, 1, 0, 1 << 30}, {1, 0, 1u << 30, 2, 0, 1 << 30},
-     {2, 0, 0, 3, 0, 1 << 30}},
-    {2, 0, 1, 3, 4}};
-static const Plan PLAN_WIDE = {7, 7, 5,
-    {{0, 32 * 1024, 1u << 30, 0, 0, 1 << 30}, {0, 27264, 32 * 1024, 1, 0, 1 << 30}, {0, 23360, 27264, 2, 0, 1 << 30},
-     {0, 14 * 1024, 23360, 3, 0, 1 << 30}, {1, 0, 1u << 30, 4, 0, 1 << 30}, {2, 0, 0, 5, 0, 1 << 30}, {0, 0, 14 * 1024, 6, 1500, 1 << 30}},
-    {4, 0, 1, 2, 3, 5, 6}};
-static const Plan &plan() {
-    static const Plan *p = [] {
-        // measured: the wide plan does not pay (7.2 vs 6.3 ms per step: more fork/join traffic, short jobs still start late),
-        // so it is opt-in for experiments and needs GPU_MAX_HW_QUEUES >= 8 in the environment of the process
-        const char *force = getenv("PQ_SUITE_PLAN");
-        return (force && force[0] == 'w') ? &PLAN_WIDE : ((force && force[0] == 'e') ? &PLAN_NARROW_E : ((force && force[0] == '5') ? &PLAN_FIVE : &PLAN_NARROW));
-    }();
-    return *p;
-}
-struct SeqJob;
-static int job_class(const SeqJob &j);
-// Timed gate in front of a grid of short jobs (wall_clock64: 100 MHz).  Bounded: it only ever waits for time to pass.
-__global__ void gate_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-}
-struct RowJob;
+//    concurrently, any further stream is serialized behind another one.
+// Hence four grids = four chains:
+//   LONG   (caller's stream)  the light-register jobs in order of decreasing cost, as many as fill the chip at t = 0, then
+//                             the "fat" ones (more LDS than THIN_LDS_MAX) whatever their cost; the lighter ROW launches follow
+//   SHORT  the remaining light-register jobs (all thin), longest first: they fill the chip as LONG workgroups retire
+//   HEAVY  the register-heavy jobs (seq_jobs_kernel<1>, 2 waves/SIMD) + the per-lane backtest scan
+//   GATHER gather-body fallbacks (very long windows / unaligned columns), and the ROW launches
+enum { CLS_LONG = 0, CLS_SHORT = 1, CLS_HEAVY = 2, CLS_GATHER = 3, NCLS = 4, NCHAIN = 4, ROW_CHAIN = 3 };
+static const int k_chain_order[NCHAIN] = {CLS_HEAVY, CLS_LONG, CLS_SHORT, CLS_GATHER}; // enqueue order: hungriest first
+static const int k_variant[NCLS] = {0, 0, 1, 2};                                       // seq_jobs_kernel<V> of each class
+constexpr unsigned THIN_LDS_MAX = 26 * 1024; // six workgroups of this size fit a CU's 160 KB
+constexpr double LONG_FILL = 3.5;            // LONG-grid workgroups per CU placed at t = 0 (4 of <= 40 KB fit)
 struct Phase {
     GridStat gs[NCLS];
     GridStat gs_row;           // the chain of ROW launches (timed as one unit)
@@ -91,12 +62,9 @@ struct Phase {
     std::vector<RowThunk> rows;
     std::vector<char> row_late; // 0: on the ROW chain; 1 + c: behind the SEQ grid(s) of chain c
     SeqJob *d_seq = nullptr;
-    RowJob *d_rowjobs = nullptr; // the fusable ROW launches of the phase (the others stay in `rows`)
-    int n_rowjobs = 0;
     unsigned long long *d_dbg = nullptr; // PQ_SUITE_DEBUG: [job][first start, last end] device timestamps
     unsigned long long *d_wg = nullptr;  // PQ_SUITE_DEBUG=2: [job][tile][start, end, hw id] of every workgroup
     unsigned wg_tiles = 0;
-    bool gate = false;        // timed gates only when the jobs do not all fit on the chip at once
     int first[NCLS + 1] = {}; // job index range of each class
     unsigned lds[NCLS] = {};
 };
@@ -130,20 +98,8 @@ struct pq_suite {
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
     X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
-static int job_class(const SeqJob &j) { // grid (ClassDef) a job runs in
-    const Plan &pl = plan();
-    const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
-    const int variant = (j.heavy && (j.lds_bytes > 0 || bt)) ? 1 : (j.lds_bytes == 0 ? 2 : 0);
-    for (int c = 0; c < pl.ncls; c++)
-        if (pl.cls[c].variant == variant && (variant == 2 || (j.lds_bytes > pl.cls[c].lds_lo && j.lds_bytes <= pl.cls[c].lds_hi)) &&
-            j.cost <= pl.cls[c].max_cost)
-            return c;
-    return pl.ncls - 1;
-}
-
 // V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
-__device__ int g_noprio = 0; // experiment switch
 template <int V>
 #ifndef PQ_LB0
 #define PQ_LB0 3 // waves per SIMD the light kernel is compiled for (168 VGPRs)
@@ -161,7 +117,7 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0
     const int64_t s = s0 + threadIdx.x;
     if (s0 >= d.n) return; // grid.x is padded to a multiple of 8 (see pq_suite_run)
     // long jobs are the critical path of the step: their waves win the issue arbitration against short jobs on the same SIMD
-    if (g_noprio) {} else if (job.cost >= 1800) __builtin_amdgcn_s_setprio(3);
+    if (job.cost >= 1800) __builtin_amdgcn_s_setprio(3);
     else if (job.cost >= 1300) __builtin_amdgcn_s_setprio(2);
     else if (job.cost >= 900) __builtin_amdgcn_s_setprio(1);
 #define X(OP)                                                                                                        \
@@ -170,9 +126,9 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0
         __builtin_memcpy(&op, job.op, sizeof(OP));                                                                   \
         if constexpr (V == 2) run_seq(op, job.in, job.out, d, s);                                                    \
         else                                                                                                         \
-            run_seq_lds(op, job.in, job.out, d, s0, jobs_lds, job.ring_ws ? job.ring_ws + blockIdx.x * job.ring_stride : nullptr); \
+            run_seq_lds(op, job.in, job.out, d, s0, jobs_lds); \
     } break;
-    // the two lists must agree with the ops' HEAVY trait (which is what job_class() looks at)
+    // the two lists must agree with the ops' HEAVY trait (which is what the class assignment in suite_finalize looks at)
 #define XL(OP) static_assert(!IsHeavy<OP>::value, "light list holds an op marked HEAVY"); X(OP)
 #define XH(OP) static_assert(IsHeavy<OP>::value, "heavy list holds an op not marked HEAVY"); X(OP)
     if constexpr (V == 2) {
@@ -208,28 +164,6 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0
 #undef X
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
-}
-
-// ---- fused ROW jobs: every recorded row-parallel op that has a ROW_ID runs inside ONE kernel, thread = (series, row).
-// The ops of a suite read the same few input columns (OHLC): evaluated back to back by the same thread block, only the
-// first one misses in L1/L2 -- 16 launches with 296 B/row of reads become one launch with ~40 B/row.
-struct RowJob { int kind; alignas(8) unsigned char blob[ROW_JOB_BLOB]; };
-#define ROW_OPS(X)                                                                                                   \
-    X(PriceOp<0>) X(PriceOp<1>) X(PriceOp<2>) X(PriceOp<3>) X(TrangeOp) X(TrendlineOp) X(TrendmodeOp) X(LagOp<0>) X(LagOp<1>) \
-    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(AroonOp<2>) X(WillrOp)
-__global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJob *jobs, int njobs, Dims d, int64_t s0) {
-    const int64_t s = s0 + blockIdx.y;
-    const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
-    if (t >= d.len) return;
-    for (int j = 0; j < njobs; j++) {
-        const RowJob &job = jobs[j];
-        switch (job.kind) { // uniform
-#define X(OP) case OP::ROW_ID: row_eval_blob<OP>(job.blob, d, s, t); break;
-            ROW_OPS(X)
-#undef X
-        default: break;
-        }
-    }
 }
 
 static int phase_for(Recorder &r, const void *const *reads, int nr, void *const *writes, int nw) {
@@ -314,35 +248,18 @@ void rec_set_shared_out(pq_ctx *ctx, bool on) {
 }
 
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
-    const char *gr = getenv("PQ_GLOBAL_RINGS");
-    const unsigned gr_min = gr ? (unsigned)atoi(gr) : 0; // experiment: jobs needing more LDS than this keep their rings in global memory
+    hipDeviceProp_t prop;
+    PQ_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
     for (Phase &p : r.phases) {
-        if (getenv("PQ_ROW_FUSION")) { // experiment (no gain measured: the separate launches already run at cache speed)
-            std::vector<RowJob> rj;
-            std::vector<RowThunk> rest;
-            for (const RowThunk &t : p.rows) {
-                if (t.kind < 0) { rest.push_back(t); continue; }
-                RowJob j;
-                j.kind = t.kind;
-                memcpy(j.blob, t.blob, ROW_JOB_BLOB);
-                rj.push_back(j);
-            }
-            if (rj.size() >= 2) {
-                p.rows.swap(rest);
-                p.n_rowjobs = (int)rj.size();
-                PQ_HIP_TRY(hipMalloc((void **)&p.d_rowjobs, sizeof(RowJob) * rj.size()));
-                PQ_HIP_TRY(hipMemcpy(p.d_rowjobs, rj.data(), sizeof(RowJob) * rj.size(), hipMemcpyHostToDevice));
-            }
-        }
-        p.gs_row.n_jobs = (int)p.rows.size() + (p.n_rowjobs > 0 ? 1 : 0);
+        p.gs_row.n_jobs = (int)p.rows.size();
         // The ROW launches are cheap streaming kernels, but beside the SEQ grids they get few wave slots and one chain of
         // them becomes the critical path of the step.  Two chains: the heaviest launches (by columns moved) stay on the ROW
-        // chain from t = 0; the rest runs on the caller's stream behind the chain-0 grid, which is the first to drain.
+        // chain from t = 0; the lighter half runs on the caller's stream behind the LONG grid.  Measured alternatives: all
+        // ROW launches on one chain (that chain becomes the critical path), the light half behind the HEAVY or the SHORT
+        // grid, early fractions of 0 / 0.3 / 0.7: all 2 - 8 % slower per step.
         p.row_late.assign(p.rows.size(), 0);
-        if (!p.seq.empty() && !getenv("PQ_NO_ROW_SPLIT")) {
-            // The lighter ROW launches run on the caller's stream behind the chain-0 grid (the > 28 KB jobs, all placed at
-            // t = 0, which is the first grid to drain).  Measured alternatives: all ROW launches on one chain 6.7 ms (that chain
-            // becomes the critical path), the light half split between chain 0 and the register-heavy chain 6.1 ms, this 5.8 ms.
+        if (!p.seq.empty()) {
             double total = 0, early = 0;
             auto weight = [](const RowThunk &t) { return (double)(t.n_reads + t.n_writes); };
             for (const RowThunk &t : p.rows) total += weight(t);
@@ -350,37 +267,30 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
             std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
             for (size_t k : idx) {
-                static const double frac = getenv("PQ_ROW_EARLY") ? atof(getenv("PQ_ROW_EARLY")) : 0.5;
-                static const int late_chain = getenv("PQ_ROW_LATE_CHAIN") ? atoi(getenv("PQ_ROW_LATE_CHAIN")) : 0;
-                if (early < frac * total) { early += weight(p.rows[k]); continue; } // (0 -> 6.1 ms, 0.7 -> same as 0.5)
-                p.row_late[k] = 1 + late_chain;
+                if (early < 0.5 * total) { early += weight(p.rows[k]); continue; }
+                p.row_late[k] = 1 + CLS_LONG;
             }
         }
         if (p.seq.empty()) continue;
-        if (gr_min) {
-            const size_t tiles = (size_t)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
-            for (SeqJob &j : p.seq) {
-                if (j.lds_bytes <= gr_min || j.lds_bytes <= j.tile_bytes) continue;
-                size_t ring_bytes = j.lds_bytes - j.tile_bytes;
-                void *ws = nullptr;
-                PQ_HIP_TRY(hipMalloc(&ws, ring_bytes * tiles));
-                r.scratch.push_back(ws);
-                j.ring_ws = (double *)ws;
-                j.ring_stride = ring_bytes / 8;
-                j.lds_bytes = j.tile_bytes;
-            }
+        // class of every job (see the comment at CLS_*): heavy / gather by trait, the light tiled jobs by cost and LDS need
+        std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cost > b.cost; });
+        double long_wgs = 0;
+        const double long_budget = LONG_FILL * (double)prop.multiProcessorCount;
+        for (SeqJob &j : p.seq) {
+            const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
+            if (j.heavy && (j.lds_bytes > 0 || bt)) j.cls = CLS_HEAVY;
+            else if (j.lds_bytes == 0) j.cls = CLS_GATHER;
+            else if (j.lds_bytes > THIN_LDS_MAX) j.cls = CLS_LONG;
+            else if (long_wgs + tiles <= long_budget) { j.cls = CLS_LONG; long_wgs += tiles; }
+            else j.cls = CLS_SHORT;
         }
-        std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) {
-            int ca = job_class(a), cb = job_class(b);
-            if (ca != cb) return ca < cb;
-            return a.cost > b.cost;
-        });
+        std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cls < b.cls; }); // cost order kept
         const double rows = (double)r.b.n_series * (double)r.b.len;
         std::map<const void *, int> masked_seen[NCLS];
         for (int c = 0; c <= NCLS; c++) p.first[c] = 0;
         for (int c = 0; c < NCLS; c++) { p.lds[c] = 0; p.gs[c].alg_bytes = 0; p.gs[c].n_jobs = 0; }
         for (const SeqJob &j : p.seq) {
-            const int g = job_class(j);
+            const int g = j.cls;
             p.first[g + 1]++;
             p.lds[g] = std::max(p.lds[g], j.lds_bytes);
             // algorithmic bytes: 8 B per f64 column and row; a column written row-disjointly by several masked
@@ -397,16 +307,8 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         for (int c = 0; c < NCLS; c++) { p.first[c + 1] += p.first[c]; p.gs[c].lds = p.lds[c]; }
-        {
-            hipDeviceProp_t prop;
-            PQ_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-            double need = 0;
-            for (const SeqJob &j : p.seq) need += (double)j.lds_bytes;
-            need *= (double)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
-            p.gate = need > 0.6 * (double)prop.multiProcessorCount * 160.0 * 1024.0;
-        }
         if (getenv("PQ_SUITE_DEBUG"))
-            for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost);
+            for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d class=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost, j.cls);
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
         if (getenv("PQ_SUITE_DEBUG")) PQ_HIP_TRY(hipMalloc((void **)&p.d_dbg, 16 * p.seq.size()));
@@ -416,28 +318,21 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
 }
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     Dims d = dims_of(&r.b);
-    const Plan &pl = plan();
     if (!r.aux[1]) { // lazily create the side streams (they live as long as the suite)
         int prio_lo = 0, prio_hi = 0;
         PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)); // numerically lower = higher priority
-        for (int i = 1; i < pl.nchain; i++) {
-            bool gated = false;
-            for (int c = 0; c < pl.ncls; c++) gated |= pl.cls[c].chain == i && pl.cls[c].gate_us > 0;
-            // the ROW launches are short streaming kernels without LDS: at low priority they crawl behind the SEQ grids and end up
-            // as the critical path of the step
-            const bool hi = !gated && (i != pl.row_chain || !getenv("PQ_ROW_PRIO_LO")) && !getenv("PQ_NO_PRIO");
-            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, hi ? prio_hi : prio_lo));
+        for (int i = 1; i < NCHAIN; i++) {
+            // (at low priority the short ROW kernels crawl behind the SEQ grids and end up as the critical path of the step)
+            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, prio_hi));
             PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
         }
         PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
     }
     // workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8, series tile x runs on XCD x % 8 for
     // EVERY job, so jobs that read the same input column share that XCD's L2 for it
-    const unsigned tiles = getenv("PQ_NO_XCD_PAD") ? (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK)
-                                                   : (unsigned)((r.b.n_series + SEQ_BLOCK * 8 - 1) / (SEQ_BLOCK * 8)) * 8;
+    const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK * 8 - 1) / (SEQ_BLOCK * 8)) * 8;
     for (Phase &p : r.phases) {
-        // the launches of one phase are independent of each other: SEQ grid class 0 runs on the caller's stream, classes
-        // 1.. on side streams aux[0..], the ROW launches on the last side stream
+        // the launches of one phase are independent of each other: one chain (stream) per class, chain 0 = the caller's
         auto timed = [&](GridStat &g, hipStream_t st, bool begin) -> hipError_t { // HIP events on the launch stream
             if (!r.timing || g.runs >= Recorder::MAX_TIMED_RUNS) return hipSuccess;
             size_t idx = (size_t)g.runs * 2 + (begin ? 0 : 1);
@@ -453,10 +348,10 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         };
         auto njobs = [&](int c) { return p.first[c + 1] - p.first[c]; };
         bool side[NCHAIN] = {};
-        for (int c = 0; c < pl.ncls; c++) side[pl.cls[c].chain] |= njobs(c) > 0;
-        side[pl.row_chain] |= !p.rows.empty() || p.n_rowjobs > 0;
+        for (int c = 0; c < NCLS; c++) side[c] |= njobs(c) > 0;
+        side[ROW_CHAIN] |= !p.rows.empty();
         bool any_side = false;
-        for (int i = 1; i < pl.nchain; i++) any_side |= side[i];
+        for (int i = 1; i < NCHAIN; i++) any_side |= side[i];
         if (p.d_dbg && atoi(getenv("PQ_SUITE_DEBUG")) >= 2 && !p.d_wg) {
             p.wg_tiles = tiles;
             PQ_HIP_TRY(hipMalloc((void **)&p.d_wg, 24 * (size_t)tiles * p.seq.size()));
@@ -468,16 +363,13 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             PQ_HIP_TRY(hipMemcpy(p.d_dbg, init.data(), 16 * p.seq.size(), hipMemcpyHostToDevice));
         }
         if (any_side) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
-        static const int gate_override = getenv("PQ_GATE_US") ? atoi(getenv("PQ_GATE_US")) : -1;
         auto launch_class = [&](int c, hipStream_t st) -> pq_status {
             const int nj = njobs(c);
             if (nj <= 0) return PQ_OK;
-            const int gate_us = (pl.cls[c].gate_us > 0 && gate_override >= 0) ? gate_override : pl.cls[c].gate_us;
-            if (gate_us > 0 && p.gate) hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)gate_us * 100ULL);
             PQ_HIP_TRY(timed(p.gs[c], st, true));
             unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
             const dim3 grid(tiles, (unsigned)nj);
-            const int v = pl.cls[c].variant;
+            const int v = k_variant[c];
             if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
             else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
@@ -485,29 +377,23 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             return PQ_OK;
         };
         pq_status ps;
-        for (int oi = 0; oi < pl.nchain; oi++) { // enqueue order: the longest / hungriest chains first
-            const int i = pl.chain_order[oi];
+        for (int oi = 0; oi < NCHAIN; oi++) { // enqueue order: the longest / hungriest chains first
+            const int i = k_chain_order[oi];
             if (!side[i] && i != 0) continue;
             hipStream_t st = i == 0 ? ctx->stream : r.aux[i];
             if (i != 0) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
-            if (i == pl.row_chain && (p.n_rowjobs > 0 || !p.rows.empty())) {
+            if (i == ROW_CHAIN && !p.rows.empty()) {
                 PQ_HIP_TRY(timed(p.gs_row, st, true));
-                for (int64_t s0 = 0; s0 < r.b.n_series && p.n_rowjobs > 0; s0 += 65535) { // grid.y is limited to 65535
-                    const int64_t ns = r.b.n_series - s0 < 65535 ? r.b.n_series - s0 : 65535;
-                    hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((r.b.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0,
-                                       st, p.d_rowjobs, p.n_rowjobs, d, s0);
-                }
                 for (size_t k = 0; k < p.rows.size(); k++)
                     if (!p.row_late[k]) p.rows[k].launch(p.rows[k].blob, st);
                 PQ_HIP_TRY(timed(p.gs_row, st, false));
             }
-            for (int c = 0; c < pl.ncls; c++)
-                if (pl.cls[c].chain == i && (ps = launch_class(c, st)) != PQ_OK) return ps;
+            if ((ps = launch_class(i, st)) != PQ_OK) return ps;
             for (size_t k = 0; k < p.rows.size(); k++) // the lighter ROW launches follow an early-draining SEQ grid (suite_finalize)
                 if (p.row_late[k] == 1 + i) p.rows[k].launch(p.rows[k].blob, st);
             if (i != 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
         }
-        for (int i = 1; i < pl.nchain; i++)
+        for (int i = 1; i < NCHAIN; i++)
             if (side[i]) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.ev_join[i], 0));
         if (p.d_dbg) { // debug only: wait and print the per-job schedule (100 MHz device clock)
             PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -517,7 +403,7 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             for (size_t i = 0; i < p.seq.size(); i++) t0 = t[2 * i] < t0 ? t[2 * i] : t0;
             for (size_t i = 0; i < p.seq.size(); i++)
                 fprintf(stderr, "[pq suite] job %2zu kind=%3d class=%d lds=%6u  start %8.1f us  end %8.1f us\n", i, p.seq[i].kind,
-                        job_class(p.seq[i]), p.seq[i].lds_bytes, (double)(t[2 * i] - t0) / 100.0,
+                        p.seq[i].cls, p.seq[i].lds_bytes, (double)(t[2 * i] - t0) / 100.0,
                         (double)(t[2 * i + 1] - t0) / 100.0);
             if (p.d_wg) {
                 std::vector<unsigned long long> w(3 * (size_t)tiles * p.seq.size());
@@ -556,7 +442,6 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     for (Phase &p : r.phases) {
         if (p.d_seq) (void)hipFree(p.d_seq);
-        if (p.d_rowjobs) (void)hipFree(p.d_rowjobs);
         if (p.d_dbg) (void)hipFree(p.d_dbg);
         if (p.d_wg) (void)hipFree(p.d_wg);
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
@@ -687,7 +572,7 @@ pq_status pq_suite_span_stats(pq_suite *s, int32_t variant, double *avg_span_ms,
     std::vector<GridStat *> gs;
     for (Phase &p : s->rec.phases)
         for (int c = 0; c < NCLS; c++)
-            if (p.gs[c].n_jobs > 0 && p.gs[c].runs > 0 && plan().cls[c].variant == variant) gs.push_back(&p.gs[c]);
+            if (p.gs[c].n_jobs > 0 && p.gs[c].runs > 0 && k_variant[c] == variant) gs.push_back(&p.gs[c]);
     *avg_span_ms = 0.0; *alg_bytes = 0.0;
     if (gs.empty()) return PQ_OK;
     int runs = gs[0]->runs;
@@ -714,7 +599,7 @@ pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
         for (int c = 0; c <= NCLS; c++) {
             if ((c < NCLS ? p.gs[c] : p.gs_row).n_jobs == 0) continue;
             if (idx++ != k) continue;
-            *variant = c < NCLS ? plan().cls[c].variant : 3; // 3 = the chain of ROW launches
+            *variant = c < NCLS ? k_variant[c] : 3; // 3 = the chain of ROW launches
             return PQ_OK;
         }
     pq_set_error("pq_suite_grid_variant: grid index out of range");
