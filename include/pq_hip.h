@@ -60,6 +60,9 @@ pq_status pq_ctx_set_stream(pq_ctx *ctx, void *hip_stream);
 pq_status pq_ctx_sync(pq_ctx *ctx);
 pq_status pq_malloc(pq_ctx *ctx, size_t bytes, void **dptr);
 pq_status pq_free(pq_ctx *ctx, void *dptr);
+/* pin / unpin a host buffer (an Arrow data buffer) so that the two copies below DMA straight from / to it */
+pq_status pq_host_register(void *host_ptr, size_t bytes);
+pq_status pq_host_unregister(void *host_ptr);
 pq_status pq_memcpy_h2d(pq_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 pq_status pq_memcpy_d2h(pq_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 /* Arrow validity bitmap (LSB-first, bit i = row i of the long column, starting at bit `bit_offset`)
@@ -215,6 +218,11 @@ pq_status pq_typprice(pq_ctx *, const pq_batch *, const double *high, const doub
 pq_status pq_wclprice(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close,
                       double *out);                                                                 /* price.rs:74 */
 
+/* ---- returns (README.md:46-75 `returns(df, price_col, period, method, return_col)`; README-only, decision D-13) ----
+ * method 0 "simple": (p[t] - p[t-period]) / p[t-period];  1 "log": ln(p[t] / p[t-period]).  Null for t < period and where
+ * either price is null; period <= 0 or another method: all null.  Pinned by the reference-held vector README.md:75. */
+pq_status pq_returns(pq_ctx *, const pq_batch *, const double *price, int64_t period, int64_t method, double *out);
+
 /* ---- cycle (src/talib/cycle.rs) ---- */
 pq_status pq_ht_dcperiod(pq_ctx *, const pq_batch *, const double *real, double *out);                          /* :10 */
 pq_status pq_ht_dcphase(pq_ctx *, const pq_batch *, const double *real, double *out);                           /* :75 */
@@ -242,6 +250,8 @@ typedef struct {
 } pq_bt_params; /* vectorized.rs:38 defaults: 1e5, 0, 0, 3e-4, 3e-4, 5, 1 */
 #define PQ_SUMMARY_COLS 8 /* annualized_return, max_drawdown, alpha, beta, sharpe_ratio, max_profit, win_rate, total_trades */
 /* buy/sell: uint8 0/1 per row (null -> 0, vectorized.rs:80-98); price null -> NaN (:70-78);
+ * EVERY column (price, buy, sell, benchmark, position, cash, equity) is [n_series][stride]: element (s, t) at
+ * ptr[s * stride + t] -- a benchmark shared by all series must be replicated per series by the caller;
  * benchmark may be NULL; position/cash/equity may be NULL (summary only); summary is [n_series][8] */
 pq_status pq_backtest_vectorized(pq_ctx *, const pq_batch *, const double *price, const uint8_t *buy,
                                  const uint8_t *sell, const double *benchmark, const pq_bt_params *params,

@@ -9,6 +9,7 @@ from ._lib import NullsNotAllowed, PqError
 from ._spec import PATTERN_NAMES, SPEC, SUMMARY_KEYS
 from .backtest import Backtest, VectorizedBacktester
 from .factor import Factor
+from .returns import returns
 from .strategy import Strategy
 from .talib import *  # noqa: F401,F403
 

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-from ._spec import I, SPEC
+from ._spec import EXTRA, I, SPEC
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["PQ_LIB_PATH"]) if os.environ.get("PQ_LIB_PATH") else _HERE / "libpolars_quant_hip.so"  # override: A/B builds
@@ -57,7 +57,7 @@ def lib() -> C.CDLL:
         L.pq_pattern_name.argtypes = [C.c_int32]
         L.pq_pattern_id.argtypes = [C.c_char_p]
         vp = C.c_void_p
-        for name, (cols, params, outs, _fam) in SPEC.items():
+        for name, (cols, params, outs, _fam) in {**SPEC, **EXTRA}.items():
             fn = getattr(L, "pq_" + name)
             fn.restype = C.c_int32
             fn.argtypes = [vp, C.POINTER(Batch)] + [vp] * len(cols) + \
@@ -112,6 +112,8 @@ def lib() -> C.CDLL:
         L.pq_validity_to_arrow.argtypes = [vp, vp, C.c_int64, vp, vp]
         L.pq_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.pq_free.argtypes = [vp, vp]
+        L.pq_host_register.argtypes = [vp, C.c_size_t]
+        L.pq_host_unregister.argtypes = [vp]
         L.pq_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.pq_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.pq_device_count.argtypes = [C.POINTER(C.c_int32)]

@@ -215,9 +215,22 @@ def backtest_vectorized(price, buy, sell, benchmark=None, want_curves: bool = Tr
     bu, _, _ = _to_device(buy, torch.uint8)
     se, _, _ = _to_device(sell, torch.uint8)
     p = p.contiguous(); bu = bu.contiguous(); se = se.contiguous()
-    bm = _to_device(benchmark)[0].contiguous() if benchmark is not None else None
     dev = p.device
     n, T = p.shape
+    # the kernel indexes every column as base + s * stride: all of them must be [N, T] like the prices
+    for nm, t in (("buy", bu), ("sell", se)):
+        if t.shape == (1, T) and n > 1:
+            raise PqError(f"backtest_vectorized: `{nm}` is one series but `price` has {n}; signals are per series ([N, T])")
+        if t.shape != (n, T):
+            raise PqError(f"backtest_vectorized: `{nm}` has shape {tuple(t.shape)}, expected {(n, T)}")
+    bm = None
+    if benchmark is not None:
+        bm = _to_device(benchmark)[0]
+        if bm.shape == (1, T) and n > 1:
+            bm = bm.expand(n, T)          # one benchmark series shared by all symbols (the reference is single-asset)
+        if bm.shape != (n, T):
+            raise PqError(f"backtest_vectorized: `benchmark` has shape {tuple(bm.shape)}, expected {(T,)} or {(n, T)}")
+        bm = bm.contiguous()
     b = Batch(n, T, T)
     mk = lambda: torch.empty((n, T), dtype=torch.float64, device=dev)
     pos, cash, eq = (mk(), mk(), mk()) if want_curves else (None, None, None)

@@ -33,6 +33,7 @@ pq_status pq_backtest_vectorized(pq_ctx *ctx, const pq_batch *b, const double *p
     else {
         PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
         a.equity = pq_ws_col(ctx, b, 0);
+        if (!a.equity) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
     }
     return bt_launch<false, false>(ctx, b, a);
 }
@@ -56,6 +57,7 @@ pq_status pq_backtest_macd_cross(pq_ctx *ctx, const pq_batch *b, const double *c
     else {
         PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
         a.equity = pq_ws_col(ctx, b, 0);
+        if (!a.equity) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
     }
     return bt_launch<true, false>(ctx, b, a);
 }

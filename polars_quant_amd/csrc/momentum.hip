@@ -22,6 +22,12 @@ LAGFN(pq_rocp, 2)
 LAGFN(pq_rocr, 3)
 LAGFN(pq_rocr100, 4)
 
+pq_status pq_returns(pq_ctx *ctx, const pq_batch *b, const double *price, int64_t period, int64_t method, double *out) {
+    CHK("pq_returns", price && out);
+    if (method == 0) { ReturnsOp<0> op{}; op.p = period; return launch_row(ctx, b, op, InCols<1>{{price}}, OutColsT<ReturnsOp<0>, double>{{out}}); }
+    ReturnsOp<1> op{}; op.p = (method == 1) ? period : 0; // an unknown method: all null (as period <= 0)
+    return launch_row(ctx, b, op, InCols<1>{{price}}, OutColsT<ReturnsOp<1>, double>{{out}});
+}
 pq_status pq_bop(pq_ctx *ctx, const pq_batch *b, const double *o, const double *h, const double *l, const double *c,
                  double *out) {
     CHK("pq_bop", o && h && l && c && out);
@@ -52,7 +58,7 @@ pq_status pq_cci_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const do
                  double *out) {
     CHK("pq_cci", h && l && c && out);
     WS(8);
-    double *sma_tp = pq_ws_col(ctx, b, 0);
+    PQ_WS_COL(sma_tp, ctx, b, 0);
     SmaTpOp s{}; s.p = p;
     PQ_TRY(launch_seq(ctx, b, s, InCols<3>{{h, l, c}}, OutCols<1>{{sma_tp}}));
     CciDevOp op{}; op.p = p;
@@ -110,7 +116,7 @@ pq_status pq_adxr_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const d
                   double *out) {
     CHK("pq_adxr", h && l && c && out);
     WS(8);
-    double *adx = pq_ws_col(ctx, b, 0);
+    PQ_WS_COL(adx, ctx, b, 0);
     PQ_TRY(pq_adx(ctx, b, h, l, c, p, adx));
     AdxrOp op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<1>{{adx}}, OutColsT<AdxrOp, double>{{out}});
@@ -130,7 +136,7 @@ pq_status pq_apo_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64
                  double *out) {
     CHK("pq_apo", real && out);
     WS(8);
-    double *f = pq_ws_col(ctx, b, 0), *s = pq_ws_col(ctx, b, 1);
+    PQ_WS_COL(f, ctx, b, 0); PQ_WS_COL(s, ctx, b, 1);
     PQ_TRY(pq_ma(ctx, b, real, fast, matype, f));
     PQ_TRY(pq_ma(ctx, b, real, slow, matype, s));
     return launch_row(ctx, b, BinOp<0>{}, InCols<2>{{f, s}}, OutColsT<BinOp<0>, double>{{out}});
@@ -139,7 +145,7 @@ pq_status pq_ppo_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64
                  double *out) {
     CHK("pq_ppo", real && out);
     WS(8);
-    double *f = pq_ws_col(ctx, b, 0), *s = pq_ws_col(ctx, b, 1);
+    PQ_WS_COL(f, ctx, b, 0); PQ_WS_COL(s, ctx, b, 1);
     PQ_TRY(pq_ma(ctx, b, real, fast, matype, f));
     PQ_TRY(pq_ma(ctx, b, real, slow, matype, s));
     return launch_row(ctx, b, BinOp<1>{}, InCols<2>{{f, s}}, OutColsT<BinOp<1>, double>{{out}});
@@ -148,7 +154,7 @@ pq_status pq_macdext_chain(pq_ctx *ctx, const pq_batch *b, const double *real, i
                      int64_t slowmt, int64_t sig, int64_t sigmt, double *macd, double *signal, double *hist) {
     CHK("pq_macdext", real && macd && signal && hist); // momentum.py:83-88
     WS(8);
-    double *f = pq_ws_col(ctx, b, 0), *s = pq_ws_col(ctx, b, 1);
+    PQ_WS_COL(f, ctx, b, 0); PQ_WS_COL(s, ctx, b, 1);
     PQ_TRY(pq_ma(ctx, b, real, fast, fastmt, f));
     PQ_TRY(pq_ma(ctx, b, real, slow, slowmt, s));
     PQ_TRY(launch_row(ctx, b, BinOp<0>{}, InCols<2>{{f, s}}, OutColsT<BinOp<0>, double>{{macd}}));
@@ -166,7 +172,7 @@ pq_status pq_stoch_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const 
                    int64_t slowk, int64_t slowk_mt, int64_t slowd, int64_t slowd_mt, double *outk, double *outd) {
     CHK("pq_stoch", h && l && c && outk && outd); // momentum.py:178-186
     WS(8);
-    double *fk = pq_ws_col(ctx, b, 0);
+    PQ_WS_COL(fk, ctx, b, 0);
     FastkOp op{}; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{h, l, c}}, OutColsT<FastkOp, double>{{fk}}));
     PQ_TRY(pq_ma(ctx, b, fk, slowk, slowk_mt, outk));
@@ -176,7 +182,7 @@ pq_status pq_stochrsi_chain(pq_ctx *ctx, const pq_batch *b, const double *real, 
                       int64_t fastd_mt, double *outk, double *outd) {
     CHK("pq_stochrsi", real && outk && outd); // momentum.py:197-205
     WS(8);
-    double *rsi = pq_ws_col(ctx, b, 0);
+    PQ_WS_COL(rsi, ctx, b, 0);
     PQ_TRY(pq_rsi(ctx, b, real, p, rsi));
     FastkOp op{}; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{rsi, rsi, rsi}}, OutColsT<FastkOp, double>{{outk}}));

@@ -26,6 +26,21 @@ struct LagOp {
         else y[0] = (c / pr) * 100.0;
     }
 };
+// README.md:46-75 returns(df, price_col, period, method) (README-only; decision D-13): METHOD 0 simple = (p[t] - p[t-period]) /
+// p[t-period], 1 log = ln(p[t] / p[t-period]); null for t < period and where either price is null; IEEE-754 on a zero price
+template <int METHOD>
+struct ReturnsOp {
+    static constexpr int NIN = 1, NOUT = 1;
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0 || t < p) return;
+        const double c = r.in[0][t], pr = r.in[0][t - p];
+        if (pq_isnull(c) || pq_isnull(pr)) return;
+        y[0] = METHOD == 0 ? (c - pr) / pr : log(c / pr);
+    }
+};
 struct BopOp { // momentum.rs:113-135
     static constexpr int NIN = 4, NOUT = 1;
     typedef double OutT;

@@ -54,7 +54,7 @@ pq_status pq_t3(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, d
 pq_status pq_trima_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_trima: null pointer");
     PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
-    double *tmp = pq_ws_col(ctx, b, 7); // scratch column 7 is reserved for trima (see pq_ma users)
+    PQ_WS_COL(tmp, ctx, b, 7); // scratch column 7 is reserved for trima (see pq_ma users)
     int64_t k1, k2;                     // overlap.rs:1313-1326
     if (p % 2 == 1) { k1 = p / 2 + 1; k2 = k1; } else { k1 = p / 2; k2 = k1 + 1; }
     PQ_TRY(pq_sma(ctx, b, real, k1, tmp));
@@ -124,26 +124,26 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     pq_status st = PQ_OK;
     bool blocked = false;
     if (matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8 && maxp < (1 << 30)) {
-        // SMA: sixteen candidate periods per job (states in registers); EMA: eight (states in LDS)
-        blocked = true;
-        st = PQ_OK;
+        // SMA: sixteen candidate periods per job (states in registers); EMA: eight (states in LDS).  Two passes: decide
+        // first whether EVERY block fits the tiled body -- nothing may be recorded before that is known, or the rows of `out`
+        // would get a second writer from the per-period fallback below
         const int64_t per_job = matype == 1 ? 8 : 16;
-        for (int64_t lo = minp; lo <= maxp && st == PQ_OK; lo += per_job) {
-            int64_t hi = lo + per_job - 1 < maxp ? lo + per_job - 1 : maxp;
-            InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
-            if (matype != 1) {
-                MavpSma16Op op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
-                if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
-                st = launch_seq(ctx, b, op, in, o1);
-            } else if (matype == 1) {
-                MavpBlockOp<1> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
-                if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
-                st = launch_seq(ctx, b, op, in, o1);
-            } else {
-                MavpBlockOp<0> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
-                if (!seq_can_lds(b, op, in, o1)) { blocked = false; break; }
-                st = launch_seq(ctx, b, op, in, o1);
+        InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 0) blocked = true;
+            for (int64_t lo = minp; lo <= maxp && st == PQ_OK && blocked; lo += per_job) {
+                int64_t hi = lo + per_job - 1 < maxp ? lo + per_job - 1 : maxp;
+                if (matype != 1) {
+                    MavpSma16Op op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
+                    if (pass == 0) blocked = seq_can_lds(b, op, in, o1);
+                    else st = launch_seq(ctx, b, op, in, o1);
+                } else {
+                    MavpBlockOp<1> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
+                    if (pass == 0) blocked = seq_can_lds(b, op, in, o1);
+                    else st = launch_seq(ctx, b, op, in, o1);
+                }
             }
+            if (!blocked) break;
         }
     }
     if (!blocked && st == PQ_OK) switch (matype) { // overlap.rs:857-869
@@ -156,7 +156,7 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
               st = mavp_jobs(ctx, b, r0, periods, minp, maxp, t3, out); break; }
     case 5: { // TRIMA is two chained SMAs: select from a materialised MA column per period
         PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
-        double *rz = pq_ws_col(ctx, b, 5), *ma = pq_ws_col(ctx, b, 6);
+        PQ_WS_COL(rz, ctx, b, 5); PQ_WS_COL(ma, ctx, b, 6);
         rec_set_shared_out(ctx, false);
         PQ_TRY(launch_row(ctx, b, ReplaceNullOp{}, IN1(real), OutColsT<ReplaceNullOp, double>{{rz}}));
         r0 = rz;

@@ -35,6 +35,10 @@ pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes);
 // k-th scratch column ([n_series][stride] doubles).  While recording, every request returns a fresh
 // column owned by the suite (recorded jobs run concurrently, so scratch cannot be shared).
 double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k);
+// scratch column or PQ_ERR_NOMEM (while recording every request is a fresh hipMalloc that can fail)
+#define PQ_WS_COL(var, ctx, b, k)                                                                  \
+    double *var = pq_ws_col(ctx, b, k);                                                            \
+    if (!var) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
 pq_status pq_check(pq_ctx *ctx, const pq_batch *b);
 
 #define PQ_HIP_TRY(expr)                                                                         \

@@ -136,6 +136,18 @@ pq_status pq_free(pq_ctx *ctx, void *dptr) {
     if (dptr) { PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); PQ_HIP_TRY(hipFree(dptr)); }
     return PQ_OK;
 }
+// Pin a host buffer (e.g. an Arrow data buffer) so that pq_memcpy_h2d / pq_memcpy_d2h move it by DMA straight from / to
+// the caller's memory instead of through the runtime's staging copies: the "zero-copy" hand-over of a host column.
+pq_status pq_host_register(void *host_ptr, size_t bytes) {
+    if (!host_ptr || !bytes) { pq_set_error("pq_host_register: null pointer or empty range"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return PQ_OK;
+}
+pq_status pq_host_unregister(void *host_ptr) {
+    if (!host_ptr) { pq_set_error("pq_host_unregister: null pointer"); return PQ_ERR_ARG; }
+    PQ_HIP_TRY(hipHostUnregister(host_ptr));
+    return PQ_OK;
+}
 pq_status pq_memcpy_h2d(pq_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (!dst && bytes) || (!src && bytes)) { pq_set_error("pq_memcpy_h2d: null pointer"); return PQ_ERR_ARG; }
     PQ_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -53,10 +53,13 @@ def _case(rng, name, log) -> int:
         g = g.cpu().numpy()
         if name in TRANSC:
             ok = np.isclose(g, e, rtol=1e-12, atol=1e-12, equal_nan=True) | (_bits(g) == _bits(e))
+            if dt == "f8":
+                ok = ok & ((_bits(g) == np.uint64(oracle.NULL_BITS)) == (_bits(e) == np.uint64(oracle.NULL_BITS)))
         else:
             ok = _bits(g) == _bits(e)
-            if dt == "f8":
-                ok = ok | ((g != g) & (e != e))
+            if dt == "f8":   # a computed NaN matches a computed NaN; a NULL (itself a NaN pattern) only matches a NULL
+                gn, en = _bits(g) == np.uint64(oracle.NULL_BITS), _bits(e) == np.uint64(oracle.NULL_BITS)
+                ok = (ok | ((g != g) & (e != e))) & (gn == en)
         if not np.all(ok):
             bad += 1
             idx = np.argwhere(~ok)[:3].tolist()

@@ -1,0 +1,196 @@
+"""-m gpu: the drop-in boundary exercised the way INTEGRATION.md's reference-side stub uses it -- plain C-ABI calls on host
+Arrow buffers -- plus the host mirror of the reference's classes (VectorizedBacktester.run()) and thread safety."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+pa = pytest.importorskip("pyarrow")
+
+NULLB = np.uint64(0x7FF80000504E554C)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from polars_quant_amd._lib import lib
+    return lib()
+
+
+def _ck(L, st):
+    assert st == 0, L.pq_last_error().decode()
+
+
+def test_arrow_column_through_the_c_abi_only(L, oracle):
+    """INTEGRATION.md section 2, step by step, with nothing but C-ABI calls: a host Arrow f64 column with a validity bitmap and
+    a NON-ZERO bit offset (a slice) -> pq_host_register -> pq_malloc -> pq_memcpy_h2d -> pq_nulls_from_arrow -> pq_ema ->
+    pq_validity_to_arrow -> pq_memcpy_d2h, compared with the oracle on the same nulls."""
+    from polars_quant_amd._lib import Batch
+    n_series, T = 70, 304
+    d = oracle.gen_ohlcv(0x5EED0007, n_series, T, 0)
+    flat = d["close"].reshape(-1)
+    rng = np.random.default_rng(1)
+    mask = rng.random(flat.shape[0] + 13) < 0.02
+    big = pa.array(np.concatenate([np.zeros(13), flat]), mask=mask)      # 13 leading rows that the slice drops
+    arr = big.slice(13)                                                  # offset 13: bit offset 13 & 7 = 5 into byte 1
+    assert arr.offset == 13 and arr.null_count > 0
+    validity, values = arr.buffers()
+    n = len(arr)
+    host_vals = values.address + arr.offset * 8
+    ctx = C.c_void_p()
+    _ck(L, L.pq_ctx_create(0, None, C.byref(ctx)))
+    d_in, d_out, d_bits, d_obits, d_cnt = (C.c_void_p() for _ in range(5))
+    nbytes_bits = (arr.offset + n + 7) // 8
+    for ptr, sz in ((d_in, n * 8), (d_out, n * 8), (d_bits, nbytes_bits), (d_obits, (n + 7) // 8), (d_cnt, 8)):
+        _ck(L, L.pq_malloc(ctx, sz, C.byref(ptr)))
+    _ck(L, L.pq_host_register(C.c_void_p(values.address), values.size))                # zero-copy source for the DMA
+    _ck(L, L.pq_memcpy_h2d(ctx, d_in, C.c_void_p(host_vals), n * 8))
+    _ck(L, L.pq_memcpy_h2d(ctx, d_bits, C.c_void_p(validity.address), nbytes_bits))
+    _ck(L, L.pq_nulls_from_arrow(ctx, d_in, d_bits, arr.offset, n))
+    b = Batch(n_series, T, T)
+    _ck(L, L.pq_ema(ctx, C.byref(b), d_in, C.c_int64(9), d_out))
+    _ck(L, L.pq_validity_to_arrow(ctx, d_out, n, d_obits, d_cnt))
+    out = np.empty(n)
+    obits = np.zeros((n + 7) // 8, np.uint8)
+    cnt = np.zeros(1, np.int64)
+    _ck(L, L.pq_memcpy_d2h(ctx, out.ctypes.data_as(C.c_void_p), d_out, n * 8))
+    _ck(L, L.pq_memcpy_d2h(ctx, obits.ctypes.data_as(C.c_void_p), d_obits, obits.size))
+    _ck(L, L.pq_memcpy_d2h(ctx, cnt.ctypes.data_as(C.c_void_p), d_cnt, 8))
+    _ck(L, L.pq_host_unregister(C.c_void_p(values.address)))
+    for ptr in (d_in, d_out, d_bits, d_obits, d_cnt):
+        _ck(L, L.pq_free(ctx, ptr))
+    _ck(L, L.pq_ctx_destroy(ctx))
+    x = flat.copy()
+    x[mask[13:]] = oracle.NULL
+    (exp,) = oracle.call("ema", x.reshape(n_series, T), timeperiod=9)
+    exp = exp.reshape(-1)
+    en = bits(exp) == NULLB
+    assert ((bits(out) == bits(exp)) | (np.isnan(out) & np.isnan(exp) & ~en)).all()
+    got_valid = np.unpackbits(obits, bitorder="little")[:n].astype(bool)
+    assert (got_valid == ~en).all() and cnt[0] == en.sum()
+    # the same column through the Python host (api -> the same C ABI): a 1-D Arrow array is ONE series of n rows
+    import polars_quant_amd as pq
+    got = pq.EMA(arr, 9)
+    (exp1,) = oracle.call("ema", x, timeperiod=9)
+    en1 = bits(exp1) == NULLB
+    assert isinstance(got, pa.Array) and got.null_count == int(en1.sum())
+    assert (np.asarray(got.is_null()) == en1).all()
+    vals = got.to_numpy(zero_copy_only=False)
+    assert (bits(vals[~en1]) == bits(exp1[~en1])).all()
+
+
+def test_vectorized_backtester_run_shapes(oracle):
+    """VectorizedBacktester(price, buy, sell, benchmark).run() -> (positions, capital, summary): vectorized.rs:204-223 and
+    polars_quant.pyi:20-49 -- positions {"position"}, capital {"cash", "equity"}, a dict of 8 floats per capital pool."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import polars_quant_amd as pq
+    d = oracle.gen_ohlcv(0x5EED0008, 6, 300, 0)
+    close = d["close"]
+    buy, sell = oracle.macd_cross_signals(close)
+    bench = d["open"][0]
+    # [T]: one asset, exactly the reference's call
+    pos, cap, summ = pq.VectorizedBacktester(close[0], buy[0], sell[0], benchmark=bench, position_size=0.5).run()
+    epos, ecash, eeq, es = oracle.backtest(close[0], buy[0], sell[0], benchmark=bench, position_size=0.5)
+    assert set(pos) == {"position"} and set(cap) == {"cash", "equity"}
+    assert np.asarray(pos["position"]).shape == (300,)
+    assert (bits(np.asarray(pos["position"])) == bits(epos)).all()
+    assert (bits(np.asarray(cap["cash"])) == bits(ecash)).all() and (bits(np.asarray(cap["equity"])) == bits(eeq)).all()
+    assert list(summ) == pq.SUMMARY_KEYS and len(summ) == 8 and all(isinstance(v, float) for v in summ.values())
+    np.testing.assert_allclose([summ[k] for k in pq.SUMMARY_KEYS], es, rtol=1e-12, atol=1e-13)
+    assert summ["total_trades"] == es[7] and summ["total_trades"] > 0
+    # [N, T]: N independent pools; a [T] benchmark is shared by all of them
+    pos, cap, summ = pq.VectorizedBacktester(close, buy, sell, benchmark=bench).run()
+    epos, ecash, eeq, es = oracle.backtest(close, buy, sell, benchmark=np.tile(bench, (6, 1)))
+    assert np.asarray(pos["position"]).shape == (6, 300) and isinstance(summ, list) and len(summ) == 6
+    assert (bits(np.asarray(cap["equity"])) == bits(eeq)).all()
+    for row, e in zip(summ, es):
+        np.testing.assert_allclose([row[k] for k in pq.SUMMARY_KEYS], e, rtol=1e-12, atol=1e-13)
+    assert any(abs(row["beta"]) > 0 for row in summ), "the shared benchmark must reach every pool"
+    with pytest.raises(pq.PqError, match="buy"):
+        pq.VectorizedBacktester(close, buy[0], sell).run()          # [T] signals with [N, T] prices: refused, not read out of bounds
+    with pytest.raises(pq.PqError, match="benchmark"):
+        pq.VectorizedBacktester(close, buy, sell, benchmark=d["open"][:3]).run()
+
+
+def test_two_threads_two_contexts(L, oracle):
+    """Two host threads, each with its own context and stream, call concurrently; results are right and pq_last_error() is
+    thread-local (an error provoked on one thread is not seen by the other)."""
+    from polars_quant_amd._lib import Batch
+    n_series, T = 130, 312
+    d = oracle.gen_ohlcv(0x5EED0009, n_series, T, 0)
+    res, errs = {}, {}
+    barrier = threading.Barrier(2)
+
+    def worker(tid, name, period):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            ctx = C.c_void_p()
+            _ck(L, L.pq_ctx_create(0, C.c_void_p(stream.cuda_stream), C.byref(ctx)))
+            x = torch.from_numpy(d["close"]).cuda()
+            out = torch.empty_like(x)
+            b = Batch(n_series, T, T)
+            fn = getattr(L, "pq_" + name)
+            barrier.wait()
+            for _ in range(20):
+                _ck(L, fn(ctx, C.byref(b), C.c_void_p(x.data_ptr()), C.c_int64(period), C.c_void_p(out.data_ptr())))
+            if tid == 0:    # provoke an argument error on this thread only
+                st = fn(ctx, C.byref(b), None, C.c_int64(period), C.c_void_p(out.data_ptr()))
+                assert st != 0
+            barrier.wait()
+            errs[tid] = L.pq_last_error().decode()
+            _ck(L, L.pq_ctx_sync(ctx))
+            res[tid] = out.cpu().numpy()
+            _ck(L, L.pq_ctx_destroy(ctx))
+        except Exception as e:  # noqa: BLE001
+            res[tid] = e
+            try:
+                barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    ths = [threading.Thread(target=worker, args=(0, "ema", 12)), threading.Thread(target=worker, args=(1, "sma", 25))]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    for tid, (name, p) in enumerate((("ema", 12), ("sma", 25))):
+        assert not isinstance(res[tid], Exception), res[tid]
+        (exp,) = oracle.call(name, d["close"], timeperiod=p)
+        assert ((bits(res[tid]) == bits(exp))).all(), name
+    assert "null pointer" in errs[0] and "null pointer" not in errs[1]
+
+
+def test_returns_reference_vector_and_parity(oracle):
+    """returns(): the one vector the reference itself holds (README.md:66-75: [100, 102, 101, 105] -> [None, 0.02, -0.0098,
+    0.0396], printed to 4 d.p.), then parity with the oracle (simple bit-exact; log within 1e-12: device log())."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import polars_quant_amd as pq
+    out = pq.returns({"date": ["2024-01-01", "2024-01-02", "2024-01-03", "2024-01-04"], "close": np.array([100.0, 102.0, 101.0, 105.0])},
+                     price_col="close", period=1, method="simple")
+    r = np.asarray(out["return"])
+    assert bits(r)[0] == NULLB and list(np.round(r[1:], 4)) == [0.02, -0.0098, 0.0396]
+    d = oracle.gen_ohlcv(0x5EED000A, 70, 304, 0)
+    x = d["close"].copy()
+    x[3, 10] = oracle.NULL; x[5, :4] = oracle.NULL; x[7, 100] = 0.0
+    for period in (1, 5, 20, 0, 400):
+        for m, name in ((0, "simple"), (1, "log")):
+            (exp,) = oracle.call("returns", x, period=period, method=m)
+            got = np.asarray(pq.returns(x, period=period, method=name))
+            en = bits(exp) == NULLB
+            assert ((bits(got) == NULLB) == en).all(), (period, name)
+            if m == 0:
+                assert ((bits(got) == bits(exp)) | (np.isnan(got) & np.isnan(exp))).all(), (period, name)
+            else:
+                ok = ~en & np.isfinite(exp)
+                np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-12, atol=1e-15)
+    with pytest.raises(ValueError):
+        pq.returns(x, method="geometric")

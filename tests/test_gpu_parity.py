@@ -12,7 +12,11 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-N_SYM, T = 70, 301          # deliberately not multiples of 64 / 8
+# (symbols, days): an odd row pitch runs the per-lane gather body (run_seq / seq_jobs_kernel<2>: columns are not 16-byte
+# aligned), the even ones the two-wave LDS-tiled body (run_seq_lds / seq_jobs_kernel<0>,<1>) that bench.py times -- with a
+# ragged last tile (304 = 38 x 8 = 19 x 16; 312 = 39 x 8 = 19.5 x 16: a 16-row tail for K = 16 ops) and 1 / 2 full + 1 partial
+# symbol tiles.  Every default / parameter / null case below runs on all three.
+SHAPES = [(70, 301), (70, 304), (130, 312)]
 SEED = 0x5EED0002
 TRANSCENDENTAL = {"ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine", "mama"}
 RTOL = 1e-12                # north_star tolerance for f64 indicators
@@ -28,18 +32,20 @@ def pq():
     return pq
 
 
-@pytest.fixture(scope="module")
-def data(oracle):
-    d = oracle.gen_ohlcv(SEED, N_SYM, T, 0)
+@pytest.fixture(scope="module", params=SHAPES, ids=[f"{n}x{t}" for n, t in SHAPES])
+def data(oracle, request):
+    n, t = request.param
+    d = oracle.gen_ohlcv(SEED, n, t, 0)
     d["real"] = d["close"]
     rng = np.random.default_rng(7)
-    d["periods"] = rng.integers(0, 40, size=(N_SYM, T)).astype(np.float64)
+    d["periods"] = rng.integers(0, 40, size=(n, t)).astype(np.float64)
     return d
 
 
-@pytest.fixture(scope="module")
-def rich(oracle):
-    d = oracle.gen_ohlcv(SEED + 1, N_SYM, T, 1)
+@pytest.fixture(scope="module", params=SHAPES[:2], ids=[f"{n}x{t}" for n, t in SHAPES[:2]])
+def rich(oracle, request):
+    n, t = request.param
+    d = oracle.gen_ohlcv(SEED + 1, n, t, 1)
     d["real"] = d["close"]
     return d
 
@@ -185,12 +191,15 @@ def test_short_and_empty_series(pq, oracle):
 def test_strided_batch(pq, oracle, data):
     """stride > len: series embedded in a wider buffer"""
     from polars_quant_amd import api
-    wide = torch.full((N_SYM, T + 11), 123.0, dtype=torch.float64, device="cuda")
-    wide[:, :T] = torch.from_numpy(data["close"]).cuda()
-    view = wide[:, :T]
-    (got,) = api.call("ema", view, timeperiod=10)
-    (exp,) = oracle.call("ema", data["close"], timeperiod=10)
-    assert_same("ema-strided", got.cpu().numpy(), exp)
+    N_SYM, T = data["close"].shape
+    for pad in (11, 12):   # odd and even row pitch
+        wide = torch.full((N_SYM, T + pad), 123.0, dtype=torch.float64, device="cuda")
+        wide[:, :T] = torch.from_numpy(data["close"]).cuda()
+        view = wide[:, :T]
+        (got,) = api.call("ema", view, timeperiod=10)
+        (exp,) = oracle.call("ema", data["close"], timeperiod=10)
+        assert_same("ema-strided", got.cpu().numpy(), exp)
+        assert (wide[:, T:] == 123.0).all(), "rows beyond len must not be written"
 
 
 def test_patterns_each(pq, oracle, rich):
@@ -486,10 +495,15 @@ def test_suite_replay_matches_direct_calls_and_oracle(pq, oracle, data):
     """pq_suite_*: the recorded job grid must reproduce the direct calls (and therefore the oracle) bit for bit"""
     from polars_quant_amd.suite import Suite
     g = {k: torch.from_numpy(v).cuda() for k, v in data.items() if k in ("open", "high", "low", "close", "volume")}
+    N_SYM, T = data["close"].shape
     st = Suite(N_SYM, T, "cuda")
     st.record(g)
     info = st.info()
-    assert info["seq_jobs"] >= 60 and info["phases"] >= 2
+    # tiled path: the multi-output forms make ~29 single-phase jobs; gather path: every composite is a chain through scratch
+    assert (info["seq_jobs"] >= 25 and info["phases"] >= 1) if T % 2 == 0 else (info["seq_jobs"] >= 60 and info["phases"] >= 2)
+    kernels = {gs["kernel"] for gs in st.grid_stats()}
+    # an even row pitch must run the tiled bodies (what bench.py times), an odd one the gather bodies
+    assert ("seq_jobs_kernel<0>" in kernels and "seq_jobs_kernel<1>" in kernels) if T % 2 == 0 else ("seq_jobs_kernel<2>" in kernels), kernels
     for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
         t.fill_(-7)                      # poison: every row must be produced by the replay
     st.run()
@@ -557,6 +571,7 @@ def test_fused_multi_output_calls(pq, oracle, data):
     from polars_quant_amd import api
     from polars_quant_amd._lib import Batch, check, lib
     g = {k: torch.from_numpy(data[k]).cuda() for k in ("high", "low", "close")}
+    N_SYM, T = data["close"].shape
     b = Batch(N_SYM, T, T)
     outs = [torch.empty((N_SYM, T), dtype=torch.float64, device="cuda") for _ in range(5)]
     for p in (14, 1, 5):
@@ -625,3 +640,138 @@ def test_fused_multi_output_calls(pq, oracle, data):
         exp = oracle.call("aroon", data["high"], data["low"], timeperiod=p) + oracle.call("aroonosc", data["high"], data["low"], timeperiod=p)
         for i, (t, e) in enumerate(zip(outs, exp)):
             assert_same(f"aroon_all[{i}](p={p})", t.cpu().numpy(), e)
+
+
+def test_recorded_suite_nulls_and_parameters_on_the_tiled_bodies(pq, oracle):
+    """A recorded job grid on an EVEN row pitch (seq_jobs_kernel<0>/<1>: the two-wave tiled bodies with rings, steady-state
+    fast paths, barrier hand-off and epilogues that bench.py times) with null-bearing inputs and non-default parameters,
+    against the oracle.  N-B functions get the null-free copy (the reference rejects nulls there)."""
+    import ctypes as C
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import Batch, check, lib
+    n, T_ = 200, 344
+    clean = oracle.gen_ohlcv(SEED + 5, n, T_, 0)
+    clean["real"] = clean["close"]
+    rng = np.random.default_rng(3)
+    holes = {}
+    for k, v in clean.items():
+        a = v.copy()
+        m = rng.random(a.shape) < 0.01
+        m[:, :2] = True            # leading nulls
+        m[4] = False               # one null-free series
+        m[9, 150:] = True          # one series that goes null for good
+        m[:, 200:260] = False      # a null-free stretch: tiles that take the fast path again after the general one
+        a[m] = oracle.NULL
+        holes[k] = a
+    cases = [("sma", dict(timeperiod=7)), ("sma", dict(timeperiod=40)), ("ema", dict(timeperiod=5)), ("bbands", dict(timeperiod=9, nbdevup=1.0, nbdevdn=3.0)),
+             ("dema", dict(timeperiod=4)), ("tema", dict(timeperiod=6)), ("t3", dict(timeperiod=3, vfactor=0.5)), ("wma", dict(timeperiod=11)),
+             ("kama", dict(timeperiod=6)), ("trima", dict(timeperiod=9)), ("trima", dict(timeperiod=20)), ("midpoint", dict(timeperiod=5)),
+             ("midprice", dict(timeperiod=9)), ("ma", dict(timeperiod=8, matype=1)), ("apo", dict(fastperiod=4, slowperiod=9, matype=0)),
+             ("ppo", dict(fastperiod=4, slowperiod=9, matype=1)), ("macdext", dict(fastperiod=5, fastmatype=0, slowperiod=11, slowmatype=0, signalperiod=8, signalmatype=0)),
+             ("stoch", dict(fastk_period=6, slowk_period=3, slowk_matype=0, slowd_period=4, slowd_matype=1)),
+             ("stochf", dict(fastk_period=4, fastd_period=3, fastd_matype=0)), ("atr", dict(timeperiod=6)), ("natr", dict(timeperiod=9)),
+             ("ad", {}), ("adosc", dict(fastperiod=2, slowperiod=7)), ("obv", {}), ("sar", dict(acceleration=0.02, maximum=0.2)),
+             ("mavp", dict(minperiod=3, maxperiod=25, matype=0)), ("mama", dict(fastlimit=0.5, slowlimit=0.05)),
+             # N-B family: clean inputs
+             ("rsi", dict(timeperiod=9)), ("cmo", dict(timeperiod=6)), ("macd", dict(fastperiod=4, slowperiod=10, signalperiod=5)),
+             ("trix", dict(timeperiod=4)), ("ultosc", dict(timeperiod1=3, timeperiod2=6, timeperiod3=12)), ("mfi", dict(timeperiod=9)),
+             ("cci", dict(timeperiod=9)), ("cci", dict(timeperiod=21)), ("adx", dict(timeperiod=8)), ("adxr", dict(timeperiod=6)),
+             ("dx", dict(timeperiod=5)), ("minus_di", dict(timeperiod=7)), ("plus_dm", dict(timeperiod=5)), ("stochrsi", dict(timeperiod=9, fastk_period=5, fastd_period=3, fastd_matype=0)),
+             ("ht_dcperiod", {}), ("ht_sine", {})]
+    clean["periods"] = holes["periods"] = rng.integers(0, 40, size=(n, T_)).astype(np.float64)
+    dev = {id(d): {k: torch.from_numpy(v).cuda() for k, v in d.items()} for d in (clean, holes)}
+    L, h, b = lib(), api.ctx(0), Batch(n, T_, T_)
+    check(L.pq_suite_begin(h, C.byref(b)))
+    recorded = []
+    try:
+        for name, prm in cases:
+            src = clean if pq.SPEC[name][3] == "N-B" else holes
+            outs = api.call(name, *[dev[id(src)][c] for c in pq.SPEC[name][0]], **prm)   # recorded, not launched
+            recorded.append((name, prm, src, outs))
+    except Exception:
+        L.pq_suite_abort(h)
+        raise
+    suite = C.c_void_p()
+    check(L.pq_suite_end(h, C.byref(suite)))
+    try:
+        check(L.pq_suite_run(h, suite))
+        check(L.pq_suite_run(h, suite))
+        torch.cuda.synchronize()
+        k, kernels = 0, set()
+        while True:
+            var = C.c_int32()
+            if L.pq_suite_grid_variant(suite, k, C.byref(var)) != 0:
+                break
+            kernels.add(var.value); k += 1
+        assert {0, 1} <= kernels and 2 not in kernels, f"expected only the tiled job kernels, got variants {kernels}"
+        for name, prm, src, outs in recorded:
+            exp = oracle.call(name, *[src[c] for c in pq.SPEC[name][0]], **prm)
+            for (oname, _), g, e in zip(pq.SPEC[name][2], outs, exp):
+                assert_same(f"recorded:{name}.{oname}{prm}", g.cpu().numpy(), e, exact=name not in TRANSCENDENTAL)
+    finally:
+        check(L.pq_suite_destroy(h, suite))
+
+
+def test_full_size_config4_factor_ic(pq, oracle):
+    """BASELINE config 4 at full size (10 000 symbols x 5 040 days): IC and Rank-IC of every day on the GPU; a sample of days
+    against the oracle (days are independent cross-sections), rolling IC of the whole series, and the n_valid census."""
+    from polars_quant_amd import api
+    N, TT = 10000, 5040
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal((N, TT))
+    r = 0.05 * f + rng.standard_normal((N, TT))
+    f[rng.random((N, TT)) < 0.02] = oracle.NULL
+    r[:, -1] = oracle.NULL                       # forward return of the last day does not exist
+    r[rng.random((N, TT)) < 0.01] = np.nan
+    fg, rg = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    days = np.array([0, 1, 7, 63, 64, 1000, 2519, 2520, 4000, 5038, 5039])
+    fs, rs = np.ascontiguousarray(f[:, days]), np.ascontiguousarray(r[:, days])
+    ics = {}
+    for method in (0, 1):
+        ic, nv = api.factor_ic(fg, rg, method=method)
+        ic, nv = ic.cpu().numpy(), nv.cpu().numpy()
+        eic, env = oracle.factor_ic(fs, rs, method=method)
+        assert (nv[days] == env).all()
+        g = ic[days]
+        assert ((bits(g) == bits(eic)) | (np.isnan(g) & np.isnan(eic))).all(), f"method {method}: {g} vs {eic}"
+        assert np.isnan(ic[-1]) and nv[-1] == 0
+        valid = (bits(f) != np.uint64(oracle.NULL_BITS)) & np.isfinite(f) & (bits(r) != np.uint64(oracle.NULL_BITS)) & np.isfinite(r)
+        assert (nv == valid.sum(axis=0)).all()
+        assert np.nanmax(np.abs(ic[:-1])) <= 1.0 + 1e-12 and abs(np.nanmean(ic[:-1]) - 0.05) < 0.01
+        ics[method] = ic
+    em, eir = oracle.rolling_ic(ics[0], 20)
+    gm, gir = api.rolling_ic(torch.from_numpy(ics[0]).cuda(), 20)
+    for g, e in ((gm.cpu().numpy(), em), (gir.cpu().numpy(), eir)):
+        assert ((bits(g) == bits(e)) | (np.isnan(g) & np.isnan(e))).all()
+
+
+def test_full_size_config5_leveraged_backtest(pq, oracle):
+    """BASELINE config 5 at full size (5 000 x 2 520, leverage 2, commission + slippage): a sample of symbols against the oracle
+    (capital pools are independent), total = cash_net + stock_value on all 12.6 M rows, and the portfolio table."""
+    from polars_quant_amd import api
+    N, TT = 5000, 2520
+    d = oracle.gen_ohlcv(0x5EED0005, N, TT, 0)
+    close = d["close"]
+    cg = torch.from_numpy(close).cuda()
+    buy, sell = api.macd_cross_signals(cg)
+    kw = dict(leverage=2.0, slippage=0.001, commission_rate=0.0005, interest_rate=0.08, margin_call_threshold=0.5)
+    bench = d["open"][0].copy()
+    g = api.backtest_leveraged(cg, buy, sell, benchmark=torch.from_numpy(bench).cuda(), max_trades=32, **kw)
+    torch.cuda.synchronize()
+    pick = np.array([0, 1, 63, 64, 65, 127, 128, 2499, 2500, 4095, 4990, 4999])
+    ebuy, esell = oracle.macd_cross_signals(close[pick])
+    assert (buy[pick].cpu().numpy() == ebuy).all() and (sell[pick].cpu().numpy() == esell).all()
+    e = oracle.backtest_leveraged(np.ascontiguousarray(close[pick]), ebuy, esell, benchmark=bench, max_trades=32, **kw)
+    for k in ("cash", "stock_value", "total_value"):
+        assert (bits(g[k][pick].cpu().numpy()) == bits(e[k])).all(), k
+    assert (g["trade_count"][pick].cpu().numpy() == e["trade_count"]).all() and e["trade_count"].sum() > 0
+    for k, v in e["trades"].items():
+        gv = g["trades"][k][pick].cpu().numpy()
+        assert (gv == v).all() if v.dtype == np.int32 else (bits(gv) == bits(v)).all(), k
+    np.testing.assert_allclose(g["summary"][pick].cpu().numpy(), e["summary"], rtol=1e-12, atol=1e-13)
+    cash, sv, tv = (g[k].cpu().numpy() for k in ("cash", "stock_value", "total_value"))
+    assert (bits(tv) == bits(cash + sv)).all()                       # D-10: total_value = (cash - debt) + stock_value, every row
+    assert (sv >= 0).all() and np.isfinite(tv).all()
+    pm = api.portfolio_metrics(g["total_value"], 100000.0 * N, torch.from_numpy(bench).cuda()).cpu().numpy()
+    assert pm.shape == (TT, 10) and np.isfinite(pm[:, 0]).all()
+    np.testing.assert_allclose(pm[:, 0], tv.sum(axis=0), rtol=1e-12)  # portfolio_value = sum over symbols (blocked order)
