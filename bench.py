@@ -6,6 +6,12 @@ the full talib suite (every function of SURVEY 8(a), Python-wrapper default para
 recognisers fused) + the fused MACD-cross per-symbol backtest with summary.  N GPUs: each rank owns its own
 shard of symbols (static split, no data-path collective); the only exchange is one all_gather of the
 [n_local, 8] summary table per step.  rows = symbols x days.
+
+  --scaling weak   (default) every GPU gets --symbols symbols (5000): per-GPU work fixed
+  --scaling strong the --symbols symbols are split over the GPUs (BASELINE config 3: 5000 symbols over 8 GPUs = 625 each)
+  --e2e            additionally times the step END TO END from host Arrow-style buffers: pq_host_register'ed OHLCV columns ->
+                   H2D -> step -> D2H of the summary table (and, second figure, of every output); reported in config.e2e,
+                   never as `value`
 """
 from __future__ import annotations
 
@@ -44,9 +50,60 @@ def cpu_baseline(sample_syms: int, T: int):
     small = {k: v[: max(8, sample_syms // 8)] for k, v in d.items()}
     t0 = time.perf_counter(); oracle.suite_bench(small, 1); t_one = time.perf_counter() - t0
     rows = sample_syms * T
+    cpu = "?"
+    try:
+        cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:  # noqa: BLE001
+        pass
+    import subprocess
+    cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0] if True else "gcc"
     return {"value": rows / t_all, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_syms} symbols x {T} days, same suite+backtest, oracle (scalar C restatement, gcc -O2, OpenMP over symbols)",
+            "sample": f"{sample_syms} symbols x {T} days, same suite+backtest, oracle (scalar C restatement of the reference; the Rust "
+                      f"reference cannot be built here), {cc}, -O3 -ffp-contract=off (no -march=native: the .so travels between hosts), "
+                      f"OpenMP over symbols on {cores} threads of '{cpu}'",
             "value_1thread": small["close"].shape[0] * T / t_one}
+
+
+def end_to_end(suite, ohlcv, n_local, T, dev):
+    """The step from HOST buffers, through the C ABI's own copy entry points: the five OHLCV columns live in page-locked
+    (pq_host_register) host arrays as an Arrow buffer handed over by the caller would; H2D (pq_memcpy_h2d) -> step -> D2H of
+    the [n, 8] summary table.  Second figure: D2H of every output column as well (10.9 GB at full size)."""
+    import ctypes as C
+    from polars_quant_amd._lib import check, lib
+    from polars_quant_amd.api import ctx
+    L, h = lib(), ctx(dev.index)
+    host = {k: np.ascontiguousarray(v.cpu().numpy()) for k, v in ohlcv.items()}
+    for a in host.values():
+        check(L.pq_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes))
+    summ = np.empty((n_local, 8))
+    check(L.pq_host_register(summ.ctypes.data_as(C.c_void_p), summ.nbytes))
+    outs = [t for ts in suite.out.values() for t in ts] + list(suite.pat.values()) + suite.bt
+    big = np.empty(max(t.numel() * t.element_size() for t in outs), dtype=np.uint8)
+    check(L.pq_host_register(big.ctypes.data_as(C.c_void_p), big.nbytes))
+
+    def once(all_outputs):
+        for k, a in host.items():
+            check(L.pq_memcpy_h2d(h, C.c_void_p(ohlcv[k].data_ptr()), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        suite.run(ohlcv)
+        check(L.pq_memcpy_d2h(h, summ.ctypes.data_as(C.c_void_p), C.c_void_p(suite.summary.data_ptr()), summ.nbytes))
+        if all_outputs:
+            for t in outs:
+                check(L.pq_memcpy_d2h(h, big.ctypes.data_as(C.c_void_p), C.c_void_p(t.data_ptr()), t.numel() * t.element_size()))
+        torch.cuda.synchronize()
+
+    res = {}
+    for label, allo, reps in (("summary_only", False, 5), ("all_outputs", True, 2)):
+        once(allo)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once(allo)
+        dt = (time.perf_counter() - t0) / reps
+        res[label] = {"ms": dt * 1e3, "rows_per_s": n_local * T / dt}
+    res["h2d_bytes"] = sum(a.nbytes for a in host.values())
+    res["d2h_bytes_all_outputs"] = sum(t.numel() * t.element_size() for t in outs)
+    for a in list(host.values()) + [summ, big]:
+        check(L.pq_host_unregister(a.ctypes.data_as(C.c_void_p)))
+    return res
 
 
 def main():
@@ -54,7 +111,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--symbols", type=int, default=N_SYM, help="symbols per GPU (weak scaling)")
+    ap.add_argument("--symbols", type=int, default=N_SYM, help="symbols per GPU (weak scaling) / in total (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--e2e", action="store_true", help="also time the step end to end from registered host buffers")
     ap.add_argument("--days", type=int, default=T_DAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stride", type=int, default=0, help="elements between series starts in HBM (0 = dense = days)")
@@ -75,8 +134,17 @@ def main():
     torch.cuda.set_device(dev)
 
     from polars_quant_amd.suite import Suite
-    n_local, T = args.symbols, args.days
-    ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
+    from polars_quant_amd.distributed import gather_summaries, shard_range
+    T = args.days
+    if args.scaling == "strong":     # one data set of --symbols symbols, split statically over the ranks
+        lo, hi = shard_range(args.symbols, rank, world)
+        n_local, n_total = hi - lo, args.symbols
+        full = make_inputs(args.symbols, T, SEED, torch.device("cpu"))
+        ohlcv = {k: v[lo:hi].contiguous().to(dev) for k, v in full.items()}
+        del full
+    else:
+        n_local, n_total = args.symbols, args.symbols * world
+        ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
     stride = args.stride or T
     if stride != T:  # re-house the inputs with the padded row pitch
         for k in list(ohlcv):
@@ -84,12 +152,11 @@ def main():
             buf[:, :T] = ohlcv[k]
             ohlcv[k] = buf[:, :T]
     suite = Suite(n_local, T, dev, stride=stride)
-    from polars_quant_amd.distributed import gather_summaries
 
     def step():
         suite.run(ohlcv)
         if world > 1:   # the one exchange of the path: per-symbol summary rows to every rank (RCCL over xGMI)
-            gather_summaries(suite.summary, world * n_local)
+            gather_summaries(suite.summary, n_total)
 
     suite.record(ohlcv)   # one-time: turn the step's calls into job grids (not part of the timed region)
     for _ in range(args.warmup):
@@ -124,35 +191,38 @@ def main():
     rows_local = n_local * T
     dom = [g for g in grids if g["kernel"] == "seq_jobs_kernel<0>"]
     n_launch = sum(g["runs"] for g in dom)
-    mean_ms = sum(g["avg_ms"] * g["runs"] for g in dom) / n_launch
-    mean_bytes = sum(g["alg_bytes"] * g["runs"] for g in dom) / n_launch
-    achieved = mean_bytes / (mean_ms * 1e-3) / 1e9
+    if n_launch:
+        mean_ms = sum(g["avg_ms"] * g["runs"] for g in dom) / n_launch
+        mean_bytes = sum(g["alg_bytes"] * g["runs"] for g in dom) / n_launch
+        achieved = mean_bytes / (mean_ms * 1e-3) / 1e9
+    else:   # e.g. an odd --days / --stride: no tiled grid exists, every job ran in the gather kernel
+        mean_ms = mean_bytes = achieved = None
     span_ms, span_bytes = suite.span_stats(0)   # the two launches as one concurrent set
     suite_bytes = suite.suite_bytes_per_row() * rows_local
     suite_gbs = suite_bytes / (elapsed / args.steps) / 1e9
     # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # command; summary committed by scripts/pmc_summary.py).  Only valid for the configuration it was collected on.
     traffic = None
-    pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+    pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
     if pmc.exists() and n_local == N_SYM and T == T_DAYS:
         k = json.loads(pmc.read_text())["kernels"].get("seq_jobs_kernel<0>")
         traffic = k["hbm_bytes_per_launch"] if k else None
 
     if rank == 0:
-        rows_total = world * rows_local * args.steps
+        rows_total = n_total * T * args.steps
         line = {
             "metric": "indicator+backtest rows/sec, 5000 sym x 2520 day f64 OHLCV",
             "value": rows_total / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
                                    f"recognisers) + fused MACD-cross backtest with summary, {n_local} symbols x {T} days "
                                    "f64 OHLCV per GPU, inputs resident in HBM",
-                       "symbols_per_gpu": n_local, "days": T, "parallelism": f"symbol-sharded x{world}",
+                       "symbols_per_gpu": n_local, "symbols_total": n_total, "days": T, "parallelism": f"symbol-sharded x{world}",
                        "algorithmic_bytes_per_row": suite.suite_bytes_per_row(),
                        "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "kernel": "seq_jobs_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": mean_bytes, "avg_launch_ms": mean_ms,
                          "launches_per_step": len(dom),
                          "concurrent_set": {"note": "the launches of this kernel overlap inside a step: their summed algorithmic bytes "
@@ -162,6 +232,8 @@ def main():
                                             "frac": span_bytes / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if span_ms else None},
                          "grids": [{k: g[k] for k in ("kernel", "avg_ms", "alg_bytes", "n_jobs", "lds_bytes")} for g in grids]},
         }
+        if args.e2e and world == 1:
+            line["config"]["e2e"] = end_to_end(suite, ohlcv, n_local, T, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4096, T)
         print(json.dumps(line))
