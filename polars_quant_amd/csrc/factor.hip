@@ -96,16 +96,35 @@ __global__ __launch_bounds__(256) void rank_prep_kernel(const double *x, const d
         }
     }
 }
+// [a, b) = the run of entries equal to ks[i] in the sorted row ks[0 .. nv): a short linear walk (runs are single elements for
+// continuous factors), then binary searches -- a discrete or constant factor (signals, buckets, all zeros before a warm-up)
+// has runs of thousands of entries and a purely linear walk would cost O(nv^2) loads per day.
+__device__ __forceinline__ void tie_run(const double *ks, int nv, int i, int &a, int &b) {
+    const double key = ks[i];
+    a = i; b = i + 1;
+    int steps = 0;
+    while (a > 0 && steps < 4 && ks[a - 1] == key) { a--; steps++; }
+    if (a > 0 && ks[a - 1] == key) { // lower bound in [0, a)
+        int lo = 0, hi = a - 1;      // ks[hi] == key; find the first index with ks == key
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ks[mid] < key) lo = mid + 1; else hi = mid; }
+        a = lo;
+    }
+    steps = 0;
+    while (b < nv && steps < 4 && ks[b] == key) { b++; steps++; }
+    if (b < nv && ks[b] == key) {    // upper bound in (b, nv]
+        int lo = b, hi = nv;         // ks[lo] == key; find the first index with ks > key
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ks[mid] <= key) lo = mid + 1; else hi = mid; }
+        b = lo;
+    }
+}
 // y side: ranks by symbol.  One workgroup per day; ks/is = the day's sorted keys / symbol ids.
 __global__ __launch_bounds__(256) void tie_rank_scatter_kernel(const double *ks, const unsigned *is, const int32_t *n_valid, int64_t n,
                                                                double *rank_by_symbol) {
     const int64_t t = blockIdx.x, base = t * n;
     const int nv = n_valid[t];
     for (int i = threadIdx.x; i < nv; i += 256) {
-        const double key = ks[base + i];
-        int a = i, b = i + 1;
-        while (a > 0 && ks[base + a - 1] == key) a--;
-        while (b < nv && ks[base + b] == key) b++;
+        int a, b;
+        tie_run(ks + base, nv, i, a, b);
         rank_by_symbol[base + is[base + i]] = ((double)(a + 1) + (double)b) / 2.0;
     }
 }
@@ -116,10 +135,8 @@ __global__ __launch_bounds__(256) void rank_corr_kernel(const double *ks, const 
     const int nv = n_valid[t];
     double Sx = 0.0, Sy = 0.0, Sxx = 0.0, Syy = 0.0, Sxy = 0.0;
     for (int i = threadIdx.x; i < nv; i += 256) {
-        const double key = ks[base + i];
-        int a = i, b = i + 1;
-        while (a > 0 && ks[base + a - 1] == key) a--;
-        while (b < nv && ks[base + b] == key) b++;
+        int a, b;
+        tie_run(ks + base, nv, i, a, b);
         const double rx = ((double)(a + 1) + (double)b) / 2.0, ry = ry_by_symbol[base + is[base + i]];
         Sx += rx; Sy += ry; Sxx += rx * rx; Syy += ry * ry; Sxy += rx * ry;
     }

@@ -775,3 +775,21 @@ def test_full_size_config5_leveraged_backtest(pq, oracle):
     pm = api.portfolio_metrics(g["total_value"], 100000.0 * N, torch.from_numpy(bench).cuda()).cpu().numpy()
     assert pm.shape == (TT, 10) and np.isfinite(pm[:, 0]).all()
     np.testing.assert_allclose(pm[:, 0], tv.sum(axis=0), rtol=1e-12)  # portfolio_value = sum over symbols (blocked order)
+
+
+def test_rank_ic_discrete_factor_long_tie_runs(pq, oracle):
+    """Rank-IC with a discrete factor (signals in {-1, 0, 1}) and coarsely rounded returns: tie runs of ~1000 entries per day,
+    found by binary search instead of a linear walk (which would be O(n^2) loads per day)."""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(9)
+    N, T_ = 3000, 24
+    f = rng.integers(-1, 2, size=(N, T_)).astype(np.float64)
+    r = np.round(0.5 * f + rng.normal(size=(N, T_)), 1)
+    f[:, 0] = 0.0                                    # a constant day: zero variance -> null
+    f[rng.random((N, T_)) < 0.02] = oracle.NULL
+    eic, env = oracle.factor_ic(f, r, method=1)
+    ic, nv = api.factor_ic(torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda(), method=1)
+    g = ic.cpu().numpy()
+    assert (nv.cpu().numpy() == env).all()
+    assert ((bits(g) == bits(eic)) | (np.isnan(g) & np.isnan(eic))).all(), (g, eic)
+    assert bits(g)[0] == np.uint64(oracle.NULL_BITS) and np.isfinite(g[1:]).all()
