@@ -1,0 +1,199 @@
+// plugin.hip -- Polars expression-plugin entry points (include/pq_polars_plugin.h) over the C ABI of this library: a spike for
+// EMA / SMA.  Host code only: import the exported Series (Arrow C Data Interface, any number of chunks, validity + offset),
+// run the batched HIP entry point with n_series = 1, export one Float64 chunk.
+#include "../../include/pq_polars_plugin.h"
+#include "pq_dev.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_plugin_err;
+static void plugin_fail(const char *what) {
+    g_plugin_err = what;
+    const char *e = pq_last_error();
+    if (e && *e) { g_plugin_err += ": "; g_plugin_err += e; }
+}
+
+// ---- a minimal pickle reader: a dict whose keys are str and whose values are int / float / bool / None (what
+// polars.plugins passes for kwargs: pickle.dumps(dict, protocol 2..5))
+namespace {
+struct PVal { enum Kind { NONE, INT, FLOAT, STR, DICT, MARK } kind; int64_t i; double f; std::string s; };
+bool pickle_scalars(const uint8_t *p, size_t n, std::vector<std::pair<std::string, PVal>> &items) {
+    std::vector<PVal> st;
+    size_t k = 0;
+    auto need = [&](size_t m) { return k + m <= n; };
+    while (k < n) {
+        const uint8_t op = p[k++];
+        switch (op) {
+        case 0x80: if (!need(1)) return false; k += 1; break;                       // PROTO
+        case 0x95: if (!need(8)) return false; k += 8; break;                       // FRAME
+        case 0x94: break;                                                           // MEMOIZE
+        case 'q': if (!need(1)) return false; k += 1; break;                        // BINPUT
+        case 'r': if (!need(4)) return false; k += 4; break;                        // LONG_BINPUT
+        case '}': st.push_back(PVal{PVal::DICT, 0, 0.0, {}}); break;                // EMPTY_DICT
+        case '(': st.push_back(PVal{PVal::MARK, 0, 0.0, {}}); break;                // MARK
+        case 'N': st.push_back(PVal{PVal::NONE, 0, 0.0, {}}); break;
+        case 0x88: st.push_back(PVal{PVal::INT, 1, 0.0, {}}); break;                // NEWTRUE
+        case 0x89: st.push_back(PVal{PVal::INT, 0, 0.0, {}}); break;                // NEWFALSE
+        case 'K': if (!need(1)) return false; st.push_back(PVal{PVal::INT, p[k], 0.0, {}}); k += 1; break;
+        case 'M': if (!need(2)) return false; st.push_back(PVal{PVal::INT, (int64_t)(p[k] | (p[k + 1] << 8)), 0.0, {}}); k += 2; break;
+        case 'J': { if (!need(4)) return false; int32_t v; memcpy(&v, p + k, 4); st.push_back(PVal{PVal::INT, v, 0.0, {}}); k += 4; break; }
+        case 0x8a: { if (!need(1)) return false; const size_t m = p[k++]; if (m > 8 || !need(m)) return false; // LONG1 (little endian, signed)
+            int64_t v = 0; for (size_t j = 0; j < m; j++) v |= (int64_t)p[k + j] << (8 * j);
+            if (m > 0 && m < 8 && (p[k + m - 1] & 0x80)) v |= -((int64_t)1 << (8 * m));
+            st.push_back(PVal{PVal::INT, v, 0.0, {}}); k += m; break; }
+        case 'G': { if (!need(8)) return false; uint64_t b = 0; for (int j = 0; j < 8; j++) b = (b << 8) | p[k + j]; // BINFLOAT big endian
+            double d; memcpy(&d, &b, 8); st.push_back(PVal{PVal::FLOAT, 0, d, {}}); k += 8; break; }
+        case 0x8c: { if (!need(1)) return false; const size_t m = p[k++]; if (!need(m)) return false;             // SHORT_BINUNICODE
+            st.push_back(PVal{PVal::STR, 0, 0.0, std::string((const char *)p + k, m)}); k += m; break; }
+        case 'X': { if (!need(4)) return false; uint32_t m; memcpy(&m, p + k, 4); k += 4; if (!need(m)) return false; // BINUNICODE
+            st.push_back(PVal{PVal::STR, 0, 0.0, std::string((const char *)p + k, m)}); k += m; break; }
+        case 's': { if (st.size() < 3) return false; PVal v = st.back(); st.pop_back(); PVal key = st.back(); st.pop_back(); // SETITEM
+            if (key.kind != PVal::STR || st.back().kind != PVal::DICT) return false;
+            items.emplace_back(key.s, v); break; }
+        case 'u': { size_t m = st.size(); while (m > 0 && st[m - 1].kind != PVal::MARK) m--;                        // SETITEMS
+            if (m == 0 || m < 2 || st[m - 2].kind != PVal::DICT || (st.size() - m) % 2) return false;
+            for (size_t j = m; j + 1 < st.size(); j += 2) { if (st[j].kind != PVal::STR) return false; items.emplace_back(st[j].s, st[j + 1]); }
+            st.resize(m - 1); break; }
+        case '.': return true;                                                                                       // STOP
+        default: return false;
+        }
+    }
+    return false;
+}
+} // namespace
+
+extern "C" int32_t pq_plugin_kwargs_i64(const uint8_t *pickle, size_t len, const char *key, int64_t *out) {
+    if (!pickle || !len || !key || !out) return 0;
+    std::vector<std::pair<std::string, PVal>> items;
+    if (!pickle_scalars(pickle, len, items)) return -1;
+    for (auto &kv : items)
+        if (kv.first == key) {
+            if (kv.second.kind == PVal::INT) { *out = kv.second.i; return 1; }
+            if (kv.second.kind == PVal::FLOAT) { *out = (int64_t)kv.second.f; return 1; }
+            return 0; // None
+        }
+    return 0;
+}
+
+// ---- export side: one Float64 chunk owning its two buffers
+namespace {
+struct OutPriv { std::vector<uint8_t> validity; std::vector<double> values; const void *bufs[2]; std::string name; };
+void release_array(ArrowArray *a) { if (a && a->release) { delete (OutPriv *)a->private_data; a->release = nullptr; } }
+void release_schema(ArrowSchema *s) { if (s && s->release) { delete (std::string *)s->private_data; s->release = nullptr; } }
+void fill_schema(ArrowSchema *s, const std::string &name) {
+    std::string *keep = new std::string(name);
+    memset(s, 0, sizeof *s);
+    s->format = "g"; s->name = keep->c_str(); s->flags = 2 /* ARROW_FLAG_NULLABLE */; s->release = release_schema; s->private_data = keep;
+}
+void release_series(pq_series_export *e) {
+    if (!e || !e->release) return;
+    if (e->arrays) { for (size_t i = 0; i < e->len; i++) { if (e->arrays[i]) { if (e->arrays[i]->release) e->arrays[i]->release(e->arrays[i]); delete e->arrays[i]; } } delete[] e->arrays; }
+    if (e->field) { if (e->field->release) e->field->release(e->field); delete e->field; }
+    e->release = nullptr;
+}
+pq_ctx *plugin_ctx() { // one context per host thread (Polars calls plugins from its rayon workers)
+    static thread_local pq_ctx *c = nullptr;
+    if (!c && pq_ctx_create(0, nullptr, &c) != PQ_OK) c = nullptr;
+    return c;
+}
+typedef pq_status (*ma_fn)(pq_ctx *, const pq_batch *, const double *, int64_t, double *);
+
+void run_ma(ma_fn fn, const char *fname, int64_t default_period, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
+            size_t kwargs_len, pq_series_export *ret) {
+    if (ret) memset(ret, 0, sizeof *ret);
+    g_plugin_err.clear();
+    if (!inputs || n_inputs < 1 || !ret || !inputs[0].field || !inputs[0].field->format) { plugin_fail("plugin: bad arguments"); return; }
+    if (strcmp(inputs[0].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+    // parameter: pickled kwargs first (overlap.rs:18-22), else the trailing literal input (overlap.py:36-43), else the default
+    int64_t period = default_period;
+    int64_t v = 0;
+    const int32_t kw = pq_plugin_kwargs_i64(kwargs, kwargs_len, "timeperiod", &v);
+    if (kw < 0) { plugin_fail("plugin: cannot parse the pickled kwargs"); return; }
+    if (kw == 1) period = v;
+    else if (n_inputs >= 2 && inputs[1].len >= 1 && inputs[1].arrays && inputs[1].arrays[0] && inputs[1].arrays[0]->length >= 1 &&
+             inputs[1].field && inputs[1].field->format) {
+        const ArrowArray *a = inputs[1].arrays[0];
+        const char *f = inputs[1].field->format;
+        const void *data = a->n_buffers >= 2 ? a->buffers[1] : nullptr;
+        if (data && !strcmp(f, "l")) period = ((const int64_t *)data)[a->offset];
+        else if (data && !strcmp(f, "i")) period = ((const int32_t *)data)[a->offset];
+        else if (data && !strcmp(f, "g")) period = (int64_t)((const double *)data)[a->offset];
+    }
+    // gather the chunks into one host column + one validity bitmap (a Polars Series may arrive in several chunks)
+    int64_t n = 0;
+    for (size_t c = 0; c < inputs[0].len; c++) n += inputs[0].arrays[c]->length;
+    OutPriv *op = new OutPriv();
+    op->values.resize((size_t)(n > 0 ? n : 1));
+    op->validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
+    std::vector<double> host((size_t)(n > 0 ? n : 1));
+    bool any_null = false;
+    int64_t pos = 0;
+    for (size_t c = 0; c < inputs[0].len; c++) {
+        const ArrowArray *a = inputs[0].arrays[c];
+        if (a->n_buffers < 2 || (!a->buffers[1] && a->length)) { delete op; plugin_fail("plugin: malformed Float64 chunk"); return; }
+        if (a->length) memcpy(host.data() + pos, (const double *)a->buffers[1] + a->offset, (size_t)a->length * 8);
+        const uint8_t *vb = (const uint8_t *)a->buffers[0];
+        if (vb && a->null_count != 0)
+            for (int64_t i = 0; i < a->length; i++) {
+                const int64_t bi = a->offset + i;
+                if (!((vb[bi >> 3] >> (bi & 7)) & 1)) { op->validity[(size_t)((pos + i) >> 3)] &= (uint8_t)~(1u << ((pos + i) & 7)); any_null = true; }
+            }
+        pos += a->length;
+    }
+    int64_t null_count = 0;
+    if (n > 0) {
+        pq_ctx *ctx = plugin_ctx();
+        if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
+        void *d_in = nullptr, *d_out = nullptr, *d_bits = nullptr, *d_cnt = nullptr;
+        const size_t nb = (size_t)((n + 7) / 8);
+        pq_status st = pq_malloc(ctx, (size_t)n * 8, &d_in);
+        if (st == PQ_OK) st = pq_malloc(ctx, (size_t)n * 8, &d_out);
+        if (st == PQ_OK) st = pq_malloc(ctx, nb, &d_bits);
+        if (st == PQ_OK) st = pq_malloc(ctx, 8, &d_cnt);
+        if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in, host.data(), (size_t)n * 8);
+        if (st == PQ_OK && any_null) {
+            st = pq_memcpy_h2d(ctx, d_bits, op->validity.data(), nb);
+            if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in, (const uint8_t *)d_bits, 0, n);
+        }
+        const pq_batch b{1, n, n};
+        if (st == PQ_OK) st = fn(ctx, &b, (const double *)d_in, period, (double *)d_out);
+        if (st == PQ_OK) st = pq_validity_to_arrow(ctx, (const double *)d_out, n, (uint8_t *)d_bits, (int64_t *)d_cnt);
+        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->values.data(), d_out, (size_t)n * 8);
+        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->validity.data(), d_bits, nb);
+        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count, d_cnt, 8);
+        for (void *p : {d_in, d_out, d_bits, d_cnt}) if (p) (void)pq_free(ctx, p);
+        if (st != PQ_OK) { delete op; plugin_fail(fname); return; }
+    }
+    ArrowArray *arr = new ArrowArray();
+    memset(arr, 0, sizeof *arr);
+    op->bufs[0] = null_count ? op->validity.data() : nullptr;
+    op->bufs[1] = op->values.data();
+    arr->length = n; arr->null_count = null_count; arr->n_buffers = 2; arr->buffers = op->bufs; arr->release = release_array; arr->private_data = op;
+    ret->field = new ArrowSchema();
+    fill_schema(ret->field, inputs[0].field->name ? inputs[0].field->name : "");
+    ret->arrays = new ArrowArray *[1];
+    ret->arrays[0] = arr;
+    ret->len = 1;
+    ret->release = release_series;
+}
+void field_f64(ArrowSchema *fields, size_t n_fields, ArrowSchema *ret) {
+    if (!ret) return;
+    fill_schema(ret, (fields && n_fields >= 1 && fields[0].name) ? fields[0].name : "");
+}
+} // namespace
+
+extern "C" {
+uint32_t _polars_plugin_get_version(void) { return (0u << 16) | 1u; }
+const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_str(); }
+void _polars_plugin_ema(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, void *) {
+    run_ma(&pq_ema, "pq_ema", 30, inputs, n_inputs, kwargs, kwargs_len, ret);
+}
+void _polars_plugin_sma(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, void *) {
+    run_ma(&pq_sma, "pq_sma", 30, inputs, n_inputs, kwargs, kwargs_len, ret);
+}
+void _polars_plugin_field_ema(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+void _polars_plugin_field_sma(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+}

@@ -1,0 +1,140 @@
+"""The Polars expression-plugin exporter spike (include/pq_polars_plugin.h).  `polars` is not installed in
+this image, so the caller's side -- what Polars does after dlsym -- is played by pyarrow: Series are exported through the
+Arrow C Data Interface into hand-built SeriesExport structs.  The struct layout is the published polars-ffi one and is NOT
+verified against the pinned polars 0.53."""
+import ctypes as C
+import pickle
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pa = pytest.importorskip("pyarrow")
+ROOT = Path(__file__).resolve().parent.parent
+
+
+class ArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class SeriesExport(C.Structure):
+    _fields_ = [("field", C.POINTER(ArrowSchema)), ("arrays", C.POINTER(C.POINTER(ArrowArray))), ("len", C.c_size_t), ("release", C.c_void_p),
+                ("private_data", C.c_void_p)]
+
+
+def _lib():
+    so = ROOT / "polars_quant_amd" / "libpolars_quant_hip.so"
+    if not so.exists():
+        import __graft_entry__ as g
+        g.build()
+    L = C.CDLL(str(so))
+    L._polars_plugin_get_version.restype = C.c_uint32
+    L._polars_plugin_get_last_error_message.restype = C.c_char_p
+    L.pq_plugin_kwargs_i64.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int64)]
+    for f in ("_polars_plugin_ema", "_polars_plugin_sma"):
+        getattr(L, f).argtypes = [C.POINTER(SeriesExport), C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(SeriesExport), C.c_void_p]
+        getattr(L, f).restype = None
+    for f in ("_polars_plugin_field_ema", "_polars_plugin_field_sma"):
+        getattr(L, f).argtypes = [C.POINTER(ArrowSchema), C.c_size_t, C.POINTER(ArrowSchema), C.c_char_p, C.c_size_t]
+        getattr(L, f).restype = None
+    return L
+
+
+def test_plugin_symbols_and_version():
+    txt = (ROOT / "include" / "pq_polars_plugin.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(_polars_plugin_[a-z0-9_]+|pq_plugin_[a-z0-9_]+)\s*\(", txt)))
+    assert {"_polars_plugin_get_version", "_polars_plugin_get_last_error_message", "_polars_plugin_ema", "_polars_plugin_field_ema"} <= set(declared)
+    L = _lib()
+    assert not [s for s in declared if not hasattr(L, s)]
+    assert L._polars_plugin_get_version() == (0 << 16) | 1
+
+
+def test_pickled_kwargs_reader():
+    """what polars.plugins passes for `kwargs=`: pickle.dumps(dict) (serde-pickle on the Rust side, overlap.rs:18-22)"""
+    L = _lib()
+    for proto in (2, 3, 4, 5):
+        for d, want in (({"timeperiod": 20}, (1, 20)), ({"timeperiod": 300, "matype": None}, (1, 300)), ({"matype": 1, "timeperiod": 70000}, (1, 70000)),
+                        ({"timeperiod": 2 ** 40}, (1, 2 ** 40)), ({"timeperiod": -3, "flag": True}, (1, -3)), ({}, (0, None)),
+                        ({"timeperiod": None}, (0, None)), ({"vfactor": 0.7}, (0, None))):
+            b, v = pickle.dumps(d, protocol=proto), C.c_int64(-999)
+            r = L.pq_plugin_kwargs_i64(b, len(b), b"timeperiod", C.byref(v))
+            assert r == want[0] and (want[1] is None or v.value == want[1]), (proto, d, r, v.value)
+    v = C.c_int64()
+    assert L.pq_plugin_kwargs_i64(b"\x80\x05garbage", 9, b"timeperiod", C.byref(v)) == -1
+    assert L.pq_plugin_kwargs_i64(pickle.dumps([1, 2]), len(pickle.dumps([1, 2])), b"timeperiod", C.byref(v)) == -1
+
+
+def _export(chunks, name):
+    """pyarrow chunks -> SeriesExport (keeps the ctypes objects alive through the returned tuple)"""
+    field = ArrowSchema()
+    arrs = [ArrowArray() for _ in chunks]
+    ptrs = (C.POINTER(ArrowArray) * len(chunks))(*[C.pointer(a) for a in arrs])
+    for i, (ch, a) in enumerate(zip(chunks, arrs)):
+        sch = ArrowSchema()
+        ch._export_to_c(C.addressof(a), C.addressof(sch) if i else C.addressof(field))
+    field_named = pa.field(name, chunks[0].type)
+    field2 = ArrowSchema()
+    field_named._export_to_c(C.addressof(field2))
+    se = SeriesExport(C.pointer(field2), ptrs, len(chunks), None, None)
+    return se, (field, field2, arrs, ptrs)
+
+
+def _import(ret):
+    assert ret.release, "the plugin left return_value empty"
+    assert ret.len == 1
+    return pa.Array._import_from_c(C.addressof(ret.arrays[0].contents), C.addressof(ret.field.contents))
+
+
+@pytest.mark.gpu
+def test_plugin_calls_match_the_oracle(oracle):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    d = oracle.gen_ohlcv(0x5EED000B, 1, 500, 0)
+    x = d["close"][0]
+    mask = np.zeros(500, bool); mask[[0, 1, 77, 300]] = True
+    xn = x.copy(); xn[mask] = oracle.NULL
+    whole = pa.array(x, mask=mask)
+    # (a) three chunks (one of them a slice with a non-zero offset), timeperiod as pickled kwargs
+    chunks = [whole.slice(0, 100), pa.concat_arrays([pa.array([1.0, 2.0, 3.0]), whole.slice(100, 250)]).slice(3), whole.slice(350)]
+    assert chunks[1].offset == 3
+    se, keep = _export(chunks, "close")
+    ret = SeriesExport()
+    kw = pickle.dumps({"timeperiod": 20})
+    L._polars_plugin_ema(C.byref(se), 1, kw, len(kw), C.byref(ret), None)
+    assert ret.release, L._polars_plugin_get_last_error_message()
+    assert ret.field.contents.name == b"close" and ret.field.contents.format == b"g"
+    got = _import(ret)
+    (exp,) = oracle.call("ema", xn, timeperiod=20)
+    en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+    assert got.null_count == int(en.sum()) and (np.asarray(got.is_null()) == en).all()
+    vals = got.to_numpy(zero_copy_only=False)
+    assert (vals[~en].view(np.uint64) == exp[~en].view(np.uint64)).all()
+    # (b) the Python wrapper's convention: timeperiod as a trailing literal input (overlap.py:36-43), no kwargs
+    se0, keep0 = _export([whole], "px")
+    se1, keep1 = _export([pa.array([7], type=pa.int64())], "literal")
+    ins = (SeriesExport * 2)(se0, se1)
+    ret = SeriesExport()
+    L._polars_plugin_sma(ins, 2, None, 0, C.byref(ret), None)
+    got = _import(ret)
+    (exp,) = oracle.call("sma", xn, timeperiod=7)
+    en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+    assert (np.asarray(got.is_null()) == en).all()
+    assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all()
+    # (c) output field + error path (a non-Float64 input is refused with a message, return_value stays empty)
+    out_field = ArrowSchema()
+    L._polars_plugin_field_ema(se0.field, 1, C.byref(out_field), None, 0)
+    assert out_field.format == b"g" and out_field.name == b"px"
+    sei, keepi = _export([pa.array([1, 2, 3], type=pa.int64())], "ints")
+    ret = SeriesExport()
+    L._polars_plugin_ema(C.byref(sei), 1, None, 0, C.byref(ret), None)
+    assert not ret.release and b"Float64" in L._polars_plugin_get_last_error_message()
