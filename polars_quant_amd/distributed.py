@@ -32,3 +32,59 @@ def gather_summaries(local: torch.Tensor, n_symbols: int, group=None) -> torch.T
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:k] for p, k in zip(parts, sizes)], dim=0)
+
+
+# ---- BASELINE config 4 (cross-sectional factor IC / Rank-IC): the parallel axis is the DAY, not the symbol (SURVEY 8e exception)
+# A day's IC needs every symbol of that day, so the symbol-sharded layout of the rest of the path does not fit: rank r owns
+# the days [shard_range(T, r, G)) with ALL symbols.  If the columns arrive symbol-sharded (the layout every other call
+# uses), one all-to-all re-shards them -- rank r sends rank q the day-slice q of its symbol rows, 1/G of its data per peer:
+# at 10 000 x 5 040 that is 50 MB per column and GPU in total, ~6.3 MB per peer, spread over the 7 xGMI links at once -- and
+# one all_gather of the [T_local] IC series puts the full series on every rank.
+def days_all_to_all(local_cols: torch.Tensor, n_symbols: int, group=None) -> torch.Tensor:
+    """local_cols: [n_local, T] (this rank's symbol shard, all days) -> [n_symbols, T_local] (all symbols, this rank's days)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    T = local_cols.shape[1]
+    if world == 1:
+        return local_cols
+    t_lo, t_hi = shard_range(T, rank, world)
+    send = [local_cols[:, shard_range(T, q, world)[0]:shard_range(T, q, world)[1]].contiguous() for q in range(world)]
+    recv = [torch.empty((shard_range(n_symbols, q, world)[1] - shard_range(n_symbols, q, world)[0], t_hi - t_lo),
+                        dtype=local_cols.dtype, device=local_cols.device) for q in range(world)]
+    # point-to-point pairs (xGMI is point-to-point: every peer has its own link) rather than the all_to_all collective, which
+    # the gloo backend used by the CPU tests does not implement
+    recv[rank].copy_(send[rank])
+    ops = []
+    for q in range(world):
+        if q != rank:
+            ops.append(dist.P2POp(dist.isend, send[q], q, group))
+            ops.append(dist.P2POp(dist.irecv, recv[q], q, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    return torch.cat(recv, dim=0)
+
+
+def gather_day_series(local: torch.Tensor, T: int, group=None) -> torch.Tensor:
+    """local: [T_local] values of this rank's days -> [T] on every rank (ragged shards padded to the longest)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = [shard_range(T, r, world)[1] - shard_range(T, r, world)[0] for r in range(world)]
+    m = max(sizes)
+    pad = torch.zeros(m, dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)])
+
+
+def factor_ic_day_sharded(factor_local, fwd_local, n_symbols: int, method: int = 0, compute=None, group=None):
+    """Day-sharded IC / Rank-IC of symbol-sharded inputs [n_local, T]: all-to-all -> per-day IC on this rank's days -> gather.
+    `compute(factor [N, T_local], fwd [N, T_local], method) -> (ic [T_local], n_valid [T_local])`; default: the HIP path."""
+    if compute is None:
+        from . import api
+        compute = lambda f, r, m: api.factor_ic(f, r, method=m)
+    T = factor_local.shape[1]
+    f = days_all_to_all(factor_local, n_symbols, group)
+    r = days_all_to_all(fwd_local, n_symbols, group)
+    ic, nv = compute(f, r, method)
+    return gather_day_series(ic, T, group), gather_day_series(nv, T, group)

@@ -55,3 +55,52 @@ def test_two_rank_symbol_sharding(n_sym, oracle):
     _, _, _, exp = oracle.backtest(d["close"], buy, sell)
     assert got.shape == (n_sym, 8)
     assert (got.view(np.uint64) == exp.view(np.uint64)).all()
+
+
+def _worker_days(rank, world, n_sym, T, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pq_oracle as oracle
+    from polars_quant_amd.distributed import factor_ic_day_sharded, shard_range
+    rng = np.random.default_rng(12)                       # every rank regenerates the same data and keeps its symbol shard
+    f = rng.normal(size=(n_sym, T)); r = 0.3 * f + rng.normal(size=(n_sym, T))
+    f[rng.random((n_sym, T)) < 0.05] = oracle.NULL
+    lo, hi = shard_range(n_sym, rank, world)
+
+    def compute(ff, rr, m):                                # CPU stand-in for api.factor_ic (no HIP device here)
+        ic, nv = oracle.factor_ic(ff.numpy(), rr.numpy(), method=m)
+        return torch.from_numpy(ic), torch.from_numpy(nv)
+    res = {}
+    for m in (0, 1):
+        ic, nv = factor_ic_day_sharded(torch.from_numpy(f[lo:hi].copy()), torch.from_numpy(r[lo:hi].copy()), n_sym, method=m, compute=compute)
+        res[m] = (ic.numpy(), nv.numpy())
+    if rank == 1:                                          # any rank holds the full series
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_sym,T", [(12, 40), (7, 33)])   # even and ragged splits of both axes
+def test_two_rank_day_sharded_factor_ic(n_sym, T, oracle):
+    """BASELINE config 4 across GPUs: symbol-sharded columns -> one all-to-all -> day-sharded IC / Rank-IC -> gather; the
+    assembled series equals the single-process oracle bit for bit (cross-sections are independent per day)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + n_sym
+    procs = [ctx.Process(target=_worker_days, args=(r, 2, n_sym, T, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(12)
+    f = rng.normal(size=(n_sym, T)); r = 0.3 * f + rng.normal(size=(n_sym, T))
+    f[rng.random((n_sym, T)) < 0.05] = oracle.NULL
+    for m in (0, 1):
+        eic, env = oracle.factor_ic(f, r, method=m)
+        gic, gnv = got[m]
+        assert (gnv == env).all()
+        assert ((gic.view(np.uint64) == eic.view(np.uint64)) | (np.isnan(gic) & np.isnan(eic))).all()
