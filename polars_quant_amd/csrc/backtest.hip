@@ -102,7 +102,6 @@ pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *pr
                      (quantity != nullptr) + (pnl != nullptr) + (pnl_pct != nullptr) + (reason != nullptr);
     PQ_REQUIRE(nrec == 0 || nrec == 8, "pq_backtest_leveraged: pass all eight trade-record arrays or none");
     PQ_REQUIRE(max_trades >= 0, "pq_backtest_leveraged: max_trades < 0");
-    if (ctx->rec) { pq_set_error("pq_backtest_leveraged cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
     if (b->n_series == 0) return PQ_OK;
     LevArgs a{};
     a.price = price; a.buy = buy; a.sell = sell; a.bench = benchmark;
@@ -115,6 +114,7 @@ pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *pr
         op.a = a; op.stride = b->stride;
         return launch_seq(ctx, b, op, InCols<1>{{price}}, OutCols<3>{{cash_net, stock_value, total_value}});
     }
+    if (ctx->rec) { pq_set_error("pq_backtest_leveraged can only be recorded into a suite with stride % 8 == 0 and 8-byte aligned signals"); return PQ_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
     hipLaunchKernelGGL(lev_backtest_kernel, grid, dim3(SEQ_BLOCK), 0, ctx->stream, a, dims_of(b));
     PQ_HIP_TRY(hipGetLastError());

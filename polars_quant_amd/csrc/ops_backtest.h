@@ -415,6 +415,10 @@ static __global__ __launch_bounds__(SEQ_BLOCK) void lev_backtest_kernel(LevArgs 
 struct LevOp {
     static constexpr int NIN = 1, NOUT = 3;
     static constexpr int TILE_K = 8;
+    static constexpr int SEQ_ID = 63;
+    static constexpr int COST_NS = 1500; // branchy per-lane state machine: some lane of the wave trades on nearly every row
+    // columns the op reads beside its tile inputs (hazard tracking of a recorded suite)
+    __host__ void extra_reads(const void *(&r)[4]) const { r[0] = a.buy; r[1] = a.sell; r[2] = a.bench; r[3] = nullptr; }
     LevArgs a;
     int64_t stride; // elements between series (set by the launcher)
     // per-lane state

@@ -687,7 +687,12 @@ struct SeqTraits { // what the scheduler needs to know about a recorded job
     size_t tile_bytes;
     int alg_cols;      // f64 column transfers credited (per reference call)
     double summary_bytes_per_series; // extra algorithmic bytes per series (the backtest's summary row)
+    const void *extra_reads[4];      // columns read outside the tile path (signal / benchmark columns): ordering hazards only
 };
+template <class Op, class = void>
+struct HasExtraReads { static constexpr bool value = false; };
+template <class Op>
+struct HasExtraReads<Op, decltype((void)&Op::extra_reads)> { static constexpr bool value = true; };
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const void *op, size_t op_bytes, const double *const *in,
                       int nin, double *const *out, int nout, void *extra_write = nullptr);
 struct RowThunk { // type-erased ROW launch for replay
@@ -740,7 +745,8 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
             void *extra = nullptr;
             if constexpr (HasFinish<Op>::value) extra = op.finish_writes();
             SeqTraits tr{Op::SEQ_ID, (int)((double)OpCost<Op>::get(op) * (double)b->len * 1e-3), IsHeavy<Op>::value, IsMasked<Op>::value,
-                         use_lds ? lds : 0, (size_t)SeqTile<Op>::BYTES, AlgCols<Op>::value, HasFinish<Op>::value ? 64.0 : 0.0};
+                         use_lds ? lds : 0, (size_t)SeqTile<Op>::BYTES, AlgCols<Op>::value, HasFinish<Op>::value ? 64.0 : 0.0, {}};
+            if constexpr (HasExtraReads<Op>::value) op.extra_reads(tr.extra_reads);
             return rec_add_seq(ctx, b, tr, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, extra);
         } else {
             pq_set_error("this SEQ op cannot be recorded into a suite");

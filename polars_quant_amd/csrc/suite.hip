@@ -94,7 +94,7 @@ struct pq_suite {
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(BtMacdOp)                                     \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \
     X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
@@ -217,7 +217,11 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
     void *writes[9];
     for (int k = 0; k < nout; k++) writes[k] = out[k];
     writes[nout] = extra_write; // e.g. the backtest's summary table: hazard tracking only
-    int ph = phase_for(r, (const void *const *)in, nin, writes, nout + 1);
+    const void *reads[10];
+    int nr = 0;
+    for (int k = 0; k < nin; k++) reads[nr++] = in[k];
+    for (int k = 0; k < 4; k++) if (tr.extra_reads[k]) reads[nr++] = tr.extra_reads[k];
+    int ph = phase_for(r, reads, nr, writes, nout + 1);
     r.phases[ph].seq.push_back(j);
     return PQ_OK;
 }

@@ -32,3 +32,38 @@ ns = 512
 b, s = buy[:ns].cpu().numpy(), sell[:ns].cpu().numpy()
 t0 = time.perf_counter(); e = oracle.backtest_leveraged(d["close"][:ns], b, s, d["close"][0], leverage=2.0, slippage=0.001); oracle.portfolio_metrics(e["total_value"], 1e5 * ns, d["close"][0]); dt = time.perf_counter() - t0
 print(f"oracle (1 thread, {ns} symbols): {ns*T/dt/1e6:.2f} M rows/s")
+
+# --- the same engine as ONE job of a recorded suite: beside the indicator suite it is 79 workgroups among ~2400
+import ctypes as C
+from polars_quant_amd._lib import Batch, LevParams, check, lib
+from polars_quant_amd._spec import LEV_DEFAULTS
+from polars_quant_amd.suite import Suite
+g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+st = Suite(N, T, "cuda")
+L, h = lib(), api.ctx(0)
+cash, sv, tv = (torch.empty((N, T), dtype=torch.float64, device="cuda") for _ in range(3))
+cnt = torch.zeros(N, dtype=torch.int32, device="cuda")
+summ = torch.empty((N, 8), dtype=torch.float64, device="cuda")
+prm = LevParams(**{**LEV_DEFAULTS, "leverage": 2.0, "slippage": 0.001})
+vp = lambda t: C.c_void_p(t.data_ptr())
+def timed(with_lev):
+    st.close()
+    check(L.pq_suite_begin(h, C.byref(st.batch)))
+    for name in st.tasks(fused=True):
+        st.run_one(name, g)
+    if with_lev:
+        check(L.pq_backtest_leveraged(h, C.byref(st.batch), vp(close), vp(buy), vp(sell), vp(bench), C.byref(prm), vp(cash), vp(sv), vp(tv), 0, vp(cnt),
+                                      *([None] * 8), vp(summ)))
+    out = C.c_void_p()
+    check(L.pq_suite_end(h, C.byref(out)))
+    st._suite = out
+    for _ in range(3): st.run()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10): st.run()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / 10
+a, b_ = timed(False), timed(True)
+ok = (tv.cpu().numpy().view(np.uint64) == r["total_value"].cpu().numpy().view(np.uint64)).all()
+print(f"suite step without / with the leveraged backtest as one more job: {a:.3f} / {b_:.3f} ms  (+{b_ - a:.3f} ms in-suite vs {ms_bt:.3f} ms solo); "
+      f"recorded result == direct call: {ok}")
