@@ -665,7 +665,10 @@ static inline bool seq_cols_aligned(const pq_batch *b, const double *const *in, 
 }
 
 template <class Op, bool LDS>
-__global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
+#ifndef PQ_SEQ_MIN_WAVES
+#define PQ_SEQ_MIN_WAVES 1 // analysis builds: 3 = compile every stand-alone op kernel under the light job kernel's register cap
+#endif
+__global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK, PQ_SEQ_MIN_WAVES) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
     if constexpr (LDS) {
         extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
         run_seq_lds(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
