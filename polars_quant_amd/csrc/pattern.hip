@@ -233,7 +233,10 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
     const int64_t base = s * d.stride;
     // ~1500 instructions per row: beside the SEQ grids of a suite (whose long jobs raise their own priority) this kernel would
     // otherwise only be issued in the gaps and become the critical path of the step
-    __builtin_amdgcn_s_setprio(3);
+#ifndef PQ_CDL_PRIO
+#define PQ_CDL_PRIO 1 // 3: +4 % per suite step (A/B): at 0.87 ms of work it no longer needs to win against the SEQ jobs
+#endif
+    __builtin_amdgcn_s_setprio(PQ_CDL_PRIO);
     Cdl w[CDL_R + 4]; // w[k] = candle of row t0 + CDL_R - 1 - k
 #pragma unroll
     for (int k = 0; k < CDL_R + 4; k++) {

@@ -46,8 +46,9 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
 //    concurrently, any further stream is serialized behind another one.
 // Hence four grids = four chains:
 //   LONG   (caller's stream)  the light-register jobs in order of decreasing cost, as many as fill the chip at t = 0, then
-//                             the "fat" ones (more LDS than THIN_LDS_MAX) whatever their cost; the lighter ROW launches follow
-//   SHORT  the remaining light-register jobs (all thin), longest first: they fill the chip as LONG workgroups retire
+//                             the "fat" ones (more LDS than THIN_LDS_MAX) whatever their cost
+//   SHORT  the remaining light-register jobs (all thin), longest first: they fill the chip as LONG workgroups retire;
+//          the lighter ROW launches follow on the same stream
 //   HEAVY  the register-heavy jobs (seq_jobs_kernel<1>, 2 waves/SIMD) + the per-lane backtest scan
 //   GATHER gather-body fallbacks (very long windows / unaligned columns), and the ROW launches
 enum { CLS_LONG = 0, CLS_SHORT = 1, CLS_HEAVY = 2, CLS_GATHER = 3, NCLS = 4, NCHAIN = 4, ROW_CHAIN = 3 };
@@ -259,9 +260,9 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         p.gs_row.n_jobs = (int)p.rows.size();
         // The ROW launches are cheap streaming kernels, but beside the SEQ grids they get few wave slots and one chain of
         // them becomes the critical path of the step.  Two chains: the heaviest launches (by columns moved) stay on the ROW
-        // chain from t = 0; the lighter half runs on the caller's stream behind the LONG grid.  Measured alternatives: all
-        // ROW launches on one chain (that chain becomes the critical path), the light half behind the HEAVY or the SHORT
-        // grid, early fractions of 0 / 0.3 / 0.7: all 2 - 8 % slower per step.
+        // chain from t = 0; the lighter half runs behind the SHORT grid, the first SEQ grid to drain (-4 % per step against
+        // behind the LONG grid, A/B in one session).  Measured alternatives: all ROW launches on one chain (that chain becomes the
+        // critical path), the light half behind the HEAVY grid, early fractions of 0 / 0.3 / 0.7: 2 - 8 % slower per step.
         p.row_late.assign(p.rows.size(), 0);
         if (!p.seq.empty()) {
             double total = 0, early = 0;
@@ -272,7 +273,10 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
             for (size_t k : idx) {
                 if (early < 0.5 * total) { early += weight(p.rows[k]); continue; }
-                p.row_late[k] = 1 + CLS_LONG;
+#ifndef PQ_ROW_LATE_CLS
+#define PQ_ROW_LATE_CLS CLS_SHORT
+#endif
+                p.row_late[k] = 1 + PQ_ROW_LATE_CLS;
             }
         }
         if (p.seq.empty()) continue;
