@@ -223,6 +223,11 @@ pq_status pq_wclprice(pq_ctx *, const pq_batch *, const double *high, const doub
  * either price is null; period <= 0 or another method: all null.  Pinned by the reference-held vector README.md:75. */
 pq_status pq_returns(pq_ctx *, const pq_batch *, const double *price, int64_t period, int64_t method, double *out);
 
+/* rolling maximum / minimum over the last `window` rows, null until the frame holds `window` non-null rows (the Polars
+ * rolling_max / rolling_min of momentum.py:181-183): channel bounds for the README's breakout strategy (README.md:947) */
+pq_status pq_rolling_max(pq_ctx *, const pq_batch *, const double *x, int64_t window, double *out);
+pq_status pq_rolling_min(pq_ctx *, const pq_batch *, const double *x, int64_t window, double *out);
+
 /* ---- cycle (src/talib/cycle.rs) ---- */
 pq_status pq_ht_dcperiod(pq_ctx *, const pq_batch *, const double *real, double *out);                          /* :10 */
 pq_status pq_ht_dcphase(pq_ctx *, const pq_batch *, const double *real, double *out);                           /* :75 */

@@ -249,6 +249,23 @@ void pqo_returns(const double *v, int64_t n, int64_t period, int64_t method, dou
         out[i] = method == 0 ? (c - pr) / pr : log(c / pr);
     }
 }
+/* Polars rolling_max / rolling_min(window) (python/polars_quant/talib/momentum.py:181-183): null until the frame of the last
+ * `window` rows holds `window` non-null rows */
+static void roll_ext(const double *v, int64_t n, int64_t w, int is_max, double *out) {
+    pqo_fill_null(out, n);
+    if (w <= 0) return;
+    for (int64_t i = w - 1; i < n; i++) {
+        double best = v[i];
+        int ok = !pqo_isnull(best);
+        for (int64_t j = i + 1 - w; j < i && ok; j++) {
+            if (pqo_isnull(v[j])) { ok = 0; break; }
+            if (is_max ? v[j] > best : v[j] < best) best = v[j];
+        }
+        if (ok) out[i] = best;
+    }
+}
+void pqo_rolling_max(const double *v, int64_t n, int64_t w, double *out) { roll_ext(v, n, w, 1, out); }
+void pqo_rolling_min(const double *v, int64_t n, int64_t w, double *out) { roll_ext(v, n, w, 0, out); }
 /* momentum.rs:507-541 */
 void pqo_rsi(const double *v, int64_t n, int64_t p, double *out) {
     double *ups = (double *)calloc((size_t)(n > 0 ? n : 1), 8), *downs = (double *)calloc((size_t)(n > 0 ? n : 1), 8);

@@ -78,6 +78,8 @@ void pqo_rocp(const double *v, int64_t n, int64_t p, double *out);
 void pqo_rocr(const double *v, int64_t n, int64_t p, double *out);
 void pqo_rocr100(const double *v, int64_t n, int64_t p, double *out);
 void pqo_returns(const double *v, int64_t n, int64_t period, int64_t method, double *out); /* README.md:46-75, D-13 */
+void pqo_rolling_max(const double *v, int64_t n, int64_t w, double *out); /* momentum.py:182 (Polars rolling_max) */
+void pqo_rolling_min(const double *v, int64_t n, int64_t w, double *out);
 void pqo_rsi(const double *v, int64_t n, int64_t p, double *out);
 void pqo_trix(const double *v, int64_t n, int64_t p, double *out);
 void pqo_ultosc(const double *h, const double *l, const double *c, int64_t n, int64_t p1,

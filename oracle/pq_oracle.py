@@ -106,6 +106,8 @@ SPEC = {
 # functions outside talib.* that share the (inputs, params, outputs) calling shape; not part of the indicator suite
 EXTRA = {
     "returns": (["real"], [("period", I, 1), ("method", I, 0)], [("return", "f8")]),  # README.md:46-75 (D-13); 0 simple, 1 log
+    "rolling_max": (["real"], [("window", I, 20)], [("rolling_max", "f8")]),
+    "rolling_min": (["real"], [("window", I, 20)], [("rolling_min", "f8")]),
 }
 
 PATTERN_NAMES = [

@@ -96,6 +96,8 @@ SPEC = {
 EXTRA = {
     # README.md:46-75 returns(df, price_col, period, method): method 0 "simple", 1 "log" (decision D-13)
     "returns": (["real"], [("period", I, 1), ("method", I, 0)], [("return", "f8")], NC),
+    "rolling_max": (["real"], [("window", I, 20)], [("rolling_max", "f8")], NA),   # Polars rolling_max (momentum.py:182)
+    "rolling_min": (["real"], [("window", I, 20)], [("rolling_min", "f8")], NA),
 }
 
 PATTERN_NAMES = [

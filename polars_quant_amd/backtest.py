@@ -132,6 +132,20 @@ class Backtest:
     def get_stock_positions(self, symbol):
         return self.get_position_records(symbol)
 
+    def get_stock_performance(self, symbol):
+        """README.md:554-589: one symbol's daily performance -- stock_value (its total assets), daily / cumulative P&L and
+        returns, and with a benchmark the benchmark return, alpha and relative return: the portfolio-metrics kernel on this
+        symbol's own capital pool."""
+        self._need()
+        i = self.symbols.index(symbol)
+        tv = np.ascontiguousarray(self._r["total_value"][i:i + 1])
+        m = _api.portfolio_metrics(tv, self.params["initial_capital"], self._bench).cpu().numpy()
+        cols = {"symbol": [symbol] * len(self.dates), "date": self.dates, "stock_value": m[:, 0], "daily_pnl": m[:, 1],
+                "daily_return_pct": m[:, 2], "cumulative_pnl": m[:, 3], "cumulative_return_pct": m[:, 4]}
+        if self._bench is not None:
+            cols.update({"benchmark_return_pct": m[:, 5], "alpha_pct": m[:, 6], "relative_return_pct": m[:, 7]})
+        return self._table(cols)
+
     def get_stock_summary(self, symbol) -> str:
         self._need()
         i = self.symbols.index(symbol)

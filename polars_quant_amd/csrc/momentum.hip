@@ -28,6 +28,16 @@ pq_status pq_returns(pq_ctx *ctx, const pq_batch *b, const double *price, int64_
     ReturnsOp<1> op{}; op.p = (method == 1) ? period : 0; // an unknown method: all null (as period <= 0)
     return launch_row(ctx, b, op, InCols<1>{{price}}, OutColsT<ReturnsOp<1>, double>{{out}});
 }
+pq_status pq_rolling_max(pq_ctx *ctx, const pq_batch *b, const double *x, int64_t window, double *out) {
+    CHK("pq_rolling_max", x && out);
+    RollingExtOp<true> op{}; op.p = window;
+    return launch_row(ctx, b, op, InCols<1>{{x}}, OutColsT<RollingExtOp<true>, double>{{out}});
+}
+pq_status pq_rolling_min(pq_ctx *ctx, const pq_batch *b, const double *x, int64_t window, double *out) {
+    CHK("pq_rolling_min", x && out);
+    RollingExtOp<false> op{}; op.p = window;
+    return launch_row(ctx, b, op, InCols<1>{{x}}, OutColsT<RollingExtOp<false>, double>{{out}});
+}
 pq_status pq_bop(pq_ctx *ctx, const pq_batch *b, const double *o, const double *h, const double *l, const double *c,
                  double *out) {
     CHK("pq_bop", o && h && l && c && out);

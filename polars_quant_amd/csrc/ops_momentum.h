@@ -41,6 +41,26 @@ struct ReturnsOp {
         y[0] = METHOD == 0 ? (c - pr) / pr : log(c / pr);
     }
 };
+// rolling maximum / minimum over the last p rows (the Polars rolling_max / rolling_min frame of momentum.py:181-183: null until
+// the frame holds p non-null rows) -- the channel bounds of the README's breakout (Donchian) strategy
+template <bool IS_MAX>
+struct RollingExtOp {
+    static constexpr int NIN = 1, NOUT = 1;
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0 || t < p - 1) return;
+        double best = r.in[0][t];
+        if (pq_isnull(best)) return;
+        for (int64_t j = t + 1 - p; j < t; j++) {
+            const double v = r.in[0][j];
+            if (pq_isnull(v)) return;
+            best = IS_MAX ? (v > best ? v : best) : (v < best ? v : best);
+        }
+        y[0] = best;
+    }
+};
 struct BopOp { // momentum.rs:113-135
     static constexpr int NIN = 4, NOUT = 1;
     typedef double OutT;

@@ -3,9 +3,11 @@ decision D-11 (oracle/backtest.c).  README-only in the reference: the rules are 
 
 Every method takes a dict / DataFrame of [N, T] (or [T]) columns named open/high/low/close/volume and returns
 {"buy_signal": uint8 [N, T], "sell_signal": uint8 [N, T]} (device tensors), ready for `VectorizedBacktester`,
-`api.backtest_vectorized` or `Backtest`.  Implemented: ma, macd, rsi, bband, stoch, cci (the other README strategies need
-indicators outside the reference's talib set, e.g. rolling max/min for the Donchian breakout: `api.channel_signals(price,
-lo, hi, 1)` takes such bounds directly).
+`api.backtest_vectorized` or `Backtest`.  All fourteen README names are here: ma, macd, rsi, bband, stoch, cci, adx, breakout,
+reversion, volume, grid, gap, pattern, trend.  The README documents parameters only for ma / macd / rsi (its `.pyi` has no
+`Strategy` class), so for the others the definitions in the docstrings below are this build's (decision D-11b); every
+indicator value comes from the HIP kernels, the comparisons that turn them into signals are the D-11 rule kernels or plain
+element-wise tensor operations on the device.
 """
 from __future__ import annotations
 
@@ -21,8 +23,11 @@ def _col(df, name):
 
 
 class Strategy:
-    def ma(self, df, price_col="close", fast_period=10, slow_period=20, ma_type="sma", trend_period=0, trend_filter=False):
-        """golden / dead cross of MA(fast) and MA(slow); with trend_filter, buys only while price > MA(trend_period)"""
+    def ma(self, df, price_col="close", fast_period=10, slow_period=20, ma_type="sma", trend_period=0, trend_filter=False,
+           slope_filter=False, distance_pct=0.0):
+        """golden / dead cross of MA(fast) and MA(slow) (README.md:877-905); trend_filter: buys only while price > MA(trend_period);
+        slope_filter: buys only while the slow MA rises (slow[i] > slow[i-1]); distance_pct: buys only while the price is at
+        least that many percent above the slow MA"""
         if ma_type not in _MA:
             raise ValueError(f"ma_type must be one of {sorted(_MA)}")
         x = _col(df, price_col)
@@ -34,6 +39,15 @@ class Strategy:
             p = _api._to_device(x)[0]
             t = _api._to_device(trend)[0]
             buy = buy & (p > t).to(torch.uint8)      # a null trend value compares False
+        if slope_filter or distance_pct > 0.0:
+            p = _api._to_device(x)[0]
+            sl = _api._to_device(slow)[0]
+            if slope_filter:
+                rising = torch.zeros_like(buy)
+                rising[:, 1:] = (sl[:, 1:] > sl[:, :-1]).to(torch.uint8)
+                buy = buy & rising
+            if distance_pct > 0.0:
+                buy = buy & ((p - sl) > sl.abs() * (distance_pct / 100.0)).to(torch.uint8)
         return {"buy_signal": buy, "sell_signal": sell}
 
     def macd(self, df, price_col="close", fast_period=12, slow_period=26, signal_period=9):
@@ -66,3 +80,84 @@ class Strategy:
         (c,) = _api.call("cci", _col(df, "high"), _col(df, "low"), _col(df, "close"), timeperiod=period)
         buy, sell = _api.band_signals(c, oversold, overbought)
         return {"buy_signal": buy, "sell_signal": sell}
+
+    # ---- the README names without documented parameters (README.md:946-953): definitions = decision D-11b --------------
+    def adx(self, df, period=14, threshold=25.0):
+        """trend strength: +DM crossing above -DM (the reference's smoothed directional movements) while ADX > threshold buys,
+        the opposite cross while ADX > threshold sells"""
+        h, l, c = _col(df, "high"), _col(df, "low"), _col(df, "close")
+        (pdm,) = _api.call("plus_dm", h, l, timeperiod=period)
+        (mdm,) = _api.call("minus_dm", h, l, timeperiod=period)
+        (adx,) = _api.call("adx", h, l, c, timeperiod=period)
+        buy, sell = _api.cross_signals(pdm, mdm)
+        strong = (_api._to_device(adx)[0] > threshold).to(torch.uint8)      # null ADX compares False
+        return {"buy_signal": buy & strong, "sell_signal": sell & strong}
+
+    def breakout(self, df, period=20):
+        """Donchian channel: buy when the close exceeds the highest high of the previous `period` bars, sell when it falls
+        below their lowest low (rule `channel`, mode 1)"""
+        (hi,) = _api.call("rolling_max", _col(df, "high"), window=period)
+        (lo,) = _api.call("rolling_min", _col(df, "low"), window=period)
+        buy, sell = _api.channel_signals(_col(df, "close"), lo, hi, 1)
+        return {"buy_signal": buy, "sell_signal": sell}
+
+    def reversion(self, df, price_col="close", period=20, threshold=2.0):
+        """mean reversion on the z-score (price - SMA) / population std (the BBANDS arithmetic): buy when z comes back up
+        through -threshold, sell when it comes back down through +threshold (rule `band`)"""
+        x = _col(df, price_col)
+        up, mid, _lo = _api.call("bbands", x, timeperiod=period, nbdevup=1.0, nbdevdn=1.0)
+        p, u, m = (_api._to_device(t)[0] for t in (x, up, mid))
+        z = (p - m) / (u - m)                         # up - mid = 1.0 * sd
+        z = torch.where(u.view(torch.int64) == _NULL_I64, u, z)   # a null band row stays null: the rule is false there
+        buy, sell = _api.band_signals(z, -threshold, threshold)
+        return {"buy_signal": buy, "sell_signal": sell}
+
+    def volume(self, df, period=20, multiplier=2.0):
+        """volume breakout: volume above multiplier x SMA(volume, period) on an up day buys, on a down day sells"""
+        v, c = _api._to_device(_col(df, "volume"))[0], _api._to_device(_col(df, "close"))[0]
+        (sv,) = _api.call("sma", _col(df, "volume"), timeperiod=period)
+        surge = (v > multiplier * _api._to_device(sv)[0])
+        up, dn = torch.zeros_like(surge), torch.zeros_like(surge)
+        up[:, 1:] = c[:, 1:] > c[:, :-1]
+        dn[:, 1:] = c[:, 1:] < c[:, :-1]
+        return {"buy_signal": (surge & up).to(torch.uint8), "sell_signal": (surge & dn).to(torch.uint8)}
+
+    def grid(self, df, price_col="close", base_period=20, grid_pct=5.0):
+        """one grid level around a moving base line: buy when the price drops through SMA x (1 - grid_pct %), sell when it rises
+        through SMA x (1 + grid_pct %) (rule `channel`, mode 0)"""
+        x = _col(df, price_col)
+        (base,) = _api.call("sma", x, timeperiod=base_period)
+        b = _api._to_device(base)[0]
+        isn = b.view(torch.int64) == _NULL_I64
+        lo = torch.where(isn, b, b * (1.0 - grid_pct / 100.0))
+        hi = torch.where(isn, b, b * (1.0 + grid_pct / 100.0))
+        buy, sell = _api.channel_signals(x, lo, hi, 0)
+        return {"buy_signal": buy, "sell_signal": sell}
+
+    def gap(self, df, gap_pct=2.0):
+        """opening gaps: an open above the previous high by gap_pct % buys, below the previous low by gap_pct % sells"""
+        o, h, l = (_api._to_device(_col(df, k))[0] for k in ("open", "high", "low"))
+        buy, sell = torch.zeros(o.shape, dtype=torch.uint8, device=o.device), torch.zeros(o.shape, dtype=torch.uint8, device=o.device)
+        buy[:, 1:] = (o[:, 1:] > h[:, :-1] * (1.0 + gap_pct / 100.0)).to(torch.uint8)
+        sell[:, 1:] = (o[:, 1:] < l[:, :-1] * (1.0 - gap_pct / 100.0)).to(torch.uint8)
+        return {"buy_signal": buy, "sell_signal": sell}
+
+    def pattern(self, df, bullish=("cdlhammer", "cdlengulfing", "cdlmorningstar", "cdlpiercing", "cdl3whitesoldiers"),
+                bearish=("cdlhangingman", "cdlengulfing", "cdleveningstar", "cdldarkcloudcover", "cdl3blackcrows")):
+        """candlestick patterns (one fused pass over OHLC): any of `bullish` at +100 buys, any of `bearish` at -100 sells"""
+        names = sorted(set(bullish) | set(bearish))
+        pats = _api.cdl_all(_col(df, "open"), _col(df, "high"), _col(df, "low"), _col(df, "close"), names=names)
+        any_ = lambda ns, v: torch.stack([(_api._to_device(pats[n], torch.int32)[0] == v) for n in ns]).any(dim=0).to(torch.uint8)
+        return {"buy_signal": any_(bullish, 100), "sell_signal": any_(bearish, -100)}
+
+    def trend(self, df, price_col="close", periods=(5, 10, 20, 60), ma_type="sma"):
+        """multi-MA alignment: buy on the first bar where MA(p1) > MA(p2) > ... holds, sell on the first bar of the reverse order"""
+        x = _col(df, price_col)
+        mas = [_api._to_device(_api.call(_MA[ma_type], x, timeperiod=p)[0])[0] for p in periods]
+        bull = torch.stack([a > b for a, b in zip(mas, mas[1:])]).all(dim=0)     # nulls (NaN) compare False
+        bear = torch.stack([a < b for a, b in zip(mas, mas[1:])]).all(dim=0)
+        first = lambda m: torch.cat([torch.zeros_like(m[:, :1]), m[:, 1:] & ~m[:, :-1]], dim=1).to(torch.uint8)
+        return {"buy_signal": first(bull), "sell_signal": first(bear)}
+
+
+_NULL_I64 = 0x7FF80000504E554C

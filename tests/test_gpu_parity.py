@@ -793,3 +793,101 @@ def test_rank_ic_discrete_factor_long_tie_runs(pq, oracle):
     assert (nv.cpu().numpy() == env).all()
     assert ((bits(g) == bits(eic)) | (np.isnan(g) & np.isnan(eic))).all(), (g, eic)
     assert bits(g)[0] == np.uint64(oracle.NULL_BITS) and np.isfinite(g[1:]).all()
+
+
+def test_remaining_readme_strategies(pq, oracle, rich):
+    """The README names without documented parameters (README.md:946-953; decision D-11b): each strategy against the same
+    composition built on the host from the ORACLE's indicator columns and signal rules (numpy for the element-wise glue)."""
+    from polars_quant_amd import api
+    d = rich
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    df = {k: dev(v) for k, v in d.items()}
+    st = pq.Strategy()
+    NULLB = np.uint64(oracle.NULL_BITS)
+    isn = lambda a: bits(a) == NULLB
+    chk = lambda sig, eb, es, nm: (np.testing.assert_array_equal(sig["buy_signal"].cpu().numpy().astype(bool), eb.astype(bool), err_msg=nm + ".buy"),
+                                   np.testing.assert_array_equal(sig["sell_signal"].cpu().numpy().astype(bool), es.astype(bool), err_msg=nm + ".sell"))
+    h, l, c, o, v = d["high"], d["low"], d["close"], d["open"], d["volume"]
+    with np.errstate(invalid="ignore"):
+        # adx
+        (pdm,), (mdm,), (adx,) = oracle.call("plus_dm", h, l, timeperiod=7), oracle.call("minus_dm", h, l, timeperiod=7), oracle.call("adx", h, l, c, timeperiod=7)
+        eb, es = oracle.cross_signals(pdm, mdm)
+        strong = np.where(isn(adx), False, adx > 20.0)
+        chk(st.adx(df, period=7, threshold=20.0), eb & strong, es & strong, "adx")
+        assert (eb & strong).sum() > 0
+        # breakout (rolling extrema kernels + rule channel mode 1)
+        (hi,), (lo,) = oracle.call("rolling_max", h, window=10), oracle.call("rolling_min", l, window=10)
+        (ghi,) = api.call("rolling_max", df["high"], window=10)
+        assert (bits(ghi.cpu().numpy()) == bits(hi)).all()
+        eb, es = oracle.channel_signals(c, lo, hi, 1)
+        chk(st.breakout(df, period=10), eb, es, "breakout")
+        assert eb.sum() > 0 and es.sum() > 0
+        # reversion: z = (x - mid) / (up - mid) with nbdev 1
+        up, mid, _ = oracle.call("bbands", c, timeperiod=10, nbdevup=1.0, nbdevdn=1.0)
+        z = (c - mid) / (up - mid)
+        z[isn(up)] = oracle.NULL
+        eb, es = oracle.band_signals(z, -1.5, 1.5)
+        chk(st.reversion(df, period=10, threshold=1.5), eb, es, "reversion")
+        assert eb.sum() > 0
+        # volume
+        (sv,) = oracle.call("sma", v, timeperiod=10)
+        surge = np.where(isn(sv), False, v > 1.2 * sv)
+        upd = np.zeros_like(surge); dnd = np.zeros_like(surge)
+        upd[:, 1:] = c[:, 1:] > c[:, :-1]; dnd[:, 1:] = c[:, 1:] < c[:, :-1]
+        chk(st.volume(df, period=10, multiplier=1.2), surge & upd, surge & dnd, "volume")
+        assert (surge & upd).sum() > 0
+        # grid
+        (base,) = oracle.call("sma", c, timeperiod=10)
+        glo, ghi_ = np.where(isn(base), base, base * (1.0 - 0.02)), np.where(isn(base), base, base * (1.0 + 0.02))
+        glo[isn(base)] = oracle.NULL; ghi_[isn(base)] = oracle.NULL
+        eb, es = oracle.channel_signals(c, glo, ghi_, 0)
+        chk(st.grid(df, base_period=10, grid_pct=2.0), eb, es, "grid")
+        assert eb.sum() > 0
+        # gap
+        eb = np.zeros(c.shape, bool); es = np.zeros(c.shape, bool)
+        eb[:, 1:] = o[:, 1:] > h[:, :-1] * (1.0 + 0.5 / 100.0); es[:, 1:] = o[:, 1:] < l[:, :-1] * (1.0 - 0.5 / 100.0)
+        chk(st.gap(df, gap_pct=0.5), eb, es, "gap")
+        # pattern
+        bull, bear = ("cdlhammer", "cdlengulfing", "cdlpiercing"), ("cdlhangingman", "cdlengulfing", "cdldarkcloudcover")
+        eb = np.any([oracle.pattern(n, o, h, l, c) == 100 for n in bull], axis=0)
+        es = np.any([oracle.pattern(n, o, h, l, c) == -100 for n in bear], axis=0)
+        chk(st.pattern(df, bullish=bull, bearish=bear), eb, es, "pattern")
+        assert eb.sum() > 0 and es.sum() > 0
+        # trend
+        mas = [oracle.call("sma", c, timeperiod=p)[0] for p in (3, 6, 12)]
+        ok = ~np.any([isn(m) for m in mas], axis=0)
+        bullm = ok & (mas[0] > mas[1]) & (mas[1] > mas[2]); bearm = ok & (mas[0] < mas[1]) & (mas[1] < mas[2])
+        first = lambda m: np.concatenate([np.zeros_like(m[:, :1]), m[:, 1:] & ~m[:, :-1]], axis=1)
+        chk(st.trend(df, periods=(3, 6, 12)), first(bullm), first(bearm), "trend")
+        assert first(bullm).sum() > 0
+        # ma with the README's slope / distance filters
+        (f,), (s_,) = oracle.call("ema", c, timeperiod=4), oracle.call("ema", c, timeperiod=9)
+        eb, es = oracle.cross_signals(f, s_)
+        rising = np.zeros(c.shape, bool); rising[:, 1:] = np.where(isn(s_[:, 1:]) | isn(s_[:, :-1]), False, s_[:, 1:] > s_[:, :-1])
+        far = np.where(isn(s_), False, (c - s_) > np.abs(s_) * 0.001)
+        chk(st.ma(df, fast_period=4, slow_period=9, ma_type="ema", slope_filter=True, distance_pct=0.1), eb & rising & far, es, "ma+filters")
+
+
+def test_backtest_get_stock_performance(pq, oracle):
+    """README.md:554-589: per-symbol daily performance table of the `Backtest` class"""
+    d = oracle.gen_ohlcv(0x5EED000C, 3, 160, 0)
+    close = d["close"]
+    ebuy, esell = oracle.macd_cross_signals(close)
+    dates = [f"d{t:03d}" for t in range(close.shape[1])]
+    syms = ["AAA", "BBB", "CCC"]
+    wide = lambda a: {"date": dates, **{s: a[i] for i, s in enumerate(syms)}}
+    bench = d["open"][0]
+    bt = pq.Backtest(wide(close), wide(ebuy), wide(esell), leverage=2.0, benchmark={"date": dates, "IDX": bench})
+    bt.run()
+    perf = bt.get_stock_performance("BBB")
+    assert list(perf) == ["symbol", "date", "stock_value", "daily_pnl", "daily_return_pct", "cumulative_pnl", "cumulative_return_pct",
+                          "benchmark_return_pct", "alpha_pct", "relative_return_pct"]
+    e = oracle.backtest_leveraged(close, ebuy, esell, benchmark=bench, leverage=2.0)
+    em = oracle.portfolio_metrics(e["total_value"][1:2], 100000.0, bench)
+    assert (bits(np.asarray(perf["stock_value"])) == bits(em[:, 0])).all()
+    assert (bits(np.asarray(perf["cumulative_return_pct"])) == bits(em[:, 4])).all()
+    assert (bits(np.asarray(perf["alpha_pct"])) == bits(em[:, 6])).all()
+    assert set(bt.get_stock_daily("AAA")) == {"symbol", "date", "cash", "stock_value", "total_value"}
+    bt2 = pq.Backtest(wide(close), wide(ebuy), wide(esell))
+    bt2.run()
+    assert "alpha_pct" not in bt2.get_stock_performance("AAA")
