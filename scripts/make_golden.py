@@ -21,10 +21,10 @@ ALT = {"timeperiod": 7, "timeperiod1": 3, "timeperiod2": 6, "timeperiod3": 11, "
        "fastk_period": 8, "slowk_period": 4, "slowd_period": 5, "fastd_period": 4, "minperiod": 3, "maxperiod": 17,
        "nbdevup": 1.5, "nbdevdn": 2.5, "vfactor": 0.4, "acceleration": 0.02, "maximum": 0.2, "fastlimit": 0.5, "slowlimit": 0.05,
        "startvalue": 0.0, "offsetonreverse": 0.01, "accelerationinitlong": 0.02, "accelerationlong": 0.02, "accelerationmaxlong": 0.2,
-       "accelerationinitshort": 0.03, "accelerationshort": 0.03, "accelerationmaxshort": 0.3, "period": 5, "method": 1}
+       "accelerationinitshort": 0.03, "accelerationshort": 0.03, "accelerationmaxshort": 0.3, "period": 5, "method": 1, "window": 7}
 NULL_TOLERANT = {"bbands", "dema", "ema", "kama", "ma", "mama", "mavp", "midpoint", "midprice", "sar", "sarext", "sma", "t3", "tema",
                  "trima", "wma", "apo", "ppo", "macdext", "stoch", "stochf", "atr", "natr", "trange", "ad", "adosc", "obv",
-                 "avgprice", "medprice", "typprice", "wclprice", "returns"}
+                 "avgprice", "medprice", "typprice", "wclprice", "returns", "rolling_max", "rolling_min"}
 
 
 def datasets():
