@@ -358,6 +358,8 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         bool side[NCHAIN] = {};
         for (int c = 0; c < NCLS; c++) side[c] |= njobs(c) > 0;
         side[ROW_CHAIN] |= !p.rows.empty();
+        for (size_t k = 0; k < p.rows.size(); k++)
+            if (p.row_late[k]) side[p.row_late[k] - 1] = true; // a chain with late ROW launches runs even without SEQ jobs of its own
         bool any_side = false;
         for (int i = 1; i < NCHAIN; i++) any_side |= side[i];
         if (p.d_dbg && atoi(getenv("PQ_SUITE_DEBUG")) >= 2 && !p.d_wg) {
