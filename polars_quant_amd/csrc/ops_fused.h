@@ -461,16 +461,24 @@ struct HtAllOp {
         for (int k = 1; k < 6; k++) y[k] = pq_null();
         if (!FAST && (core.dead || i < 31)) return;
         const double i1 = core.i1[0], q1 = core.q1[0];
-        double ph = (i1 != 0.0) ? atan(q1 / i1) * 180.0 / PQ_PI : 0.0; // cycle.rs:130-134 == :294-298
+        const double tq = q1 / i1;                                          // the quotient both the phase and the sine take
+        double ph = (i1 != 0.0) ? atan(tq) * PQ_RAD2DEG : 0.0;           // cycle.rs:130-134 == :294-298
         double dc_phase = ph + 90.0;
         if (i1 < 0.0) dc_phase += 180.0;
         if (dc_phase > 315.0) dc_phase -= 360.0;
         y[1] = dc_phase;
         y[2] = i1; y[3] = q1;
-        // one sincos instead of two sin calls: sin(x + pi/4) = (sin x + cos x) / sqrt(2), within the 1e-12 budget of these
-        // outputs (absolute error ~1e-16; the single-output pq_ht_sine keeps the reference's two calls)
-        double sn, cs;
-        sincos(ph * PQ_PI / 180.0, &sn, &cs);
+        // sine / leadsine (cycle.rs:294-300) without a device sin: with phi = atan(t), sin(phi) = t / sqrt(1 + t^2) and
+        // cos(phi) = 1 / sqrt(1 + t^2) (phi in (-pi/2, pi/2): cos >= 0), and sin(phi + pi/4) = (sin + cos) / sqrt(2).  The
+        // reference takes sin() of phi after a degrees round trip (two roundings, ~2e-16 relative on the argument); this form is
+        // within a few ulp of the exact value: far inside the 1e-12 budget of these outputs (the single-output pq_ht_sine keeps
+        // the reference's two sin calls).  A sqrt + a division replace the ~100-instruction sincos on the step's longest job.
+        double sn = 0.0, cs = 1.0;
+        if (i1 != 0.0) {
+            const double r = 1.0 / sqrt(1.0 + tq * tq);
+            sn = tq * r; cs = r;
+            if (fabs(tq) >= 1e150) { sn = copysign(1.0, tq); cs = 0.0; }     // t^2 overflows: phi = +-pi/2 (false for a NaN t)
+        }
         y[4] = sn;
         y[5] = (sn + cs) * 0.70710678118654752440;
     }

@@ -134,6 +134,9 @@ struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
 //   0 ht_dcperiod  1 ht_dcphase  2 ht_phasor(2)  3 ht_sine(2)  4 mama(2, decision D-4)
 #define PQ_PI 3.14159265358979323846
 #define PQ_TAU 6.28318530717958647692
+// degrees per radian as ONE constant: `x * 180.0 / PI` costs a multiplication and a true division per row (no fast-math);
+// the outputs that pass through it are transcendental-class (1e-12), one more rounding of ~1e-16 is immaterial
+#define PQ_RAD2DEG (180.0 / PQ_PI)
 template <int MODE>
 struct HtOp {
     static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
@@ -203,7 +206,7 @@ struct HtOp {
             if (FAST || i >= 31) y[0] = smooth_period;
         } else if (MODE == 1) {
             if (FAST || i >= 31) {
-                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
+                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * PQ_RAD2DEG : 0.0;
                 dc_phase += 90.0;
                 if (i1[0] < 0.0) dc_phase += 180.0;
                 if (dc_phase > 315.0) dc_phase -= 360.0;
@@ -213,12 +216,12 @@ struct HtOp {
             if (FAST || i >= 31) { y[0] = i1[0]; y[NOUT - 1] = q1[0]; }
         } else if (MODE == 3) {
             if (FAST || i >= 31) {
-                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
+                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * PQ_RAD2DEG : 0.0;
                 y[0] = sin(dc_phase * PQ_PI / 180.0);
                 y[NOUT - 1] = sin((dc_phase + 45.0) * PQ_PI / 180.0);
             }
         } else {
-            double phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * 180.0 / PQ_PI : 0.0;
+            double phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * PQ_RAD2DEG : 0.0;
             double dphase = prev_phase - phase;
             if (dphase < 1.0) dphase = 1.0;
             double alpha = fastlimit / dphase;
