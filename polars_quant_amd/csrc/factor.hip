@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void rank_prep_kernel(const double *x, const d
         const double a = tx[lx][r], b = ty[lx][r];
         if (in) {
             kx[t * d.n + s] = a; ky[t * d.n + s] = b;
-            ids[t * d.n + s] = (unsigned)s;
+            if (ids) ids[t * d.n + s] = (unsigned)s;
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(in && a != inf);
         if (lx == 0 && t < d.len) { // a wave holds two of the tile's days: lanes 0-31 one, lanes 32-63 the other
@@ -158,6 +158,171 @@ __global__ __launch_bounds__(256) void rank_corr_kernel(const double *ks, const 
         ic[t] = out;
     }
 }
+// ---- Rank IC, n_series <= RANK_LDS_MAX: one workgroup per day, the day's keys sorted in LDS ------------------------------------
+// Keys only, no payload: a bitonic network over P = 2^p >= n keys (invalid pairs and the padding are +inf and end up last), every
+// thread holding 16 keys in registers so that up to four compare-exchange stages cost one LDS round trip (29 round trips instead of
+// 105 stages at P = 16384).  Every merge is written in its all-ascending form -- the first stage of the merge of size k pairs key i
+// with its mirror i ^ (k-1), the later stages are plain half-cleaners -- so a compare-exchange is one v_min_f64 + one v_max_f64 with
+// static register pairs and no direction selects.  A symbol's rank is then two binary searches of its own key in the sorted row --
+// [lb, ub) is its tie run, 2 x rank = lb + ub + 1 -- so nothing is scattered and the rank sums are integer sums (exact; converted
+// once).  The closed form is the oracle's.
+constexpr int RANK_LDS_MAX = 16384;
+#ifndef RK_NB
+#define RK_NB 8
+#endif
+__device__ __forceinline__ int rk_phys(int i) { return i + (i >> 4); } // one pad slot per 16 keys: stride-16 rows hit distinct banks
+__device__ __forceinline__ void rk_cmpex(double &a, double &b) {       // a <= b afterwards (keys are never NaN)
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    a = lo; b = hi;
+}
+template <int B> __device__ __forceinline__ void rk_half_clean(double (&r)[16]) { // register bit B
+#pragma unroll
+    for (int m = 0; m < 16; m++)
+        if (!(m & (1 << B))) rk_cmpex(r[m], r[m | (1 << B)]);
+}
+template <int W> __device__ __forceinline__ void rk_mirror(double (&r)[16]) {     // first stage of a merge of W registers
+#pragma unroll
+    for (int m = 0; m < 16; m++)
+        if (!(m & (W >> 1))) rk_cmpex(r[m], r[m ^ (W - 1)]);
+}
+// NST stages of one merge on the 16 keys {base | m << SH} (register bits 3 .. 4-NST).  TOP: the group opens the merge, so register
+// bit 3 is the mirror stage -- the upper eight registers then hold the keys whose bits below SH are the complement of the task's.
+template <int SH, int NST, bool TOP> __device__ __forceinline__ void rk_group(double *S, int task) {
+    const int base = (task & ((1 << SH) - 1)) | ((task >> SH) << (SH + 4));
+    const int base_hi = TOP ? base ^ ((1 << SH) - 1) : base;
+    double r[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) r[m] = S[rk_phys((m < 8 ? base : base_hi) | (m << SH))];
+    if (TOP) rk_mirror<16>(r); else rk_half_clean<3>(r);
+    if (NST >= 2) rk_half_clean<2>(r);
+    if (NST >= 3) rk_half_clean<1>(r);
+    if (NST >= 4) rk_half_clean<0>(r);
+#pragma unroll
+    for (int m = 0; m < 16; m++) S[rk_phys((m < 8 ? base : base_hi) | (m << SH))] = r[m];
+}
+// sorts S[0 .. P) ascending (P = 1 << p >= 16, P / 16 tasks spread over the workgroup); ends with a barrier
+__device__ __forceinline__ void rk_sort(double *S, int p, int tid, int nthr) {
+    const int ntask = 1 << (p - 4);
+    for (int task = tid; task < ntask; task += nthr) { // merges of size 2, 4, 8, 16 in registers
+        double r[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) r[m] = S[rk_phys(task * 16 + m)];
+        rk_half_clean<0>(r);
+        rk_mirror<4>(r); rk_half_clean<0>(r);
+        rk_mirror<8>(r); rk_half_clean<1>(r); rk_half_clean<0>(r);
+        rk_mirror<16>(r); rk_half_clean<2>(r); rk_half_clean<1>(r); rk_half_clean<0>(r);
+#pragma unroll
+        for (int m = 0; m < 16; m++) S[rk_phys(task * 16 + m)] = r[m];
+    }
+    __syncthreads();
+    for (int q = 5; q <= p; q++) {   // merge size 2^q: stage bits q-1 .. 0, four per LDS round trip, the remainder first
+#define RK_RUN(SH, NST, TOP) { for (int task = tid; task < ntask; task += nthr) rk_group<SH, NST, TOP>(S, task); __syncthreads(); }
+        switch (q) {
+        case 5: RK_RUN(1, 1, true) break;
+        case 6: RK_RUN(2, 2, true) break;
+        case 7: RK_RUN(3, 3, true) break;
+        case 8: RK_RUN(4, 4, true) break;
+        case 9: RK_RUN(5, 1, true) RK_RUN(4, 4, false) break;
+        case 10: RK_RUN(6, 2, true) RK_RUN(4, 4, false) break;
+        case 11: RK_RUN(7, 3, true) RK_RUN(4, 4, false) break;
+        case 12: RK_RUN(8, 4, true) RK_RUN(4, 4, false) break;
+        case 13: RK_RUN(9, 1, true) RK_RUN(8, 4, false) RK_RUN(4, 4, false) break;
+        default: RK_RUN(10, 2, true) RK_RUN(8, 4, false) RK_RUN(4, 4, false) break;
+        }
+        if (q >= 5) RK_RUN(0, 4, false)
+#undef RK_RUN
+    }
+}
+// 2 x the average rank of each of NB keys in the sorted row (0 for an invalid key): NB independent binary searches in step, so that
+// their LDS latencies overlap; the second search (the end of the tie run) only runs where a key has an equal right neighbour.
+template <int NB> __device__ __forceinline__ void rk_rank2(const double *S, int P, const double (&key)[NB], int (&r2)[NB]) {
+    const double inf = __longlong_as_double(0x7FF0000000000000LL);
+    int lb[NB], ub[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) lb[j] = 0;
+    for (int step = P >> 1; step > 0; step >>= 1)
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+            if (S[rk_phys(lb[j] + step - 1)] < key[j]) lb[j] += step;
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        ub[j] = lb[j] + 1;
+        tie |= key[j] != inf && ub[j] < P && S[rk_phys(ub[j])] == key[j];
+    }
+    if (tie) { // ub = the number of keys <= key
+#pragma unroll
+        for (int j = 0; j < NB; j++) ub[j] = 0;
+        for (int step = P >> 1; step > 0; step >>= 1)
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+                if (S[rk_phys(ub[j] + step - 1)] <= key[j]) ub[j] += step;
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+            if (ub[j] == P - 1 && S[rk_phys(P - 1)] <= key[j]) ub[j] = P;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) r2[j] = key[j] != inf ? lb[j] + ub[j] + 1 : 0;
+}
+__global__ __launch_bounds__(1024) void rank_ic_lds_kernel(const double *kx, const double *ky, const int32_t *n_valid, int64_t n, int p,
+                                                           double *ic) {
+    extern __shared__ __align__(16) unsigned char rank_lds[];
+    double *S = (double *)rank_lds;
+    const int64_t base = (int64_t)blockIdx.x * n;
+    const int P = 1 << p, tid = threadIdx.x, nthr = blockDim.x;
+    const double inf = __longlong_as_double(0x7FF0000000000000LL);
+    int rx2[16];
+    unsigned long long sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int side = 0; side < 2; side++) {
+        const double *row = (side ? ky : kx) + base;
+        for (int i = tid; i < P; i += nthr) S[rk_phys(i)] = i < n ? row[i] : inf;
+        __syncthreads();
+        rk_sort(S, p, tid, nthr);
+#pragma unroll
+        for (int m0 = 0; m0 < 16; m0 += RK_NB) {
+            double key[RK_NB];
+            int r2[RK_NB];
+#pragma unroll
+            for (int j = 0; j < RK_NB; j++) {
+                const int i = tid + (m0 + j) * nthr;
+                key[j] = i < n ? row[i] : inf;
+            }
+            rk_rank2<RK_NB>(S, P, key, r2);
+#pragma unroll
+            for (int j = 0; j < RK_NB; j++) {
+                if (side == 0) rx2[m0 + j] = r2[j];
+                else {
+                    const unsigned long long a = (unsigned)rx2[m0 + j], c = (unsigned)r2[j];
+                    sx += a; sy += c; sxx += a * a; syy += c * c; sxy += a * c;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    unsigned long long v[5] = {sx, sy, sxx, syy, sxy};
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    unsigned long long *red = (unsigned long long *)rank_lds; // the key row is dead
+    if ((tid & 63) == 0)
+        for (int k = 0; k < 5; k++) red[(tid >> 6) * 5 + k] = v[k];
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (nthr >> 6); w++)
+            for (int k = 0; k < 5; k++) v[k] += red[w * 5 + k];
+        const int nv = n_valid[blockIdx.x];
+        double out = pq_null();
+        if (nv >= 2) { // ranks are half-integers: the sums below are exact, as are the oracle's
+            const double nn = (double)nv, Sx = (double)v[0] / 2.0, Sy = (double)v[1] / 2.0, Sxx = (double)v[2] / 4.0, Syy = (double)v[3] / 4.0,
+                         Sxy = (double)v[4] / 4.0;
+            const double vx = nn * Sxx - Sx * Sx, vy = nn * Syy - Sy * Sy;
+            if (vx > 0.0 && vy > 0.0) out = (nn * Sxy - Sx * Sy) / (sqrt(vx) * sqrt(vy));
+        }
+        ic[blockIdx.x] = out;
+    }
+}
 __global__ __launch_bounds__(256) void iota_offsets_kernel(unsigned *off, int64_t segs, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i <= segs) off[i] = (unsigned)(i * n);
@@ -208,13 +373,34 @@ pq_status pq_factor_ic(pq_ctx *ctx, const pq_batch *b, const double *factor, con
     }
     PQ_REQUIRE(b->n_series <= 100000, "pq_factor_ic: rank IC supports at most 100000 series (exact rank sums)");
     const size_t cells = (size_t)d.len * (size_t)d.n;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    if (d.n <= RANK_LDS_MAX) { // workspace: kx, ky (f64, day-major) | counts (i32)
+        const size_t o_ky = al(cells * 8), o_cnt = o_ky + al(cells * 8), total = o_cnt + al((size_t)d.len * 4);
+        PQ_TRY(pq_ws_reserve(ctx, total));
+        unsigned char *w = (unsigned char *)ctx->ws;
+        double *kx = (double *)w, *ky = (double *)(w + o_ky);
+        int32_t *cnt = (int32_t *)(w + o_cnt);
+        int p = 4;
+        while ((1 << p) < d.n) p++;
+        const int P = 1 << p, nthr = P / 16 > 64 ? P / 16 : 64;
+        const size_t lds = (size_t)(P + P / 16) * 8 > 1024 ? (size_t)(P + P / 16) * 8 : 1024;
+        PQ_HIP_TRY(hipFuncSetAttribute((const void *)rank_ic_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PQ_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)d.len * 4, ctx->stream));
+        hipLaunchKernelGGL(rank_prep_kernel, dim3((unsigned)((d.len + 31) / 32), (unsigned)((d.n + 31) / 32)), dim3(256), 0, ctx->stream, factor,
+                           fwd_return, d, kx, ky, (unsigned *)nullptr, cnt);
+        hipLaunchKernelGGL(rank_ic_lds_kernel, dim3((unsigned)d.len), dim3(nthr), lds, ctx->stream, (const double *)kx, (const double *)ky,
+                           (const int32_t *)cnt, d.n, p, ic);
+        if (n_valid) PQ_HIP_TRY(hipMemcpyAsync(n_valid, cnt, (size_t)d.len * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        PQ_HIP_TRY(hipGetLastError());
+        return PQ_OK;
+    }
+    // wider cross-sections: segmented radix sort of (key, symbol id) pairs
     PQ_REQUIRE(cells < (1ull << 32), "pq_factor_ic: rank IC needs n_series * len < 2^32");
     // workspace: kx, ky, sx, sy (f64) | ry (f64) | ids, ix, iy (u32) | offsets (u32) | counts (i32) | rocPRIM temp
     size_t tmp_bytes = 0;
     PQ_HIP_TRY(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, (double *)nullptr, (double *)nullptr, (unsigned *)nullptr,
                                                    (unsigned *)nullptr, (unsigned)cells, (unsigned)d.len, (unsigned *)nullptr,
                                                    (unsigned *)nullptr, 0, 64, ctx->stream));
-    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t o_kx = 0, o_ky = o_kx + al(cells * 8), o_sx = o_ky + al(cells * 8), o_sy = o_sx + al(cells * 8), o_ry = o_sy + al(cells * 8),
                  o_id = o_ry + al(cells * 8), o_ix = o_id + al(cells * 4), o_iy = o_ix + al(cells * 4), o_off = o_iy + al(cells * 4),
                  o_cnt = o_off + al((size_t)(d.len + 1) * 4), o_tmp = o_cnt + al((size_t)d.len * 4), total = o_tmp + al(tmp_bytes);

@@ -795,6 +795,29 @@ def test_rank_ic_discrete_factor_long_tie_runs(pq, oracle):
     assert bits(g)[0] == np.uint64(oracle.NULL_BITS) and np.isfinite(g[1:]).all()
 
 
+@pytest.mark.parametrize("N,T_", [(16, 9), (17, 9), (255, 7), (1024, 6), (1025, 6), (4097, 5), (10000, 4), (16384, 4), (16385, 3), (20000, 3)])
+def test_rank_ic_cross_section_sizes(pq, oracle, N, T_):
+    """Rank-IC on both sides of every size boundary of the per-day LDS sort (P = 16 .. 16384 keys, 64 .. 1024 threads) and beyond
+    it (N > 16384: the segmented-sort path).  Day 0: every key equal (one tie run of all N); day 1: two-valued factor; day 2: nulls."""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(1000 + N)
+    f = rng.normal(size=(N, T_))
+    r = 0.3 * f + rng.normal(size=(N, T_))
+    f[:, 0] = 1.25
+    f[:, 1] = (rng.random(N) < 0.5).astype(np.float64)
+    r[:, 1] = np.round(r[:, 1], 1)
+    f[rng.random(N) < 0.1, 2] = oracle.NULL
+    r[rng.random(N) < 0.1, 2] = np.nan
+    u = rng.random(N)
+    r[:, -1] = np.where(u < 0.3, 0.0, np.where(u < 0.6, -0.0, r[:, -1]))      # +0.0 and -0.0 are one tie run
+    eic, env = oracle.factor_ic(f, r, method=1)
+    ic, nv = api.factor_ic(torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda(), method=1)
+    g = ic.cpu().numpy()
+    assert (nv.cpu().numpy() == env).all()
+    assert ((bits(g) == bits(eic)) | (np.isnan(g) & np.isnan(eic))).all(), (N, g, eic)
+    assert np.isfinite(g[1:]).all()
+
+
 def test_remaining_readme_strategies(pq, oracle, rich):
     """The README names without documented parameters (README.md:946-953; decision D-11b): each strategy against the same
     composition built on the host from the ORACLE's indicator columns and signal rules (numpy for the element-wise glue)."""
