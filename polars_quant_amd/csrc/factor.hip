@@ -5,10 +5,11 @@
 //  * Pearson IC: the sums are order-sensitive, so the oracle's order IS the definition: blocks of 256 symbols, ascending
 //    inside a block, block sums added in ascending order.  One (day, block) per thread; consecutive threads read
 //    consecutive days -> coalesced; 16 loads per column in flight.
-//  * Rank IC: a tiled transpose builds day-major key rows (invalid pairs -> +inf), rocPRIM's segmented radix sort orders
-//    every day's row (keys + symbol ids), a per-day workgroup turns sorted positions into average ranks (ties share the
-//    mean rank) and accumulates the five rank sums.  Ranks are half-integers, so the sums are exact in f64 in ANY order
-//    (n_series <= 100 000) and the closed form below is bit-identical to the oracle.
+//  * Rank IC: a tiled transpose builds day-major key rows (invalid pairs -> +inf).  Up to 16 384 symbols one workgroup per day
+//    sorts the day's keys in LDS and ranks every symbol by binary search (rank_ic_lds_kernel below).  Wider cross-sections:
+//    rocPRIM's segmented radix sort orders every day's row (keys + symbol ids) and a per-day workgroup turns sorted positions
+//    into average ranks (ties share the mean rank).  Ranks are half-integers, so the five rank sums are exact in f64 in ANY
+//    order (n_series <= 100 000) and the closed form is bit-identical to the oracle.
 #include <cstring>
 #include "pq_dev.h"
 #include <rocprim/rocprim.hpp>
@@ -177,6 +178,8 @@ __device__ __forceinline__ void rk_cmpex(double &a, double &b) {       // a <= b
     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     a = lo; b = hi;
 }
+// orders this wave's LDS writes before its later LDS reads (one wave's DS operations execute in order)
+#define RK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <int B> __device__ __forceinline__ void rk_half_clean(double (&r)[16]) { // register bit B
 #pragma unroll
     for (int m = 0; m < 16; m++)
@@ -189,8 +192,9 @@ template <int W> __device__ __forceinline__ void rk_mirror(double (&r)[16]) {   
 }
 // NST stages of one merge on the 16 keys {base | m << SH} (register bits 3 .. 4-NST).  TOP: the group opens the merge, so register
 // bit 3 is the mirror stage -- the upper eight registers then hold the keys whose bits below SH are the complement of the task's.
-template <int SH, int NST, bool TOP> __device__ __forceinline__ void rk_group(double *S, int task) {
+template <int SH, int NST, bool TOP> __device__ __forceinline__ void rk_group(double *S, int task, int n) {
     const int base = (task & ((1 << SH) - 1)) | ((task >> SH) << (SH + 4));
+    if ((base | (1 << SH)) >= n) return; // at most one key below n: see rk_sort
     const int base_hi = TOP ? base ^ ((1 << SH) - 1) : base;
     double r[16];
 #pragma unroll
@@ -202,10 +206,13 @@ template <int SH, int NST, bool TOP> __device__ __forceinline__ void rk_group(do
 #pragma unroll
     for (int m = 0; m < 16; m++) S[rk_phys((m < 8 ? base : base_hi) | (m << SH))] = r[m];
 }
-// sorts S[0 .. P) ascending (P = 1 << p >= 16, P / 16 tasks spread over the workgroup); ends with a barrier
-__device__ __forceinline__ void rk_sort(double *S, int p, int tid, int nthr) {
+// sorts S[0 .. P) ascending (P = 1 << p >= 16, P / 16 tasks spread over the workgroup); ends with a barrier.  S[n .. P) is +inf
+// and stays +inf (every compare-exchange keeps the larger key at the larger index), so a compare-exchange that touches an index
+// >= n changes nothing and a task with fewer than two keys below n is skipped: the network costs ~n/P of the full one.
+__device__ __forceinline__ void rk_sort(double *S, int p, int n, int tid, int nthr) {
     const int ntask = 1 << (p - 4);
     for (int task = tid; task < ntask; task += nthr) { // merges of size 2, 4, 8, 16 in registers
+        if (task * 16 + 1 >= n) break;
         double r[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) r[m] = S[rk_phys(task * 16 + m)];
@@ -216,24 +223,32 @@ __device__ __forceinline__ void rk_sort(double *S, int p, int tid, int nthr) {
 #pragma unroll
         for (int m = 0; m < 16; m++) S[rk_phys(task * 16 + m)] = r[m];
     }
-    __syncthreads();
-    for (int q = 5; q <= p; q++) {   // merge size 2^q: stage bits q-1 .. 0, four per LDS round trip, the remainder first
-#define RK_RUN(SH, NST, TOP) { for (int task = tid; task < ntask; task += nthr) rk_group<SH, NST, TOP>(S, task); __syncthreads(); }
+    RK_WAVE_SYNC();
+    // Thread t of wave w owns task t, and every group with SH <= 6 only touches keys of the wave's own block of 1024 (bits 0..9):
+    // such groups are ordered by the wave's own in-order LDS queue, no workgroup barrier, and the waves drift apart so that one
+    // wave's LDS round trip overlaps another's min/max.  Only the stages on bits >= 10 (merges of 2048 keys and more) cross waves.
+#define RK_RUN(SH, NST, TOP) { for (int task = tid; task < ntask; task += nthr) rk_group<SH, NST, TOP>(S, task, n); }
+#define RK_LOCAL(SH, NST, TOP) { RK_RUN(SH, NST, TOP) RK_WAVE_SYNC(); }
+#define RK_CROSS(SH, NST) { __syncthreads(); RK_RUN(SH, NST, true) __syncthreads(); RK_LOCAL(6, 2, false) RK_LOCAL(4, 4, false) }
+    for (int q = 5; q <= p; q++) {   // merge size 2^q: stage bits q-1 .. 0, up to four per LDS round trip
         switch (q) {
-        case 5: RK_RUN(1, 1, true) break;
-        case 6: RK_RUN(2, 2, true) break;
-        case 7: RK_RUN(3, 3, true) break;
-        case 8: RK_RUN(4, 4, true) break;
-        case 9: RK_RUN(5, 1, true) RK_RUN(4, 4, false) break;
-        case 10: RK_RUN(6, 2, true) RK_RUN(4, 4, false) break;
-        case 11: RK_RUN(7, 3, true) RK_RUN(4, 4, false) break;
-        case 12: RK_RUN(8, 4, true) RK_RUN(4, 4, false) break;
-        case 13: RK_RUN(9, 1, true) RK_RUN(8, 4, false) RK_RUN(4, 4, false) break;
-        default: RK_RUN(10, 2, true) RK_RUN(8, 4, false) RK_RUN(4, 4, false) break;
+        case 5: RK_LOCAL(1, 1, true) break;
+        case 6: RK_LOCAL(2, 2, true) break;
+        case 7: RK_LOCAL(3, 3, true) break;
+        case 8: RK_LOCAL(4, 4, true) break;
+        case 9: RK_LOCAL(5, 1, true) RK_LOCAL(4, 4, false) break;
+        case 10: RK_LOCAL(6, 2, true) RK_LOCAL(4, 4, false) break;
+        case 11: RK_CROSS(7, 1) break;
+        case 12: RK_CROSS(8, 2) break;
+        case 13: RK_CROSS(9, 3) break;
+        default: RK_CROSS(10, 4) break;
         }
-        if (q >= 5) RK_RUN(0, 4, false)
-#undef RK_RUN
+        RK_LOCAL(0, 4, false)
     }
+#undef RK_RUN
+#undef RK_LOCAL
+#undef RK_CROSS
+    __syncthreads();
 }
 // 2 x the average rank of each of NB keys in the sorted row (0 for an invalid key): NB independent binary searches in step, so that
 // their LDS latencies overlap; the second search (the end of the tie run) only runs where a key has an equal right neighbour.
@@ -277,9 +292,10 @@ __global__ __launch_bounds__(1024) void rank_ic_lds_kernel(const double *kx, con
     unsigned long long sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
     for (int side = 0; side < 2; side++) {
         const double *row = (side ? ky : kx) + base;
-        for (int i = tid; i < P; i += nthr) S[rk_phys(i)] = i < n ? row[i] : inf;
-        __syncthreads();
-        rk_sort(S, p, tid, nthr);
+        for (int i0 = (tid >> 6) << 10; i0 < P; i0 += nthr << 4) // each wave fills the 1024-key blocks its tasks sort first
+            for (int i = i0 + (tid & 63); i < i0 + 1024 && i < P; i += 64) S[rk_phys(i)] = i < n ? row[i] : inf;
+        RK_WAVE_SYNC();
+        rk_sort(S, p, (int)n, tid, nthr);
 #pragma unroll
         for (int m0 = 0; m0 < 16; m0 += RK_NB) {
             double key[RK_NB];
