@@ -9,6 +9,7 @@ __device__ __forceinline__ double n0m(double x) { return pq_isnull(x) ? 0.0 : x;
 template <int KIND> // 0 avgprice(o,h,l,c) 1 medprice(h,l) 2 typprice(h,l,c) 3 wclprice(h,l,c)
 struct PriceOp {
     static constexpr int NIN = (KIND == 0 ? 4 : (KIND == 1 ? 2 : 3)), NOUT = 1;
+    static constexpr int ROW_ID = 1 + KIND;
     typedef double OutT;
     __device__ void eval(const Row<NIN> &r, int64_t t, double (&y)[1]) {
         double a[NIN];
@@ -29,6 +30,7 @@ __device__ __forceinline__ double true_range(double h, double l, double pc) { //
 }
 struct TrangeOp { // volatility.rs:67-84 (ROW; row 0 null because pre_close = close.shift(1))
     static constexpr int NIN = 3, NOUT = 1;
+    static constexpr int ROW_ID = 5;
     typedef double OutT;
     __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {
         y[0] = pq_null();
@@ -238,6 +240,7 @@ struct HtOp {
 // cycle.rs:310-374 / :377-448: pure functions of real[i-3..i] (the pipeline result is unused)
 struct TrendlineOp {
     static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int ROW_ID = 6;
     typedef double OutT;
     __device__ void eval(const Row<1> &r, int64_t i, double (&y)[1]) {
         y[0] = pq_null();
@@ -250,6 +253,7 @@ struct TrendlineOp {
 };
 struct TrendmodeOp {
     static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int ROW_ID = 7;
     typedef int32_t OutT;
     __device__ void eval(const Row<1> &r, int64_t i, int32_t (&y)[1]) {
         y[0] = PQ_NULL_I32;

@@ -12,6 +12,7 @@ __device__ __forceinline__ double z0(double x) { return pq_isnull(x) ? 0.0 : x; 
 template <int KIND> // 0 mom, 1 roc, 2 rocp, 3 rocr, 4 rocr100   (momentum.rs:384-397, :439-504)
 struct LagOp {
     static constexpr int NIN = 1, NOUT = 1;
+    static constexpr int ROW_ID = 8 + KIND;
     typedef double OutT;
     int64_t p;
     __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) {
@@ -63,6 +64,7 @@ struct RollingExtOp {
 };
 struct BopOp { // momentum.rs:113-135
     static constexpr int NIN = 4, NOUT = 1;
+    static constexpr int ROW_ID = 13;
     typedef double OutT;
     __device__ void eval(const Row<4> &r, int64_t t, double (&y)[1]) {
         double diff = r.in[1][t] - r.in[2][t];
@@ -72,6 +74,7 @@ struct BopOp { // momentum.rs:113-135
 template <int MODE> // 0: (up, down)  1: up - down (AROONOSC, decision D-6)  2: (up, down, up - down) in one scan   momentum.rs:70-110
 struct AroonOp {
     static constexpr int NIN = 2, NOUT = (MODE == 0 ? 2 : (MODE == 1 ? 1 : 3));
+    static constexpr int ROW_ID = 14 + MODE;
     typedef double OutT;
     int64_t p;
     __device__ void eval(const Row<2> &r, int64_t t, double (&y)[NOUT]) {
@@ -93,6 +96,7 @@ struct AroonOp {
 };
 struct WillrOp { // momentum.rs:630-662
     static constexpr int NIN = 3, NOUT = 1;
+    static constexpr int ROW_ID = 17;
     typedef double OutT;
     int64_t p;
     __device__ void eval(const Row<3> &r, int64_t t, double (&y)[1]) {

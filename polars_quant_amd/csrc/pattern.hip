@@ -323,6 +323,9 @@ static pq_status cdl_launch(pq_ctx *ctx, const pq_batch *b, const CdlArgs &args,
         static_assert(sizeof(CdlBlob) <= sizeof(RowThunk::blob), "CdlBlob too large");
         RowThunk t;
         t.launch = &cdl_launch_blob;
+        t.row_id = 0;
+        t.blob_bytes = (int)sizeof cb;
+        t.dims = dims_of(b);
         memcpy(t.blob, &cb, sizeof cb);
         t.n_reads = 4;
         t.reads[0] = args.o; t.reads[1] = args.h; t.reads[2] = args.l; t.reads[3] = args.c;

@@ -437,7 +437,11 @@ __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
     if (v.x == 1.2345e-300) *p = v.y;
 #else
     pq_d2v w = {v.x, v.y};
+#ifdef PQ_EXP_PLAIN_STORES
+    *reinterpret_cast<pq_d2v *>(p) = w;
+#else
     __builtin_nontemporal_store(w, reinterpret_cast<pq_d2v *>(p));
+#endif
 #endif
 }
 template <class Op>
@@ -700,6 +704,9 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
                       int nin, double *const *out, int nout, void *extra_write = nullptr);
 struct RowThunk { // type-erased ROW launch for replay
     void (*launch)(const void *blob, hipStream_t stream);
+    int row_id;     // Op::ROW_ID if the suite may run it inside its fused ROW grid (row_jobs_kernel), else 0
+    int blob_bytes; // sizeof(RowBlob<Op>)
+    Dims dims;      // of the batch the call was made on
     unsigned char blob[1200];
     const void *reads[8];
     int n_reads;
@@ -789,6 +796,8 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> i
     for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][s * d.stride + t]); // written once, not re-read
 #endif
 }
+template <class Op, class = void> struct RowId { static constexpr int value = 0; };
+template <class Op> struct RowId<Op, decltype((void)Op::ROW_ID)> { static constexpr int value = Op::ROW_ID; };
 template <class Op>
 struct RowBlob {
     Op op;
@@ -820,6 +829,9 @@ static inline pq_status launch_row(pq_ctx *ctx, const pq_batch *b, const Op &op,
         static_assert(sizeof(RowBlob<Op>) <= sizeof(RowThunk::blob), "ROW blob too large");
         RowThunk t;
         t.launch = &row_launch_blob<Op>;
+        t.row_id = RowId<Op>::value;
+        t.blob_bytes = (int)sizeof rb;
+        t.dims = dims_of(b);
         memcpy(t.blob, &rb, sizeof rb);
         t.n_reads = Op::NIN;
         for (int k = 0; k < Op::NIN; k++) t.reads[k] = in.p[k];

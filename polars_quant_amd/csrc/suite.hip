@@ -62,6 +62,9 @@ struct Phase {
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
     std::vector<char> row_late; // 0: on the ROW chain; 1 + c: behind the SEQ grid(s) of chain c
+    std::vector<char> row_fused; // the launch runs inside the fused ROW grid of its chain position
+    struct RowJobDev *d_rows[NCHAIN + 1] = {}; // fused ROW grid per position (index = row_late value)
+    int n_rows[NCHAIN + 1] = {};
     SeqJob *d_seq = nullptr;
     unsigned long long *d_dbg = nullptr; // PQ_SUITE_DEBUG: [job][first start, last end] device timestamps
     unsigned long long *d_wg = nullptr;  // PQ_SUITE_DEBUG=2: [job][tile][start, end, hw id] of every workgroup
@@ -252,6 +255,46 @@ void rec_set_shared_out(pq_ctx *ctx, bool on) {
     if (ctx->rec) ctx->rec->shared_out = on;
 }
 
+// ---- fused ROW grid ------------------------------------------------------------------------------------------------------------
+// The window-bounded ROW ops of a phase (price transforms, BOP, TRANGE, MOM / ROC x 4, AROON, WILLR, HT_TRENDLINE / TRENDMODE) read
+// the same few OHLC columns: as separate launches each streams its inputs from HBM again (32 column reads for 4 distinct columns)
+// and the chain of small launches cannot fill the slots the SEQ grids leave.  One grid instead: a block takes 256 rows of one series
+// through EVERY recorded ROW job, so the inputs come from HBM once and from L1/L2 afterwards.  Same eval(), same stores: identical
+// results.  Ops without a ROW_ID (the 61-pattern kernel, signal rules...) keep their own launches.
+constexpr int ROW_FUSE_BLOB = 176;
+struct RowJobDev { int kind; int pad; unsigned char blob[ROW_FUSE_BLOB]; };
+#define ROW_OPS(X)                                                                                                             \
+    X(PriceOp<0>) X(PriceOp<1>) X(PriceOp<2>) X(PriceOp<3>) X(TrangeOp) X(TrendlineOp) X(TrendmodeOp) X(LagOp<0>) X(LagOp<1>) \
+    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(AroonOp<2>) X(WillrOp)
+__global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJobDev *jobs, int n_jobs, Dims d, int64_t s_base) {
+    const int64_t s = s_base + blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
+    if (t >= d.len) return;
+    for (int j = 0; j < n_jobs; j++) {
+        const RowJobDev &job = jobs[j];
+        switch (job.kind) {
+#define X(OP)                                                                                                                  \
+    case OP::ROW_ID: {                                                                                                         \
+        static_assert(sizeof(RowBlob<OP>) <= ROW_FUSE_BLOB, "ROW blob too large for the fused grid");                           \
+        const RowBlob<OP> &rb = *reinterpret_cast<const RowBlob<OP> *>(job.blob);                                               \
+        OP op = rb.op;                                                                                                         \
+        Row<OP::NIN> r;                                                                                                        \
+        r.len = d.len;                                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < OP::NIN; k++) r.in[k] = rb.in.p[k] + s * d.stride;                              \
+        typename OP::OutT y[OP::NOUT];                                                                                         \
+        op.eval(r, t, y);                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < OP::NOUT; k++) __builtin_nontemporal_store(y[k], &rb.out.p[k][s * d.stride + t]); \
+    } break;
+            ROW_OPS(X)
+#undef X
+        default: break;
+        }
+    }
+}
+static bool row_fusable(const RowThunk &t, const Dims &d) {
+    return t.row_id > 0 && t.blob_bytes <= ROW_FUSE_BLOB && t.dims.n == d.n && t.dims.len == d.len && t.dims.stride == d.stride;
+}
+
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
     hipDeviceProp_t prop;
     PQ_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
@@ -273,13 +316,35 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return weight(p.rows[a]) > weight(p.rows[b]); });
             for (size_t k : idx) {
                 if (early < 0.5 * total) { early += weight(p.rows[k]); continue; }
-#ifndef PQ_ROW_LATE_CLS
-#define PQ_ROW_LATE_CLS CLS_SHORT
-#endif
-                p.row_late[k] = 1 + PQ_ROW_LATE_CLS;
+                p.row_late[k] = 1 + CLS_SHORT;
             }
         }
-        if (p.seq.empty()) continue;
+        // fusable launches of one chain position become one grid (at least two of them, or there is nothing to share)
+        auto fuse_rows = [&]() -> pq_status {
+            p.row_fused.assign(p.rows.size(), 0);
+#ifndef PQ_NO_ROW_FUSION // A/B builds: every ROW launch on its own
+            const Dims bd = dims_of(&r.b);
+            for (int pos = 0; pos <= NCHAIN; pos++) {
+                std::vector<RowJobDev> jobs;
+                for (size_t k = 0; k < p.rows.size(); k++)
+                    if (p.row_late[k] == pos && row_fusable(p.rows[k], bd)) {
+                        RowJobDev j;
+                        memset(&j, 0, sizeof j);
+                        j.kind = p.rows[k].row_id;
+                        memcpy(j.blob, p.rows[k].blob, (size_t)p.rows[k].blob_bytes);
+                        jobs.push_back(j);
+                    }
+                if (jobs.size() < 2) continue;
+                for (size_t k = 0; k < p.rows.size(); k++)
+                    if (p.row_late[k] == pos && row_fusable(p.rows[k], bd)) p.row_fused[k] = 1;
+                p.n_rows[pos] = (int)jobs.size();
+                PQ_HIP_TRY(hipMalloc((void **)&p.d_rows[pos], sizeof(RowJobDev) * jobs.size()));
+                PQ_HIP_TRY(hipMemcpy(p.d_rows[pos], jobs.data(), sizeof(RowJobDev) * jobs.size(), hipMemcpyHostToDevice));
+            }
+#endif
+            return PQ_OK;
+        };
+        if (p.seq.empty()) { PQ_TRY(fuse_rows()); continue; }
         // class of every job (see the comment at CLS_*): heavy / gather by trait, the light tiled jobs by cost and LDS need
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cost > b.cost; });
         double long_wgs = 0;
@@ -292,6 +357,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             else if (long_wgs + tiles <= long_budget) { j.cls = CLS_LONG; long_wgs += tiles; }
             else j.cls = CLS_SHORT;
         }
+        PQ_TRY(fuse_rows());
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cls < b.cls; }); // cost order kept
         const double rows = (double)r.b.n_series * (double)r.b.len;
         std::map<const void *, int> masked_seen[NCLS];
@@ -326,16 +392,16 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
 }
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
     Dims d = dims_of(&r.b);
-    if (!r.aux[1]) { // lazily create the side streams (they live as long as the suite)
+    if (!r.ev_fork) PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
+    auto side_stream = [&](int i) -> hipError_t { // side streams are created when a chain first has work (they live as long as the suite):
+        if (r.aux[i]) return hipSuccess;          // an unused stream would still take its turn in the runtime's queue assignment
         int prio_lo = 0, prio_hi = 0;
-        PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)); // numerically lower = higher priority
-        for (int i = 1; i < NCHAIN; i++) {
-            // (at low priority the short ROW kernels crawl behind the SEQ grids and end up as the critical path of the step)
-            PQ_HIP_TRY(hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, prio_hi));
-            PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming));
-        }
-        PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
-    }
+        hipError_t e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
+        if (e != hipSuccess) return e;
+        // (at low priority the short ROW kernels crawl behind the SEQ grids and end up as the critical path of the step)
+        if ((e = hipStreamCreateWithPriority(&r.aux[i], hipStreamNonBlocking, prio_hi)) != hipSuccess) return e;
+        return hipEventCreateWithFlags(&r.ev_join[i], hipEventDisableTiming);
+    };
     // workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8, series tile x runs on XCD x % 8 for
     // EVERY job, so jobs that read the same input column share that XCD's L2 for it
     const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK * 8 - 1) / (SEQ_BLOCK * 8)) * 8;
@@ -386,21 +452,32 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             PQ_HIP_TRY(timed(p.gs[c], st, false));
             return PQ_OK;
         };
+        auto launch_rows = [&](int pos, hipStream_t st) { // the fused ROW grid of a chain position
+            if (!p.n_rows[pos]) return;
+            for (int64_t sb = 0; sb < d.n; sb += 65535) { // grid.y is limited to 65535: slice the series axis
+                const int64_t ns = d.n - sb < 65535 ? d.n - sb : 65535;
+                hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((d.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0, st,
+                                   (const RowJobDev *)p.d_rows[pos], p.n_rows[pos], d, sb);
+            }
+        };
         pq_status ps;
         for (int oi = 0; oi < NCHAIN; oi++) { // enqueue order: the longest / hungriest chains first
             const int i = k_chain_order[oi];
             if (!side[i] && i != 0) continue;
+            if (i != 0) PQ_HIP_TRY(side_stream(i));
             hipStream_t st = i == 0 ? ctx->stream : r.aux[i];
             if (i != 0) PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0));
             if (i == ROW_CHAIN && !p.rows.empty()) {
                 PQ_HIP_TRY(timed(p.gs_row, st, true));
                 for (size_t k = 0; k < p.rows.size(); k++)
-                    if (!p.row_late[k]) p.rows[k].launch(p.rows[k].blob, st);
+                    if (!p.row_late[k] && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
+                launch_rows(0, st);
                 PQ_HIP_TRY(timed(p.gs_row, st, false));
             }
             if ((ps = launch_class(i, st)) != PQ_OK) return ps;
             for (size_t k = 0; k < p.rows.size(); k++) // the lighter ROW launches follow an early-draining SEQ grid (suite_finalize)
-                if (p.row_late[k] == 1 + i) p.rows[k].launch(p.rows[k].blob, st);
+                if (p.row_late[k] == 1 + i && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
+            launch_rows(1 + i, st);
             if (i != 0) PQ_HIP_TRY(hipEventRecord(r.ev_join[i], st));
         }
         for (int i = 1; i < NCHAIN; i++)
@@ -452,6 +529,8 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     for (Phase &p : r.phases) {
         if (p.d_seq) (void)hipFree(p.d_seq);
+        for (int pos = 0; pos <= NCHAIN; pos++)
+            if (p.d_rows[pos]) { (void)hipFree(p.d_rows[pos]); p.d_rows[pos] = nullptr; p.n_rows[pos] = 0; }
         if (p.d_dbg) (void)hipFree(p.d_dbg);
         if (p.d_wg) (void)hipFree(p.d_wg);
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }

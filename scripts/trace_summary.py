@@ -14,7 +14,7 @@ for r in rows:
         clusters.append(cur); cur = []
     cur.append(r); end = max(end, e)
 clusters.append(cur)
-steps = [c for c in clusters if sum("seq_jobs_kernel" in r["Kernel_Name"] for r in c) >= 2 and len(c) > 10]
+steps = [c for c in clusters if sum("seq_jobs_kernel" in r["Kernel_Name"] for r in c) >= 2 and len(c) >= 4]
 print(f"{len(rows)} kernel launches, {len(steps)} suite steps")
 c = steps[len(steps) // 2]
 t0 = int(c[0]["Start_Timestamp"])
