@@ -66,8 +66,9 @@ def cpu_baseline(sample_syms: int, T: int):
 
 def end_to_end(suite, ohlcv, n_local, T, dev):
     """The step from HOST buffers, through the C ABI's own copy entry points: the five OHLCV columns live in page-locked
-    (pq_host_register) host arrays as an Arrow buffer handed over by the caller would; H2D (pq_memcpy_h2d) -> step -> D2H of
-    the [n, 8] summary table.  Second figure: D2H of every output column as well (10.9 GB at full size)."""
+    (pq_host_register) DENSE host arrays as an Arrow buffer handed over by the caller would; H2D into the pitched device
+    columns (pq_memcpy_h2d_pitched) -> step -> D2H of the [n, 8] summary table.  Second figure: D2H of every output column as
+    well (10.9 GB at full size)."""
     import ctypes as C
     from polars_quant_amd._lib import check, lib
     from polars_quant_amd.api import ctx
@@ -83,12 +84,13 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
 
     def once(all_outputs):
         for k, a in host.items():
-            check(L.pq_memcpy_h2d(h, C.c_void_p(ohlcv[k].data_ptr()), a.ctypes.data_as(C.c_void_p), a.nbytes))
+            check(L.pq_memcpy_h2d_pitched(h, C.c_void_p(ohlcv[k].data_ptr()), suite.stride * 8, a.ctypes.data_as(C.c_void_p), T * 8, T * 8, n_local))
         suite.run(ohlcv)
         check(L.pq_memcpy_d2h(h, summ.ctypes.data_as(C.c_void_p), C.c_void_p(suite.summary.data_ptr()), summ.nbytes))
         if all_outputs:
             for t in outs:
-                check(L.pq_memcpy_d2h(h, big.ctypes.data_as(C.c_void_p), C.c_void_p(t.data_ptr()), t.numel() * t.element_size()))
+                es = t.element_size()
+                check(L.pq_memcpy_d2h_pitched(h, big.ctypes.data_as(C.c_void_p), T * es, C.c_void_p(t.data_ptr()), suite.stride * es, T * es, n_local))
         torch.cuda.synchronize()
 
     res = {}
@@ -116,7 +118,8 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="also time the step end to end from registered host buffers")
     ap.add_argument("--days", type=int, default=T_DAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stride", type=int, default=0, help="elements between series starts in HBM (0 = dense = days)")
+    ap.add_argument("--stride", type=int, default=0,
+                    help="row pitch of the device columns in elements (0 = days rounded up to a multiple of 16 = 128 B; = days: dense)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +148,10 @@ def main():
     else:
         n_local, n_total = args.symbols, args.symbols * world
         ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
-    stride = args.stride or T
+    # Device columns are pitched like a hipMallocPitch allocation: a row pitch that is a multiple of 128 B makes every 64 / 128-byte
+    # tile piece one aligned cache line (dense 2520-element rows start at odd multiples of 64 B): -8 % per step.  `--stride <days>`
+    # measures the dense layout.
+    stride = args.stride or (T + 15) // 16 * 16
     if stride != T:  # re-house the inputs with the padded row pitch
         for k in list(ohlcv):
             buf = torch.zeros((n_local, stride), dtype=torch.float64, device=dev)
@@ -218,7 +224,8 @@ def main():
             "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
                                    f"recognisers) + fused MACD-cross backtest with summary, {n_local} symbols x {T} days "
                                    "f64 OHLCV per GPU, inputs resident in HBM",
-                       "symbols_per_gpu": n_local, "symbols_total": n_total, "days": T, "parallelism": f"symbol-sharded x{world}",
+                       "symbols_per_gpu": n_local, "symbols_total": n_total, "days": T, "row_pitch_elements": stride,
+                       "parallelism": f"symbol-sharded x{world}",
                        "algorithmic_bytes_per_row": suite.suite_bytes_per_row(),
                        "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "kernel": "seq_jobs_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -65,6 +65,13 @@ pq_status pq_host_register(void *host_ptr, size_t bytes);
 pq_status pq_host_unregister(void *host_ptr);
 pq_status pq_memcpy_h2d(pq_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 pq_status pq_memcpy_d2h(pq_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* The same for `rows` rows of `width_bytes` each with different row pitches on the two sides: a dense host column
+ * ([n_series][len], what Arrow hands over) to / from a device column whose pitch is a multiple of 128 B (pq_batch.stride > len:
+ * every 64 / 128-byte tile piece is then one aligned cache line, which the suite replay rewards with ~8 %). */
+pq_status pq_memcpy_h2d_pitched(pq_ctx *ctx, void *dst_dev, size_t dst_pitch_bytes, const void *src_host, size_t src_pitch_bytes,
+                                size_t width_bytes, size_t rows);
+pq_status pq_memcpy_d2h_pitched(pq_ctx *ctx, void *dst_host, size_t dst_pitch_bytes, const void *src_dev, size_t src_pitch_bytes,
+                                size_t width_bytes, size_t rows);
 /* Arrow validity bitmap (LSB-first, bit i = row i of the long column, starting at bit `bit_offset`)
  * -> overwrite null rows of `col` (n contiguous rows) with PQ_NULL_BITS */
 pq_status pq_nulls_from_arrow(pq_ctx *ctx, double *col, const uint8_t *validity_bits, int64_t bit_offset, int64_t n);

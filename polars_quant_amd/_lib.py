@@ -116,6 +116,8 @@ def lib() -> C.CDLL:
         L.pq_host_unregister.argtypes = [vp]
         L.pq_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.pq_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.pq_memcpy_h2d_pitched.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.pq_memcpy_d2h_pitched.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
         L.pq_device_count.argtypes = [C.POINTER(C.c_int32)]
         L.pq_suite_begin.argtypes = [vp, C.POINTER(Batch)]
         L.pq_suite_end.argtypes = [vp, C.POINTER(vp)]

@@ -486,6 +486,70 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #ifndef PQ_STORER_ACC
 #define PQ_STORER_ACC 1 // 2 / 4: -1 % .. +4 % per suite step (A/B in one session): the microbenchmark's gain does not carry over
 #endif
+#ifndef PQ_STORER_PAIR
+#define PQ_STORER_PAIR 1
+#endif
+#ifndef PQ_PAIR_CAP
+#define PQ_PAIR_CAP 136
+#endif
+            if constexpr (K == 8 && PQ_STORER_PAIR) {
+                // Pair mode: the storer re-maps its lanes to (series of a group of 8, one of the 8 chunks of TWO consecutive tiles):
+                // lanes with chunk < 4 pull their 16 bytes out of the even tile, the others out of the odd tile into the same
+                // registers, and one store instruction then writes 8 series x 128 contiguous bytes instead of 16 x 64 -- with a row
+                // pitch that is a multiple of 128 B every piece is one full cache line (no partial-line write in L2): -8 % per suite
+                // step at pitch 2528 (against 64-byte pieces at the dense pitch 2520; -4 % of it from the pitch alone, which also
+                // aligns the 16-row tiles of the 1-in/1-out ops).  No extra LDS, the register count of two held tiles; columns
+                // beyond the register cap go out per tile as before.
+                constexpr int CAP = IsHeavy<Op>::value ? 208 : PQ_PAIR_CAP;
+                constexpr int W0 = (CAP - NOUT * NI * 4) / (NI * 4);
+                constexpr int W = W0 < 0 ? 0 : (W0 > NOUT ? NOUT : W0), R = NOUT - W;
+                const int half = (lane >> 2) & 1, sub = lane >> 3;
+                const unsigned char *pr_row = lds + sub * ROWB + (lane & 3) * 16;
+                for (int64_t it = 0; it < nt; it += 2) {
+                    double2 w[W > 0 ? W : 1][8];
+#pragma unroll
+                    for (int a = 0; a < 2; a++) {
+                        if (it + a < nt) {
+                            double2 v[R > 0 ? R : 1][NI];
+                            __builtin_amdgcn_s_barrier(); // A: out tile `it + a` is complete
+                            lds_fence();
+                            if (half == a) {
+#pragma unroll
+                                for (int k = 0; k < W; k++)
+#pragma unroll
+                                    for (int i = 0; i < 8; i++) {
+                                        const double *q = reinterpret_cast<const double *>(pr_row + i * 8 * ROWB + k * TB);
+                                        w[k][i] = make_double2(q[0], q[1]);
+                                    }
+                            }
+#pragma unroll
+                            for (int k = 0; k < R; k++)
+#pragma unroll
+                                for (int i = 0; i < NI; i++) {
+                                    const double *q = reinterpret_cast<const double *>(co_row[i] + (W + k) * TB);
+                                    v[k][i] = make_double2(q[0], q[1]);
+                                }
+                            lds_fence();
+                            __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
+                            const int64_t t0 = (it + a) * K;
+#pragma unroll
+                            for (int k = 0; k < R; k++)
+#pragma unroll
+                                for (int i = 0; i < NI; i++)
+                                    if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[W + k] + crow[i] + t0, v[k][i]);
+                        }
+                    }
+                    const bool mine = it + 1 < nt || half == 0; // an odd tile count leaves the last tile alone
+                    const int64_t t0 = it * K + (lane & 7) * 2;
+#pragma unroll
+                    for (int k = 0; k < W; k++)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int64_t srs = tile_s0 + i * 8 + sub;
+                            if (mine && srs < d.n) nt_store2(outp[k] + srs * d.stride + t0, w[k][i]);
+                        }
+                }
+            } else {
             constexpr int ACC = (NOUT * NI * 4 * PQ_STORER_ACC <= 136) ? PQ_STORER_ACC : 1; // registers of the (otherwise idle) storer wave
             for (int64_t it = 0; it < nt; it += ACC) {
                 double2 v[ACC][NOUT][NI];
@@ -513,6 +577,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                         for (int a = 0; a < ACC; a++)
                             if (it + a < nt && tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0 + a * K, v[a][k][i]);
+            }
             }
             if constexpr (HasFinish<Op>::value) { // the epilogue of wave 0 reads what this wave stored
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store acknowledged

@@ -159,6 +159,21 @@ pq_status pq_memcpy_d2h(pq_ctx *ctx, void *dst, const void *src, size_t bytes) {
     PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PQ_OK;
 }
+pq_status pq_memcpy_h2d_pitched(pq_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows) {
+    if (!ctx || !dst || !src) { pq_set_error("pq_memcpy_h2d_pitched: null pointer"); return PQ_ERR_ARG; }
+    if (width > dpitch || width > spitch) { pq_set_error("pq_memcpy_h2d_pitched: a row is wider than its pitch"); return PQ_ERR_ARG; }
+    if (!width || !rows) return PQ_OK;
+    PQ_HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, ctx->stream));
+    return PQ_OK;
+}
+pq_status pq_memcpy_d2h_pitched(pq_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows) {
+    if (!ctx || !dst || !src) { pq_set_error("pq_memcpy_d2h_pitched: null pointer"); return PQ_ERR_ARG; }
+    if (width > dpitch || width > spitch) { pq_set_error("pq_memcpy_d2h_pitched: a row is wider than its pitch"); return PQ_ERR_ARG; }
+    if (!width || !rows) return PQ_OK;
+    PQ_HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
 pq_status pq_nulls_from_arrow(pq_ctx *ctx, double *col, const uint8_t *bits, int64_t bit_offset, int64_t n) {
     if (!ctx || !col || !bits || n < 0 || bit_offset < 0) { pq_set_error("pq_nulls_from_arrow: bad argument"); return PQ_ERR_ARG; }
     if (n == 0) return PQ_OK;

@@ -29,6 +29,35 @@ def _ck(L, st):
     assert st == 0, L.pq_last_error().decode()
 
 
+def test_pitched_copies_place_dense_host_columns_at_a_128_byte_pitch(L, oracle):
+    """pq_memcpy_h2d_pitched / pq_memcpy_d2h_pitched: a dense [n, len] host column into a device column with a 128-byte row pitch
+    (the layout bench.py measures), one C-ABI call on it with pq_batch.stride = the pitch, and back; the padding is untouched."""
+    from polars_quant_amd._lib import Batch
+    n, T, pitch = 9, 203, 208
+    rng = np.random.default_rng(4)
+    host = np.ascontiguousarray(rng.normal(size=(n, T)).cumsum(axis=1) + 50.0)
+    ctx = C.c_void_p()
+    _ck(L, L.pq_ctx_create(0, None, C.byref(ctx)))
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    _ck(L, L.pq_malloc(ctx, n * pitch * 8, C.byref(d_in)))
+    _ck(L, L.pq_malloc(ctx, n * pitch * 8, C.byref(d_out)))
+    poison = np.full((n, pitch), -7.0)
+    _ck(L, L.pq_memcpy_h2d(ctx, d_in, poison.ctypes.data_as(C.c_void_p), poison.nbytes))
+    _ck(L, L.pq_memcpy_h2d(ctx, d_out, poison.ctypes.data_as(C.c_void_p), poison.nbytes))
+    _ck(L, L.pq_memcpy_h2d_pitched(ctx, d_in, pitch * 8, host.ctypes.data_as(C.c_void_p), T * 8, T * 8, n))
+    b = Batch(n, T, pitch)
+    _ck(L, L.pq_ema(ctx, C.byref(b), d_in, 10, d_out))
+    got = np.empty((n, T))
+    _ck(L, L.pq_memcpy_d2h_pitched(ctx, got.ctypes.data_as(C.c_void_p), T * 8, d_out, pitch * 8, T * 8, n))
+    (exp,) = oracle.call("ema", host, timeperiod=10)
+    assert (bits(got) == bits(exp)).all()
+    raw = np.empty((n, pitch))
+    _ck(L, L.pq_memcpy_d2h(ctx, raw.ctypes.data_as(C.c_void_p), d_out, raw.nbytes))
+    assert (raw[:, T:] == -7.0).all()                       # rows between the series are never written
+    assert L.pq_memcpy_h2d_pitched(ctx, d_in, 8, host.ctypes.data_as(C.c_void_p), T * 8, T * 8, n) != 0   # width > pitch
+    _ck(L, L.pq_free(ctx, d_in)); _ck(L, L.pq_free(ctx, d_out)); _ck(L, L.pq_ctx_destroy(ctx))
+
+
 def test_arrow_column_through_the_c_abi_only(L, oracle):
     """INTEGRATION.md section 2, step by step, with nothing but C-ABI calls: a host Arrow f64 column with a validity bitmap and
     a NON-ZERO bit offset (a slice) -> pq_host_register -> pq_malloc -> pq_memcpy_h2d -> pq_nulls_from_arrow -> pq_ema ->

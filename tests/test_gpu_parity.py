@@ -493,17 +493,39 @@ def test_numpy_and_arrow_roundtrip(pq, oracle, data):
 
 def test_suite_replay_matches_direct_calls_and_oracle(pq, oracle, data):
     """pq_suite_*: the recorded job grid must reproduce the direct calls (and therefore the oracle) bit for bit"""
+    _check_suite_replay(pq, oracle, data, None)
+
+
+@pytest.mark.parametrize("pad", [3, 8, 16])
+def test_suite_replay_padded_row_pitch(pq, oracle, data, pad):
+    """The same with a row pitch larger than the row length (bench.py's layout: pitch = a multiple of 128 B): rows between
+    the series are never read or written; an odd length under an even pitch runs the tiled bodies with a ragged tail."""
+    T = data["close"].shape[1]
+    stride = T + pad if (T + pad) % 2 == 0 else T + pad + 1
+    if pad == 16: stride = (T + 15) // 16 * 16       # the 128-byte pitch itself
+    _check_suite_replay(pq, oracle, data, stride)
+
+
+def _check_suite_replay(pq, oracle, data, stride):
     from polars_quant_amd.suite import Suite
-    g = {k: torch.from_numpy(v).cuda() for k, v in data.items() if k in ("open", "high", "low", "close", "volume")}
     N_SYM, T = data["close"].shape
-    st = Suite(N_SYM, T, "cuda")
+    if stride is None:
+        g = {k: torch.from_numpy(v).cuda() for k, v in data.items() if k in ("open", "high", "low", "close", "volume")}
+    else:                                   # inputs re-housed with the padded pitch; the padding holds a poison value
+        g = {}
+        for k in ("open", "high", "low", "close", "volume"):
+            buf = torch.full((N_SYM, stride), 1e300, dtype=torch.float64, device="cuda")
+            buf[:, :T] = torch.from_numpy(data[k]).cuda()
+            g[k] = buf[:, :T]
+    st = Suite(N_SYM, T, "cuda", stride=stride)
+    pitch = T if stride is None else stride
     st.record(g)
     info = st.info()
     # tiled path: the multi-output forms make ~29 single-phase jobs; gather path: every composite is a chain through scratch
-    assert (info["seq_jobs"] >= 25 and info["phases"] >= 1) if T % 2 == 0 else (info["seq_jobs"] >= 60 and info["phases"] >= 2)
+    assert (info["seq_jobs"] >= 25 and info["phases"] >= 1) if pitch % 2 == 0 else (info["seq_jobs"] >= 60 and info["phases"] >= 2)
     kernels = {gs["kernel"] for gs in st.grid_stats()}
     # an even row pitch must run the tiled bodies (what bench.py times), an odd one the gather bodies
-    assert ("seq_jobs_kernel<0>" in kernels and "seq_jobs_kernel<1>" in kernels) if T % 2 == 0 else ("seq_jobs_kernel<2>" in kernels), kernels
+    assert ("seq_jobs_kernel<0>" in kernels and "seq_jobs_kernel<1>" in kernels) if pitch % 2 == 0 else ("seq_jobs_kernel<2>" in kernels), kernels
     for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
         t.fill_(-7)                      # poison: every row must be produced by the replay
     st.run()
