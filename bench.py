@@ -29,7 +29,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_SYM, T_DAYS, SEED = 5000, 2520, 0x5EED0002
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+COPY_GBS = 4400.0   # torch copy_ of 4-12 GB on MI355X: 2.2 TB/s read + 2.2 TB/s written (profiles/r02_ubench_write_bw.txt)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured here: streaming read 6.1, fill 6.6 TB/s
 
 
 def make_inputs(n_sym: int, T: int, seed: int, device):
@@ -211,8 +212,14 @@ def main():
     traffic = None
     pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
     if pmc.exists() and n_local == N_SYM and T == T_DAYS:
-        k = json.loads(pmc.read_text())["kernels"].get("seq_jobs_kernel<0>")
+        kernels = json.loads(pmc.read_text())["kernels"]
+        k = kernels.get("seq_jobs_kernel<0>")
         traffic = k["hbm_bytes_per_launch"] if k else None
+        # every kernel of the step (the PMC file holds means per launch; seq_jobs_kernel<0> is launched twice per step)
+        step_traffic = sum(v["hbm_bytes_per_launch"] * (2 if name == "seq_jobs_kernel<0>" else 1)
+                           for name, v in kernels.items() if name in ("seq_jobs_kernel<0>", "seq_jobs_kernel<1>", "cdl_all_kernel", "row_jobs_kernel"))
+    else:
+        step_traffic = None
 
     if rank == 0:
         rows_total = n_total * T * args.steps
@@ -230,6 +237,11 @@ def main():
                        "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "kernel": "seq_jobs_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         # the whole step against what this chip does for a read/write MIX: its L2-miss bytes (PMC) per second, and
+                         # the rate of a streaming copy (2.2 TB/s read + 2.2 TB/s written, scripts/ubench/write_bw.py)
+                         "step_traffic": step_traffic,
+                         "step_traffic_GBps": step_traffic / (elapsed / args.steps) / 1e9 if step_traffic and world == 1 else None,
+                         "copy_GBps_measured": COPY_GBS,
                          "algorithmic_bytes_per_launch": mean_bytes, "avg_launch_ms": mean_ms,
                          "launches_per_step": len(dom),
                          "concurrent_set": {"note": "the launches of this kernel overlap inside a step: their summed algorithmic bytes "

@@ -548,6 +548,26 @@ def _check_suite_replay(pq, oracle, data, stride):
     st.close()
 
 
+def test_fused_row_grid_slices_more_than_65535_series(pq, oracle):
+    """The suite's fused ROW grid (row_jobs_kernel) and the tiled SEQ grids with more series than one grid dimension holds
+    (grid.y <= 65535): 66 000 short series, a task list of ROW ops plus two sequential jobs, against the oracle."""
+    from polars_quant_amd.suite import Suite
+    N, T_ = 66000, 48
+    d = oracle.gen_ohlcv(0x5EED0009, N, T_, 0)
+    g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    st = Suite(N, T_, "cuda")
+    tasks = ["bop", "mom", "roc", "willr", "trange", "avgprice", "typprice", "aroon_all", "ht_trendmode", "sma", "rsi"]
+    st.record(g, tasks)
+    assert st.info()["row_launches"] >= 9
+    st.run(); torch.cuda.synchronize()
+    d = dict(d); d["real"] = d["close"]
+    for name in ("bop", "mom", "roc", "willr", "trange", "avgprice", "typprice", "aroon", "aroonosc", "ht_trendmode", "sma", "rsi"):
+        exp = oracle.call(name, *[d[c] for c in pq.SPEC[name][0]])
+        for (oname, _), got, e in zip(pq.SPEC[name][2], st.out[name], exp):
+            assert_same(f"wide:{name}.{oname}", got.cpu().numpy(), e, exact=True)
+    st.close()
+
+
 def test_full_size_suite_sampled_parity_and_properties(pq, oracle):
     """BASELINE full size (5000 symbols x 2520 days), the bench's own Suite object: (1) every output of a sample of symbols
     equals the oracle run on just those symbols (series are independent, so a sample at full length is a full-length parity
