@@ -46,16 +46,23 @@ typedef struct pq_series_export {
 
 uint32_t _polars_plugin_get_version(void);                       /* (major << 16) | minor = 0.1 */
 const char *_polars_plugin_get_last_error_message(void);        /* thread-local, set when a call leaves return_value empty */
-/* inputs: `n_inputs` exported Series; kwargs: pickle bytes or NULL/0; return_value: filled on success (release != NULL) */
-void _polars_plugin_ema(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,
-                        pq_series_export *return_value, void *context);                      /* overlap.rs:127 */
-void _polars_plugin_sma(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,
-                        pq_series_export *return_value, void *context);                      /* overlap.rs:494 */
-/* output field (name of the first input, Float64): `#[polars_expr(output_type=Float64)]` */
-void _polars_plugin_field_ema(struct ArrowSchema *fields, size_t n_fields, struct ArrowSchema *return_value,
-                              const uint8_t *kwargs, size_t kwargs_len);
-void _polars_plugin_field_sma(struct ArrowSchema *fields, size_t n_fields, struct ArrowSchema *return_value,
-                              const uint8_t *kwargs, size_t kwargs_len);
+/* One pair of symbols per reference function of the shape (real[, timeperiod]) -> Float64.
+ *   _polars_plugin_<f>(inputs, n_inputs, kwargs, kwargs_len, return_value, context)
+ *       inputs: `n_inputs` exported Series (the column, optionally the period as a trailing literal Series -- momentum.rs);
+ *       kwargs: pickle bytes of {"timeperiod": n} or NULL/0 (overlap.rs:11-28 MaKwargs); return_value: filled on success
+ *       (release != NULL), left zeroed on failure with the message in _polars_plugin_get_last_error_message()
+ *   _polars_plugin_field_<f>(fields, n_fields, return_value, kwargs, kwargs_len)
+ *       output field: the first input's name, Float64 (`#[polars_expr(output_type=Float64)]`)
+ * reference: overlap.rs:494 sma, :127 ema, :531 wma, :119 dema, :513 tema, :522 trima, :137 kama, :180 midpoint;
+ *            momentum.rs:507 rsi, :181 cmo, :384 mom, :439 roc, :456 rocp, :473 rocr, :490 rocr100, :544 trix */
+#define PQ_PLUGIN_DECL(NAME)                                                                                                   \
+    void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
+                               pq_series_export *return_value, void *context);                                                \
+    void _polars_plugin_field_##NAME(struct ArrowSchema *fields, size_t n_fields, struct ArrowSchema *return_value,            \
+                                     const uint8_t *kwargs, size_t kwargs_len);
+PQ_PLUGIN_DECL(sma) PQ_PLUGIN_DECL(ema) PQ_PLUGIN_DECL(wma) PQ_PLUGIN_DECL(dema) PQ_PLUGIN_DECL(tema) PQ_PLUGIN_DECL(trima)
+PQ_PLUGIN_DECL(kama) PQ_PLUGIN_DECL(midpoint) PQ_PLUGIN_DECL(rsi) PQ_PLUGIN_DECL(cmo) PQ_PLUGIN_DECL(mom) PQ_PLUGIN_DECL(roc)
+PQ_PLUGIN_DECL(rocp) PQ_PLUGIN_DECL(rocr) PQ_PLUGIN_DECL(rocr100) PQ_PLUGIN_DECL(trix)
 
 /* host-only helper behind the kwargs path (CPU-testable): the int64 value of `key` in a pickled dict of scalars.
  * returns 1 found, 0 absent or None, -1 malformed / unsupported pickle */

@@ -101,7 +101,7 @@ pq_ctx *plugin_ctx() { // one context per host thread (Polars calls plugins from
 }
 typedef pq_status (*ma_fn)(pq_ctx *, const pq_batch *, const double *, int64_t, double *);
 
-void run_ma(ma_fn fn, const char *fname, int64_t default_period, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
+void run_ma(ma_fn fn, const char *fname, int64_t default_period, bool reject_nulls, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
             size_t kwargs_len, pq_series_export *ret) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
@@ -143,6 +143,8 @@ void run_ma(ma_fn fn, const char *fname, int64_t default_period, pq_series_expor
             }
         pos += a->length;
     }
+    // the momentum family goes through rechunk().cont_slice()? in the reference (momentum.rs:12-13): a null is an error there
+    if (any_null && reject_nulls) { delete op; plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
     int64_t null_count = 0;
     if (n > 0) {
         pq_ctx *ctx = plugin_ctx();
@@ -188,12 +190,18 @@ void field_f64(ArrowSchema *fields, size_t n_fields, ArrowSchema *ret) {
 extern "C" {
 uint32_t _polars_plugin_get_version(void) { return (0u << 16) | 1u; }
 const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_str(); }
-void _polars_plugin_ema(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, void *) {
-    run_ma(&pq_ema, "pq_ema", 30, inputs, n_inputs, kwargs, kwargs_len, ret);
-}
-void _polars_plugin_sma(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, void *) {
-    run_ma(&pq_sma, "pq_sma", 30, inputs, n_inputs, kwargs, kwargs_len, ret);
-}
-void _polars_plugin_field_ema(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
-void _polars_plugin_field_sma(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+// every reference function of the shape (real[, timeperiod]) -> Float64: overlap.rs takes the period as pickled kwargs (MaKwargs,
+// overlap.rs:11-28), momentum.rs as a trailing literal input; run_ma accepts both.  X(name, default timeperiod, rejects nulls)
+#define PQ_PLUGIN_TP_FUNCS(X)                                                                                                  \
+    X(sma, 30, false) X(ema, 30, false) X(wma, 30, false) X(dema, 30, false) X(tema, 30, false) X(trima, 30, false)            \
+    X(kama, 30, false) X(midpoint, 14, false) X(rsi, 14, true) X(cmo, 14, true) X(mom, 10, true) X(roc, 10, true)              \
+    X(rocp, 10, true) X(rocr, 10, true) X(rocr100, 10, true) X(trix, 30, true)
+#define X(NAME, DEFAULT, NB)                                                                                                     \
+    void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
+                               pq_series_export *ret, void *) {                                                                \
+        run_ma(&pq_##NAME, "pq_" #NAME, DEFAULT, NB, inputs, n_inputs, kwargs, kwargs_len, ret);                                  \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+PQ_PLUGIN_TP_FUNCS(X)
+#undef X
 }

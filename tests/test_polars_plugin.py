@@ -29,19 +29,28 @@ class SeriesExport(C.Structure):
                 ("private_data", C.c_void_p)]
 
 
+# every reference function of the shape (real[, timeperiod]) -> Float64 has a plugin symbol pair: name -> default timeperiod
+TP_FUNCS = {"sma": 30, "ema": 30, "wma": 30, "dema": 30, "tema": 30, "trima": 30, "kama": 30, "midpoint": 14, "rsi": 14, "cmo": 14,
+            "mom": 10, "roc": 10, "rocp": 10, "rocr": 10, "rocr100": 10, "trix": 30}
+
+
 def _lib():
     so = ROOT / "polars_quant_amd" / "libpolars_quant_hip.so"
     if not so.exists():
         import __graft_entry__ as g
         g.build()
+    try:
+        import torch  # noqa: F401  (its bundled HIP runtime must be the first one in the process, as in polars_quant_amd._lib)
+    except ImportError:
+        pass
     L = C.CDLL(str(so))
     L._polars_plugin_get_version.restype = C.c_uint32
     L._polars_plugin_get_last_error_message.restype = C.c_char_p
     L.pq_plugin_kwargs_i64.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int64)]
-    for f in ("_polars_plugin_ema", "_polars_plugin_sma"):
+    for f in ("_polars_plugin_" + n for n in TP_FUNCS):
         getattr(L, f).argtypes = [C.POINTER(SeriesExport), C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(SeriesExport), C.c_void_p]
         getattr(L, f).restype = None
-    for f in ("_polars_plugin_field_ema", "_polars_plugin_field_sma"):
+    for f in ("_polars_plugin_field_" + n for n in TP_FUNCS):
         getattr(L, f).argtypes = [C.POINTER(ArrowSchema), C.c_size_t, C.POINTER(ArrowSchema), C.c_char_p, C.c_size_t]
         getattr(L, f).restype = None
     return L
@@ -50,7 +59,13 @@ def _lib():
 def test_plugin_symbols_and_version():
     txt = (ROOT / "include" / "pq_polars_plugin.h").read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(_polars_plugin_[a-z0-9_]+|pq_plugin_[a-z0-9_]+)\s*\(", txt)))
+    declared = set(re.findall(r"\b(_polars_plugin_[a-z0-9_]+|pq_plugin_[a-z0-9_]+)\s*\(", txt))
+    for n in re.findall(r"\bPQ_PLUGIN_DECL\((\w+)\)", txt):      # the per-function pairs are declared through a macro
+        if n != "NAME":                                           # (the macro's own parameter)
+            declared |= {"_polars_plugin_" + n, "_polars_plugin_field_" + n}
+    declared = {n for n in declared if "##" not in n and not n.endswith("_")}
+    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in TP_FUNCS}
+    declared = sorted(declared)
     assert {"_polars_plugin_get_version", "_polars_plugin_get_last_error_message", "_polars_plugin_ema", "_polars_plugin_field_ema"} <= set(declared)
     L = _lib()
     assert not [s for s in declared if not hasattr(L, s)]
@@ -138,3 +153,49 @@ def test_plugin_calls_match_the_oracle(oracle):
     ret = SeriesExport()
     L._polars_plugin_ema(C.byref(sei), 1, None, 0, C.byref(ret), None)
     assert not ret.release and b"Float64" in L._polars_plugin_get_last_error_message()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(TP_FUNCS))
+def test_every_timeperiod_function_through_its_plugin_symbol(oracle, name):
+    """Each exported pair: default period (no kwargs, no literal), pickled kwargs, trailing literal -- against the oracle on a
+    two-chunk column; null-bearing for the overlap functions, null-free for the momentum family, which must REFUSE a null like
+    the reference's rechunk().cont_slice()? (momentum.rs:12-13)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    d = oracle.gen_ohlcv(0x5EED000C, 1, 400, 0)
+    x = d["close"][0]
+    from polars_quant_amd._spec import SPEC
+    rejects = SPEC[name][3] == "N-B"
+    mask = np.zeros(400, bool); mask[[5, 6, 200]] = True
+    fn = getattr(L, "_polars_plugin_" + name)
+    if rejects:
+        se, keep = _export([pa.array(x, mask=mask)], "close")
+        ret = SeriesExport(); fn(C.byref(se), 1, None, 0, C.byref(ret), None)
+        assert not ret.release and b"nulls" in L._polars_plugin_get_last_error_message()
+        mask[:] = False
+    xn = x.copy(); xn[mask] = oracle.NULL
+    whole = pa.array(x, mask=mask)
+
+    def check(ret, period):
+        assert ret.release, L._polars_plugin_get_last_error_message()
+        got = _import(ret)
+        (exp,) = oracle.call(name, xn, timeperiod=period)
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert (np.asarray(got.is_null()) == en).all(), name
+        assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all(), name
+
+    se, keep = _export([whole.slice(0, 150), whole.slice(150)], "close")
+    ret = SeriesExport(); fn(C.byref(se), 1, None, 0, C.byref(ret), None); check(ret, TP_FUNCS[name])
+    se, keep = _export([whole.slice(0, 150), whole.slice(150)], "close")
+    kw = pickle.dumps({"timeperiod": 9})
+    ret = SeriesExport(); fn(C.byref(se), 1, kw, len(kw), C.byref(ret), None); check(ret, 9)
+    se0, keep0 = _export([whole], "close")
+    se1, keep1 = _export([pa.array([21], type=pa.int64())], "literal")
+    ins = (SeriesExport * 2)(se0, se1)
+    ret = SeriesExport(); fn(ins, 2, None, 0, C.byref(ret), None); check(ret, 21)
+    out_field = ArrowSchema()
+    getattr(L, "_polars_plugin_field_" + name)(se0.field, 1, C.byref(out_field), None, 0)
+    assert out_field.format == b"g" and out_field.name == b"close"
