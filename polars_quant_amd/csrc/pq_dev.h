@@ -634,7 +634,11 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         PQ_PROF_T(c1);
         if constexpr (HasFast<Op>::value) {
             // steady state on the whole wave and a null-free tile: straight-line rows
+#ifdef PQ_EXP_NOCOMPUTE
+            if (true) {
+#else
             if (__builtin_amdgcn_ballot_w64(maybe_null || !op.steady(t0)) == 0) {
+#endif
                 constexpr int FU = FastUnroll<Op>::value < K ? FastUnroll<Op>::value : K;
                 static_assert(K % FU == 0, "FAST_UNROLL must divide the tile height");
 #pragma unroll 1
@@ -644,7 +648,11 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     for (int u = 0; u < FU; u++)
 #pragma unroll
                         for (int k = 0; k < NIN; k++) xs[u][k] = *reinterpret_cast<const double *>(my_row + k * TB + (j0 + u) * 8);
+#ifdef PQ_EXP_NOCOMPUTE // experiment: the traffic and the hand-off machinery alone (outputs = the first input)
+                    for (int u = 0; u < FU; u++) for (int k = 0; k < NOUT; k++) ys[u][k] = xs[u][0];
+#else
                     fast_rows<Op, FU>(op, t0 + j0, xs, ys);
+#endif
 #pragma unroll
                     for (int u = 0; u < FU; u++) {
                         if constexpr (MASKED) {
