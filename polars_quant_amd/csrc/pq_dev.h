@@ -612,7 +612,11 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
+#ifdef PQ_EXP_NOLOAD // experiment (with PQ_EXP_NOCOMPUTE): what do the input reads cost?
+            for (int i = 0; i < NI; i++) buf[k][i] = make_double2((double)t0, (double)i);
+#else
             for (int i = 0; i < NI; i++) buf[k][i] = *reinterpret_cast<const double2 *>(inp[k] + crow[i] + t0);
+#endif
     };
     auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
