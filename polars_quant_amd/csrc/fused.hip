@@ -108,7 +108,9 @@ pq_status pq_dmi_all(pq_ctx *ctx, const pq_batch *b, const double *h, const doub
 pq_status pq_ht_all(pq_ctx *ctx, const pq_batch *b, const double *real, double *dcperiod, double *dcphase, double *inphase,
                     double *quadrature, double *sine, double *leadsine) {
     CHK("pq_ht_all", real && dcperiod && dcphase && inphase && quadrature && sine && leadsine);
-    return launch_seq(ctx, b, HtAllOp{}, InCols<1>{{real}}, OutCols<6>{{dcperiod, dcphase, inphase, quadrature, sine, leadsine}});
+    PQ_TRY(launch_seq(ctx, b, HtAllOp{}, InCols<1>{{real}}, OutCols<3>{{dcperiod, inphase, quadrature}}));
+    // (in a recorded suite the ROW launch reads what the job writes, so it lands in the next phase)
+    return launch_row(ctx, b, HtPhaseSineOp{}, InCols<2>{{inphase, quadrature}}, OutColsT<HtPhaseSineOp, double>{{dcphase, sine, leadsine}});
 }
 
 // ---- multi-output forms: several reference functions over the same inputs as ONE job (bit-identical columns) ----

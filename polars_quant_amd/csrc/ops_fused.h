@@ -438,49 +438,61 @@ struct DmAllOp {
     }
 };
 
-// cycle.rs: the shared Hilbert pipeline once for ht_dcperiod, ht_dcphase, ht_phasor and ht_sine
+// cycle.rs: the shared Hilbert pipeline once for ht_dcperiod, ht_dcphase, ht_phasor and ht_sine.  The sequential job emits what
+// needs the serial walk -- the smoothed period and the phasor components -- and HtPhaseSineOp (a ROW kernel, any order) derives
+// dcphase, sine and leadsine from the stored phasor columns: they are pure functions of (inphase, quadrature) (cycle.rs:130-134,
+// :294-300).  The six-output form of this job was the last workgroup to finish in a suite step and spent 40 % of its time waiting
+// for its storer wave's queue position in the write path (11 600 of 27 300 cycles per 8-row tile, PQ_PROFILE_WAVES); with three
+// output columns and one atan less per row it is no longer the step's critical path.
 struct HtAllOp {
-    static constexpr int NIN = 1, NOUT = 6; // dcperiod, dcphase, inphase, quadrature, sine, leadsine
-    static constexpr int ALG_COLS = 2 + 2 + 3 + 3; // ht_dcperiod, ht_dcphase, ht_phasor, ht_sine
+    static constexpr int NIN = 1, NOUT = 3; // dcperiod, inphase, quadrature
+    static constexpr int ALG_COLS = 2 + 3;  // ht_dcperiod, ht_phasor (ht_dcphase and ht_sine are credited to HtPhaseSineOp's launch)
     static constexpr int SEQ_ID = 79;
-    static constexpr int COST_NS = 885;
+    static constexpr int COST_NS = 800;
     static constexpr bool HEAVY = true;
     HtOp<0> core;
     __device__ void init(const Row<1> &r) { core.init(r); }
     static constexpr bool FAST_NULL_OK = true;
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t t0) const { return core.steady(t0); }
-    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[6]) { row<true>(i, x, y); }
-    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[6]) { row<false>(i, x, y); }
+    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[3]) { row<true>(i, x, y); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[3]) { row<false>(i, x, y); }
     template <bool FAST>
-    __device__ __forceinline__ void row(int64_t i, const double (&x)[1], double (&y)[6]) {
+    __device__ __forceinline__ void row(int64_t i, const double (&x)[1], double (&y)[3]) {
         double yp[1];
         core.template row<FAST>(i, x, yp); // advances the pipeline, emits the smoothed period
         y[0] = yp[0];
-#pragma unroll
-        for (int k = 1; k < 6; k++) y[k] = pq_null();
+        y[1] = y[2] = pq_null();
         if (!FAST && (core.dead || i < 31)) return;
-        const double i1 = core.i1[0], q1 = core.q1[0];
+        y[1] = core.i1[0]; y[2] = core.q1[0];
+    }
+};
+// dcphase (cycle.rs:130-139), sine and leadsine (cycle.rs:294-300) from the phasor components of the same row.
+struct HtPhaseSineOp {
+    static constexpr int NIN = 2, NOUT = 3; // inphase, quadrature -> dcphase, sine, leadsine
+    typedef double OutT;
+    __device__ void eval(const Row<2> &r, int64_t t, double (&y)[3]) {
+        const double i1 = r.in[0][t], q1 = r.in[1][t];
+        y[0] = y[1] = y[2] = pq_null();
+        if (pq_isnull(i1)) return; // a row the pipeline does not emit (series shorter than 32 rows, rows 0..30)
         const double tq = q1 / i1;                                          // the quotient both the phase and the sine take
-        double ph = (i1 != 0.0) ? atan(tq) * PQ_RAD2DEG : 0.0;           // cycle.rs:130-134 == :294-298
+        double ph = (i1 != 0.0) ? atan(tq) * PQ_RAD2DEG : 0.0;
         double dc_phase = ph + 90.0;
         if (i1 < 0.0) dc_phase += 180.0;
         if (dc_phase > 315.0) dc_phase -= 360.0;
-        y[1] = dc_phase;
-        y[2] = i1; y[3] = q1;
-        // sine / leadsine (cycle.rs:294-300) without a device sin: with phi = atan(t), sin(phi) = t / sqrt(1 + t^2) and
-        // cos(phi) = 1 / sqrt(1 + t^2) (phi in (-pi/2, pi/2): cos >= 0), and sin(phi + pi/4) = (sin + cos) / sqrt(2).  The
-        // reference takes sin() of phi after a degrees round trip (two roundings, ~2e-16 relative on the argument); this form is
-        // within a few ulp of the exact value: far inside the 1e-12 budget of these outputs (the single-output pq_ht_sine keeps
-        // the reference's two sin calls).  A sqrt + a division replace the ~100-instruction sincos on the step's longest job.
+        y[0] = dc_phase;
+        // sine / leadsine without a device sin: with phi = atan(t), sin(phi) = t / sqrt(1 + t^2) and cos(phi) = 1 / sqrt(1 + t^2)
+        // (phi in (-pi/2, pi/2): cos >= 0), and sin(phi + pi/4) = (sin + cos) / sqrt(2).  The reference takes sin() of phi after a
+        // degrees round trip (two roundings, ~2e-16 relative on the argument); this form is within a few ulp of the exact value: far
+        // inside the 1e-12 budget of these outputs (the single-output pq_ht_sine keeps the reference's two sin calls).
         double sn = 0.0, cs = 1.0;
         if (i1 != 0.0) {
-            const double r = 1.0 / sqrt(1.0 + tq * tq);
-            sn = tq * r; cs = r;
+            const double rr = 1.0 / sqrt(1.0 + tq * tq);
+            sn = tq * rr; cs = rr;
             if (fabs(tq) >= 1e150) { sn = copysign(1.0, tq); cs = 0.0; }     // t^2 overflows: phi = +-pi/2 (false for a NaN t)
         }
-        y[4] = sn;
-        y[5] = (sn + cs) * 0.70710678118654752440;
+        y[1] = sn;
+        y[2] = (sn + cs) * 0.70710678118654752440;
     }
 };
 
