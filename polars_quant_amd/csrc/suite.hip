@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <map>
+#include <set>
 #include <vector>
 
 struct SeqJob { // device-visible
@@ -62,6 +63,7 @@ struct Phase {
     std::vector<SeqJob> seq;   // sorted at finalize by class, longest jobs first inside a class
     std::vector<RowThunk> rows;
     std::vector<char> row_late; // 0: on the ROW chain; 1 + c: behind the SEQ grid(s) of chain c
+    std::set<const void *> rd, wr; // every column the phase's calls read / write (hazard bookkeeping of the recording)
     std::vector<char> row_fused; // the launch runs inside the fused ROW grid of its chain position
     struct RowJobDev *d_rows[NCHAIN + 1] = {}; // fused ROW grid per position (index = row_late value)
     int n_rows[NCHAIN + 1] = {};
@@ -187,9 +189,11 @@ static int phase_for(Recorder &r, const void *const *reads, int nr, void *const 
     for (int i = 0; i < nr; i++) {
         int &rp = r.reader_phase[reads[i]];
         rp = std::max(rp, ph);
+        r.phases[ph].rd.insert(reads[i]);
     }
     for (int i = 0; i < nw; i++)
         if (writes[i]) {
+            r.phases[ph].wr.insert(writes[i]);
             auto it = r.writer_phase.find(writes[i]);
             r.writer_phase[writes[i]] = (it == r.writer_phase.end()) ? ph : std::max(it->second, ph);
         }
@@ -299,7 +303,8 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
     hipDeviceProp_t prop;
     PQ_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
     const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
-    for (Phase &p : r.phases) {
+    for (size_t pi = 0; pi < r.phases.size(); pi++) {
+        Phase &p = r.phases[pi];
         p.gs_row.n_jobs = (int)p.rows.size();
         // The ROW launches are cheap streaming kernels, but beside the SEQ grids they get few wave slots and one chain of
         // them becomes the critical path of the step.  Two chains: the heaviest launches (by columns moved) stay on the ROW
@@ -357,6 +362,34 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             else if (long_wgs + tiles <= long_budget) { j.cls = CLS_LONG; long_wgs += tiles; }
             else j.cls = CLS_SHORT;
         }
+        // A ROW launch of the NEXT phase whose inputs come only from sequential jobs of ONE class of this phase (e.g. dcphase / sine /
+        // leadsine from the Hilbert job's phasor columns) needs no phase barrier: behind that class's grid on the same stream it is
+        // ordered after its producers and overlaps the other chains' tails instead of extending the step.
+        if (pi + 1 < r.phases.size()) {
+            Phase &q = r.phases[pi + 1];
+            std::vector<RowThunk> stay;
+            for (const RowThunk &t : q.rows) {
+                int cls = -1;
+                bool ok = true;
+                for (int k = 0; k < t.n_reads && ok; k++) {
+                    if (!p.wr.count(t.reads[k])) continue;      // not produced in this phase
+                    int c = -1;
+                    for (const SeqJob &j : p.seq)
+                        for (int o = 0; o < j.nout; o++) if (j.out[o] == t.reads[k]) c = j.cls;
+                    if (c < 0 || (cls >= 0 && c != cls)) ok = false; // written by a ROW launch, or by jobs of two classes
+                    cls = c;
+                }
+                for (int k = 0; k < t.n_writes && ok; k++)
+                    if (p.rd.count(t.writes[k]) || p.wr.count(t.writes[k])) ok = false; // its outputs are touched in this phase
+                if (!ok || cls < 0) { stay.push_back(t); continue; }
+                p.rows.push_back(t);
+                p.row_late.push_back((char)(1 + cls));
+                for (int k = 0; k < t.n_reads; k++) p.rd.insert(t.reads[k]);
+                for (int k = 0; k < t.n_writes; k++) p.wr.insert(t.writes[k]);
+            }
+            q.rows.swap(stay);
+            p.gs_row.n_jobs = (int)p.rows.size();
+        }
         PQ_TRY(fuse_rows());
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cls < b.cls; }); // cost order kept
         const double rows = (double)r.b.n_series * (double)r.b.len;
@@ -388,6 +421,8 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         if (getenv("PQ_SUITE_DEBUG")) PQ_HIP_TRY(hipMalloc((void **)&p.d_dbg, 16 * p.seq.size()));
     }
     PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); // the host vectors are pageable
+    for (size_t pi = r.phases.size(); pi-- > 0;) // a phase whose only launches were hoisted is gone
+        if (r.phases[pi].seq.empty() && r.phases[pi].rows.empty()) r.phases.erase(r.phases.begin() + (long)pi);
     return PQ_OK;
 }
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
