@@ -217,7 +217,7 @@ def main():
         traffic = k["hbm_bytes_per_launch"] if k else None
         # every kernel of the step (the PMC file holds means per launch; seq_jobs_kernel<0> is launched twice per step)
         step_traffic = sum(v["hbm_bytes_per_launch"] * (2 if name == "seq_jobs_kernel<0>" else 1)
-                           for name, v in kernels.items() if name in ("seq_jobs_kernel<0>", "seq_jobs_kernel<1>", "cdl_all_kernel", "row_jobs_kernel"))
+                           for name, v in kernels.items() if not name.startswith(("at::", "__amd")))   # torch's own kernels excluded
     else:
         step_traffic = None
 
