@@ -253,6 +253,21 @@ def main():
         }
         if args.e2e and world == 1:
             line["config"]["e2e"] = end_to_end(suite, ohlcv, n_local, T, dev)
+        if world == 1 and stride != T and args.scaling == "weak" and not args.no_cpu_baseline:
+            # for the record: the same step on the DENSE layout (row pitch = days), outside the timed region above
+            suite.close()
+            dense_in = {k: v.contiguous() for k, v in ohlcv.items()}
+            dense = Suite(n_local, T, dev, stride=T)
+            dense.record(dense_in)
+            for _ in range(args.warmup):
+                dense.run(dense_in)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dense.run(dense_in)
+            torch.cuda.synchronize()
+            line["config"]["dense_layout"] = {"row_pitch_elements": T, "ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3}
+            dense.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4096, T)
         print(json.dumps(line))
