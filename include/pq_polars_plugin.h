@@ -46,15 +46,22 @@ typedef struct pq_series_export {
 
 uint32_t _polars_plugin_get_version(void);                       /* (major << 16) | minor = 0.1 */
 const char *_polars_plugin_get_last_error_message(void);        /* thread-local, set when a call leaves return_value empty */
-/* One pair of symbols per reference function of the shape (real[, timeperiod]) -> Float64.
+/* One pair of symbols per reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64 (41 of the 115).
  *   _polars_plugin_<f>(inputs, n_inputs, kwargs, kwargs_len, return_value, context)
- *       inputs: `n_inputs` exported Series (the column, optionally the period as a trailing literal Series -- momentum.rs);
+ *       inputs: `n_inputs` exported Series -- the columns in the reference's order (high, low, close, volume ...), optionally
+ *       followed by the period as a literal Series (momentum.rs / volatility.rs: `inputs[k].i64()?.get(0)`);
  *       kwargs: pickle bytes of {"timeperiod": n} or NULL/0 (overlap.rs:11-28 MaKwargs); return_value: filled on success
- *       (release != NULL), left zeroed on failure with the message in _polars_plugin_get_last_error_message()
+ *       (release != NULL), left zeroed on failure with the message in _polars_plugin_get_last_error_message().  A null in the
+ *       input of a function that goes through `rechunk().cont_slice()?` in the reference (momentum / cycle family) is such a failure.
  *   _polars_plugin_field_<f>(fields, n_fields, return_value, kwargs, kwargs_len)
  *       output field: the first input's name, Float64 (`#[polars_expr(output_type=Float64)]`)
- * reference: overlap.rs:494 sma, :127 ema, :531 wma, :119 dema, :513 tema, :522 trima, :137 kama, :180 midpoint;
- *            momentum.rs:507 rsi, :181 cmo, :384 mom, :439 roc, :456 rocp, :473 rocr, :490 rocr100, :544 trix */
+ * reference: overlap.rs:494 sma, :127 ema, :531 wma, :119 dema, :513 tema, :522 trima, :137 kama, :180 midpoint, :281 midprice;
+ *   momentum.rs:507 rsi, :181 cmo, :384 mom, :439 roc, :456 rocp, :473 rocr, :490 rocr100, :544 trix, :11 adx, :32 adxr, :226 dx,
+ *   :400 plus_di, :345 minus_di, :414 plus_dm, :359 minus_dm, :113 bop, :138 cci, :286 mfi, :630 willr;
+ *   volatility.rs:18 atr, :34 natr, :51 trange; volume.rs:19 ad, :70 obv; price.rs:10 avgprice, :33 medprice, :52 typprice,
+ *   :73 wclprice;
+ *   cycle.rs:10 ht_dcperiod, :75 ht_dcphase, :310 ht_trendline; aroonosc: registered by python/polars_quant/talib/momentum.py:42,
+ *   absent from the Rust library (decision D-6: AROON up - down) */
 #define PQ_PLUGIN_DECL(NAME)                                                                                                   \
     void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
                                pq_series_export *return_value, void *context);                                                \
@@ -62,7 +69,12 @@ const char *_polars_plugin_get_last_error_message(void);        /* thread-local,
                                      const uint8_t *kwargs, size_t kwargs_len);
 PQ_PLUGIN_DECL(sma) PQ_PLUGIN_DECL(ema) PQ_PLUGIN_DECL(wma) PQ_PLUGIN_DECL(dema) PQ_PLUGIN_DECL(tema) PQ_PLUGIN_DECL(trima)
 PQ_PLUGIN_DECL(kama) PQ_PLUGIN_DECL(midpoint) PQ_PLUGIN_DECL(rsi) PQ_PLUGIN_DECL(cmo) PQ_PLUGIN_DECL(mom) PQ_PLUGIN_DECL(roc)
-PQ_PLUGIN_DECL(rocp) PQ_PLUGIN_DECL(rocr) PQ_PLUGIN_DECL(rocr100) PQ_PLUGIN_DECL(trix)
+PQ_PLUGIN_DECL(rocp) PQ_PLUGIN_DECL(rocr) PQ_PLUGIN_DECL(rocr100) PQ_PLUGIN_DECL(trix) PQ_PLUGIN_DECL(ht_dcperiod)
+PQ_PLUGIN_DECL(ht_dcphase) PQ_PLUGIN_DECL(ht_trendline) PQ_PLUGIN_DECL(midprice) PQ_PLUGIN_DECL(plus_dm) PQ_PLUGIN_DECL(minus_dm)
+PQ_PLUGIN_DECL(aroonosc) PQ_PLUGIN_DECL(medprice) PQ_PLUGIN_DECL(obv) PQ_PLUGIN_DECL(adx) PQ_PLUGIN_DECL(adxr) PQ_PLUGIN_DECL(dx)
+PQ_PLUGIN_DECL(plus_di) PQ_PLUGIN_DECL(minus_di) PQ_PLUGIN_DECL(cci) PQ_PLUGIN_DECL(willr) PQ_PLUGIN_DECL(atr) PQ_PLUGIN_DECL(natr)
+PQ_PLUGIN_DECL(trange) PQ_PLUGIN_DECL(typprice) PQ_PLUGIN_DECL(wclprice) PQ_PLUGIN_DECL(mfi) PQ_PLUGIN_DECL(bop) PQ_PLUGIN_DECL(ad)
+PQ_PLUGIN_DECL(avgprice)
 
 /* host-only helper behind the kwargs path (CPU-testable): the int64 value of `key` in a pickled dict of scalars.
  * returns 1 found, 0 absent or None, -1 malformed / unsupported pickle */

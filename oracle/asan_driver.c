@@ -50,6 +50,7 @@ int main(void) {
                 pqo_mom(c, n, p, a); fold(a, n); pqo_roc(c, n, p, a); fold(a, n); pqo_rocp(c, n, p, a); fold(a, n);
                 pqo_rocr(c, n, p, a); fold(a, n); pqo_rocr100(c, n, p, a); fold(a, n);
                 pqo_returns(c, n, p, 0, a); fold(a, n); pqo_returns(c, n, p, 1, a); fold(a, n);
+                pqo_rolling_max(h, n, p, a); fold(a, n); pqo_rolling_min(l, n, p, a); fold(a, n);
                 pqo_rsi(c, n, p, a); fold(a, n); pqo_trix(c, n, p, a); fold(a, n);
                 pqo_ultosc(h, l, c, n, p, p + 2, 2 * p + 1, a); fold(a, n); pqo_willr(h, l, c, n, p, a); fold(a, n);
                 for (int64_t mt = 0; mt < 9; mt += 4) {

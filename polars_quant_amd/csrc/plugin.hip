@@ -1,5 +1,5 @@
-// plugin.hip -- Polars expression-plugin entry points (include/pq_polars_plugin.h) over the C ABI of this library: a spike for
-// EMA / SMA.  Host code only: import the exported Series (Arrow C Data Interface, any number of chunks, validity + offset),
+// plugin.hip -- Polars expression-plugin entry points (include/pq_polars_plugin.h) over the C ABI of this library: every reference
+// function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64.  Host code only: import the exported Series (Arrow C Data Interface, any number of chunks, validity + offset),
 // run the batched HIP entry point with n_series = 1, export one Float64 chunk.
 #include "../../include/pq_polars_plugin.h"
 #include "pq_dev.h"
@@ -99,75 +99,101 @@ pq_ctx *plugin_ctx() { // one context per host thread (Polars calls plugins from
     if (!c && pq_ctx_create(0, nullptr, &c) != PQ_OK) c = nullptr;
     return c;
 }
-typedef pq_status (*ma_fn)(pq_ctx *, const pq_batch *, const double *, int64_t, double *);
+// one adapter per exported function: `in` = the NIN device columns in the reference's input order
+typedef pq_status (*col_fn)(pq_ctx *, const pq_batch *, const double *const *in, int64_t timeperiod, double *out);
+struct PlugFn { const char *name; int nin; bool has_tp; int64_t default_tp; bool reject_nulls; col_fn call; };
 
-void run_ma(ma_fn fn, const char *fname, int64_t default_period, bool reject_nulls, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
-            size_t kwargs_len, pq_series_export *ret) {
-    if (ret) memset(ret, 0, sizeof *ret);
-    g_plugin_err.clear();
-    if (!inputs || n_inputs < 1 || !ret || !inputs[0].field || !inputs[0].field->format) { plugin_fail("plugin: bad arguments"); return; }
-    if (strcmp(inputs[0].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
-    // parameter: pickled kwargs first (overlap.rs:18-22), else the trailing literal input (overlap.py:36-43), else the default
-    int64_t period = default_period;
-    int64_t v = 0;
-    const int32_t kw = pq_plugin_kwargs_i64(kwargs, kwargs_len, "timeperiod", &v);
-    if (kw < 0) { plugin_fail("plugin: cannot parse the pickled kwargs"); return; }
-    if (kw == 1) period = v;
-    else if (n_inputs >= 2 && inputs[1].len >= 1 && inputs[1].arrays && inputs[1].arrays[0] && inputs[1].arrays[0]->length >= 1 &&
-             inputs[1].field && inputs[1].field->format) {
-        const ArrowArray *a = inputs[1].arrays[0];
-        const char *f = inputs[1].field->format;
-        const void *data = a->n_buffers >= 2 ? a->buffers[1] : nullptr;
-        if (data && !strcmp(f, "l")) period = ((const int64_t *)data)[a->offset];
-        else if (data && !strcmp(f, "i")) period = ((const int32_t *)data)[a->offset];
-        else if (data && !strcmp(f, "g")) period = (int64_t)((const double *)data)[a->offset];
-    }
-    // gather the chunks into one host column + one validity bitmap (a Polars Series may arrive in several chunks)
-    int64_t n = 0;
-    for (size_t c = 0; c < inputs[0].len; c++) n += inputs[0].arrays[c]->length;
-    OutPriv *op = new OutPriv();
-    op->values.resize((size_t)(n > 0 ? n : 1));
-    op->validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
-    std::vector<double> host((size_t)(n > 0 ? n : 1));
-    bool any_null = false;
+// gather the chunks of one exported Float64 Series into a host column + a validity bitmap (bit = 1: valid)
+bool gather_f64(const pq_series_export &in, int64_t n, std::vector<double> &host, std::vector<uint8_t> &validity, bool &any_null) {
+    host.resize((size_t)(n > 0 ? n : 1));
+    validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
     int64_t pos = 0;
-    for (size_t c = 0; c < inputs[0].len; c++) {
-        const ArrowArray *a = inputs[0].arrays[c];
-        if (a->n_buffers < 2 || (!a->buffers[1] && a->length)) { delete op; plugin_fail("plugin: malformed Float64 chunk"); return; }
+    for (size_t c = 0; c < in.len; c++) {
+        const ArrowArray *a = in.arrays[c];
+        if (a->n_buffers < 2 || (!a->buffers[1] && a->length)) return false;
         if (a->length) memcpy(host.data() + pos, (const double *)a->buffers[1] + a->offset, (size_t)a->length * 8);
         const uint8_t *vb = (const uint8_t *)a->buffers[0];
         if (vb && a->null_count != 0)
             for (int64_t i = 0; i < a->length; i++) {
                 const int64_t bi = a->offset + i;
-                if (!((vb[bi >> 3] >> (bi & 7)) & 1)) { op->validity[(size_t)((pos + i) >> 3)] &= (uint8_t)~(1u << ((pos + i) & 7)); any_null = true; }
+                if (!((vb[bi >> 3] >> (bi & 7)) & 1)) { validity[(size_t)((pos + i) >> 3)] &= (uint8_t)~(1u << ((pos + i) & 7)); any_null = true; }
             }
         pos += a->length;
     }
-    // the momentum family goes through rechunk().cont_slice()? in the reference (momentum.rs:12-13): a null is an error there
-    if (any_null && reject_nulls) { delete op; plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
+    return true;
+}
+int64_t series_len(const pq_series_export &in) {
+    int64_t n = 0;
+    for (size_t c = 0; c < in.len; c++) n += in.arrays[c]->length;
+    return n;
+}
+
+void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret) {
+    if (ret) memset(ret, 0, sizeof *ret);
+    g_plugin_err.clear();
+    if (!inputs || (int)n_inputs < f.nin || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
+    for (int k = 0; k < f.nin; k++) {
+        if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
+        if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+    }
+    // parameter: pickled kwargs first (overlap.rs:18-22), else the trailing literal input (overlap.py:36-43), else the default
+    int64_t period = f.default_tp;
+    if (f.has_tp) {
+        int64_t v = 0;
+        const int32_t kw = pq_plugin_kwargs_i64(kwargs, kwargs_len, "timeperiod", &v);
+        if (kw < 0) { plugin_fail("plugin: cannot parse the pickled kwargs"); return; }
+        const pq_series_export *lit = (int)n_inputs > f.nin ? &inputs[f.nin] : nullptr;
+        if (kw == 1) period = v;
+        else if (lit && lit->len >= 1 && lit->arrays && lit->arrays[0] && lit->arrays[0]->length >= 1 && lit->field && lit->field->format) {
+            const ArrowArray *a = lit->arrays[0];
+            const char *fm = lit->field->format;
+            const void *data = a->n_buffers >= 2 ? a->buffers[1] : nullptr;
+            if (data && !strcmp(fm, "l")) period = ((const int64_t *)data)[a->offset];
+            else if (data && !strcmp(fm, "i")) period = ((const int32_t *)data)[a->offset];
+            else if (data && !strcmp(fm, "g")) period = (int64_t)((const double *)data)[a->offset];
+        }
+    }
+    const int64_t n = series_len(inputs[0]);
+    for (int k = 1; k < f.nin; k++)
+        if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
+    std::vector<double> host[4];
+    std::vector<uint8_t> valid[4];
+    bool nulls[4] = {false, false, false, false}, any_null = false;
+    for (int k = 0; k < f.nin; k++) {
+        if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed Float64 chunk"); return; }
+        any_null |= nulls[k];
+    }
+    // the momentum / cycle families go through rechunk().cont_slice()? in the reference (momentum.rs:12-13): a null is an error there
+    if (any_null && f.reject_nulls) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
+    OutPriv *op = new OutPriv();
+    op->values.resize((size_t)(n > 0 ? n : 1));
+    op->validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
     int64_t null_count = 0;
     if (n > 0) {
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
-        void *d_in = nullptr, *d_out = nullptr, *d_bits = nullptr, *d_cnt = nullptr;
+        void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr, *d_bits = nullptr, *d_cnt = nullptr;
         const size_t nb = (size_t)((n + 7) / 8);
-        pq_status st = pq_malloc(ctx, (size_t)n * 8, &d_in);
-        if (st == PQ_OK) st = pq_malloc(ctx, (size_t)n * 8, &d_out);
+        pq_status st = pq_malloc(ctx, (size_t)n * 8, &d_out);
         if (st == PQ_OK) st = pq_malloc(ctx, nb, &d_bits);
         if (st == PQ_OK) st = pq_malloc(ctx, 8, &d_cnt);
-        if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in, host.data(), (size_t)n * 8);
-        if (st == PQ_OK && any_null) {
-            st = pq_memcpy_h2d(ctx, d_bits, op->validity.data(), nb);
-            if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in, (const uint8_t *)d_bits, 0, n);
+        for (int k = 0; k < f.nin && st == PQ_OK; k++) {
+            st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
+            if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
+            if (st == PQ_OK && nulls[k]) {
+                st = pq_memcpy_h2d(ctx, d_bits, valid[k].data(), nb);
+                if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in[k], (const uint8_t *)d_bits, 0, n);
+            }
         }
         const pq_batch b{1, n, n};
-        if (st == PQ_OK) st = fn(ctx, &b, (const double *)d_in, period, (double *)d_out);
+        const double *cols[4] = {(const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3]};
+        if (st == PQ_OK) st = f.call(ctx, &b, cols, period, (double *)d_out);
         if (st == PQ_OK) st = pq_validity_to_arrow(ctx, (const double *)d_out, n, (uint8_t *)d_bits, (int64_t *)d_cnt);
         if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->values.data(), d_out, (size_t)n * 8);
         if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->validity.data(), d_bits, nb);
         if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count, d_cnt, 8);
-        for (void *p : {d_in, d_out, d_bits, d_cnt}) if (p) (void)pq_free(ctx, p);
-        if (st != PQ_OK) { delete op; plugin_fail(fname); return; }
+        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_bits, d_cnt}) if (q) (void)pq_free(ctx, q);
+        if (st != PQ_OK) { delete op; plugin_fail(f.name); return; }
     }
     ArrowArray *arr = new ArrowArray();
     memset(arr, 0, sizeof *arr);
@@ -190,18 +216,37 @@ void field_f64(ArrowSchema *fields, size_t n_fields, ArrowSchema *ret) {
 extern "C" {
 uint32_t _polars_plugin_get_version(void) { return (0u << 16) | 1u; }
 const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_str(); }
-// every reference function of the shape (real[, timeperiod]) -> Float64: overlap.rs takes the period as pickled kwargs (MaKwargs,
-// overlap.rs:11-28), momentum.rs as a trailing literal input; run_ma accepts both.  X(name, default timeperiod, rejects nulls)
-#define PQ_PLUGIN_TP_FUNCS(X)                                                                                                  \
-    X(sma, 30, false) X(ema, 30, false) X(wma, 30, false) X(dema, 30, false) X(tema, 30, false) X(trima, 30, false)            \
-    X(kama, 30, false) X(midpoint, 14, false) X(rsi, 14, true) X(cmo, 14, true) X(mom, 10, true) X(roc, 10, true)              \
-    X(rocp, 10, true) X(rocr, 10, true) X(rocr100, 10, true) X(trix, 30, true)
-#define X(NAME, DEFAULT, NB)                                                                                                     \
+// Every reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64.  overlap.rs takes the period as pickled
+// kwargs (MaKwargs, overlap.rs:11-28), momentum.rs / volatility.rs as a trailing literal input; run_cols accepts both.
+// X(name, number of input columns, takes timeperiod (1/0), default timeperiod, rejects nulls (N-B family))
+#define PQ_PLUGIN_FUNCS(X)                                                                                                     \
+    X(sma, 1, 1, 30, false) X(ema, 1, 1, 30, false) X(wma, 1, 1, 30, false) X(dema, 1, 1, 30, false) X(tema, 1, 1, 30, false)    \
+    X(trima, 1, 1, 30, false) X(kama, 1, 1, 30, false) X(midpoint, 1, 1, 14, false) X(rsi, 1, 1, 14, true) X(cmo, 1, 1, 14, true) \
+    X(mom, 1, 1, 10, true) X(roc, 1, 1, 10, true) X(rocp, 1, 1, 10, true) X(rocr, 1, 1, 10, true) X(rocr100, 1, 1, 10, true)      \
+    X(trix, 1, 1, 30, true) X(ht_dcperiod, 1, 0, 0, true) X(ht_dcphase, 1, 0, 0, true) X(ht_trendline, 1, 0, 0, true)             \
+    X(midprice, 2, 1, 14, false) X(plus_dm, 2, 1, 14, true) X(minus_dm, 2, 1, 14, true) X(aroonosc, 2, 1, 14, true)              \
+    X(medprice, 2, 0, 0, false) X(obv, 2, 0, 0, false)                                                                           \
+    X(adx, 3, 1, 14, true) X(adxr, 3, 1, 14, true) X(dx, 3, 1, 14, true) X(plus_di, 3, 1, 14, true) X(minus_di, 3, 1, 14, true)   \
+    X(cci, 3, 1, 14, true) X(willr, 3, 1, 14, true) X(atr, 3, 1, 14, false) X(natr, 3, 1, 14, false) X(trange, 3, 0, 0, false)    \
+    X(typprice, 3, 0, 0, false) X(wclprice, 3, 0, 0, false)                                                                      \
+    X(mfi, 4, 1, 14, true) X(bop, 4, 0, 0, true) X(ad, 4, 0, 0, false) X(avgprice, 4, 0, 0, false)
+#define PQ_ARGS_1(in) in[0]
+#define PQ_ARGS_2(in) in[0], in[1]
+#define PQ_ARGS_3(in) in[0], in[1], in[2]
+#define PQ_ARGS_4(in) in[0], in[1], in[2], in[3]
+#define PQ_CALL_1(NAME, NIN) pq_##NAME(ctx, b, PQ_ARGS_##NIN(in), tp, out)
+#define PQ_CALL_0(NAME, NIN) pq_##NAME(ctx, b, PQ_ARGS_##NIN(in), out)
+#define X(NAME, NIN, HAS_TP, DEFAULT, NB)                                                                                      \
+    static pq_status plug_call_##NAME(pq_ctx *ctx, const pq_batch *b, const double *const *in, int64_t tp, double *out) {       \
+        (void)tp;                                                                                                              \
+        return PQ_CALL_##HAS_TP(NAME, NIN);                                                                                    \
+    }                                                                                                                          \
     void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
                                pq_series_export *ret, void *) {                                                                \
-        run_ma(&pq_##NAME, "pq_" #NAME, DEFAULT, NB, inputs, n_inputs, kwargs, kwargs_len, ret);                                  \
+        static const PlugFn f = {"pq_" #NAME, NIN, HAS_TP != 0, DEFAULT, NB, &plug_call_##NAME};                               \
+        run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);                                                                \
     }                                                                                                                          \
     void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
-PQ_PLUGIN_TP_FUNCS(X)
+PQ_PLUGIN_FUNCS(X)
 #undef X
 }

@@ -29,9 +29,12 @@ class SeriesExport(C.Structure):
                 ("private_data", C.c_void_p)]
 
 
-# every reference function of the shape (real[, timeperiod]) -> Float64 has a plugin symbol pair: name -> default timeperiod
-TP_FUNCS = {"sma": 30, "ema": 30, "wma": 30, "dema": 30, "tema": 30, "trima": 30, "kama": 30, "midpoint": 14, "rsi": 14, "cmo": 14,
-            "mom": 10, "roc": 10, "rocp": 10, "rocr": 10, "rocr100": 10, "trix": 30}
+# every reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64 has a plugin symbol pair
+PLUGIN_FUNCS = ["sma", "ema", "wma", "dema", "tema", "trima", "kama", "midpoint", "rsi", "cmo", "mom", "roc", "rocp", "rocr", "rocr100",
+                "trix", "ht_dcperiod", "ht_dcphase", "ht_trendline", "midprice", "plus_dm", "minus_dm", "aroonosc", "medprice", "obv",
+                "adx", "adxr", "dx", "plus_di", "minus_di", "cci", "willr", "atr", "natr", "trange", "typprice", "wclprice", "mfi", "bop",
+                "ad", "avgprice"]
+TP_FUNCS = PLUGIN_FUNCS   # (name kept for the argtypes loops below)
 
 
 def _lib():
@@ -64,7 +67,7 @@ def test_plugin_symbols_and_version():
         if n != "NAME":                                           # (the macro's own parameter)
             declared |= {"_polars_plugin_" + n, "_polars_plugin_field_" + n}
     declared = {n for n in declared if "##" not in n and not n.endswith("_")}
-    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in TP_FUNCS}
+    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in PLUGIN_FUNCS}
     declared = sorted(declared)
     assert {"_polars_plugin_get_version", "_polars_plugin_get_last_error_message", "_polars_plugin_ema", "_polars_plugin_field_ema"} <= set(declared)
     L = _lib()
@@ -156,46 +159,66 @@ def test_plugin_calls_match_the_oracle(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(TP_FUNCS))
-def test_every_timeperiod_function_through_its_plugin_symbol(oracle, name):
-    """Each exported pair: default period (no kwargs, no literal), pickled kwargs, trailing literal -- against the oracle on a
-    two-chunk column; null-bearing for the overlap functions, null-free for the momentum family, which must REFUSE a null like
-    the reference's rechunk().cont_slice()? (momentum.rs:12-13)."""
+@pytest.mark.parametrize("name", sorted(PLUGIN_FUNCS))
+def test_every_exported_function_through_its_plugin_symbol(oracle, name):
+    """Each exported pair: default period (no kwargs, no literal), pickled kwargs, trailing literal -- against the oracle on
+    two-chunk columns; null-bearing where the reference accepts nulls, null-free for the momentum / cycle family, which must
+    REFUSE a null like the reference's rechunk().cont_slice()? (momentum.rs:12-13)."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    L = _lib()
-    d = oracle.gen_ohlcv(0x5EED000C, 1, 400, 0)
-    x = d["close"][0]
     from polars_quant_amd._spec import SPEC
-    rejects = SPEC[name][3] == "N-B"
+    L = _lib()
+    cols, params, _outs, fam = SPEC[name]
+    has_tp, default = len(params) == 1, (params[0][2] if params else None)
+    d = oracle.gen_ohlcv(0x5EED000C, 1, 400, 0)
+    data = {c: d["close" if c == "real" else c][0] for c in cols}
     mask = np.zeros(400, bool); mask[[5, 6, 200]] = True
     fn = getattr(L, "_polars_plugin_" + name)
-    if rejects:
-        se, keep = _export([pa.array(x, mask=mask)], "close")
-        ret = SeriesExport(); fn(C.byref(se), 1, None, 0, C.byref(ret), None)
+    nullcol = cols[-1] if cols[-1] != "volume" else cols[-2]    # the nulls sit in one column (the last price column)
+
+    def export(msk):
+        keep, ses = [], []
+        for c in cols:
+            arr = pa.array(data[c], mask=msk if c == nullcol else None)
+            se, k = _export([arr.slice(0, 150), arr.slice(150)], c)
+            ses.append(se); keep.append(k)
+        return ses, keep
+
+    if fam == "N-B":
+        ses, keep = export(mask)
+        ins = (SeriesExport * len(ses))(*ses)
+        ret = SeriesExport(); fn(ins, len(ses), None, 0, C.byref(ret), None)
         assert not ret.release and b"nulls" in L._polars_plugin_get_last_error_message()
         mask[:] = False
-    xn = x.copy(); xn[mask] = oracle.NULL
-    whole = pa.array(x, mask=mask)
+    ref_in = {c: data[c].copy() for c in cols}
+    ref_in[nullcol][mask] = oracle.NULL
 
     def check(ret, period):
         assert ret.release, L._polars_plugin_get_last_error_message()
         got = _import(ret)
-        (exp,) = oracle.call(name, xn, timeperiod=period)
+        kw = {"timeperiod": period} if has_tp else {}
+        (exp,) = oracle.call(name, *[ref_in[c] for c in cols], **kw)
         en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
         assert (np.asarray(got.is_null()) == en).all(), name
-        assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all(), name
+        g = got.to_numpy(zero_copy_only=False)[~en]
+        if name in ("ht_dcperiod", "ht_dcphase"):           # transcendental class
+            np.testing.assert_allclose(g, exp[~en], rtol=1e-12, atol=1e-12)
+        else:
+            assert (g.view(np.uint64) == exp[~en].view(np.uint64)).all(), name
 
-    se, keep = _export([whole.slice(0, 150), whole.slice(150)], "close")
-    ret = SeriesExport(); fn(C.byref(se), 1, None, 0, C.byref(ret), None); check(ret, TP_FUNCS[name])
-    se, keep = _export([whole.slice(0, 150), whole.slice(150)], "close")
-    kw = pickle.dumps({"timeperiod": 9})
-    ret = SeriesExport(); fn(C.byref(se), 1, kw, len(kw), C.byref(ret), None); check(ret, 9)
-    se0, keep0 = _export([whole], "close")
-    se1, keep1 = _export([pa.array([21], type=pa.int64())], "literal")
-    ins = (SeriesExport * 2)(se0, se1)
-    ret = SeriesExport(); fn(ins, 2, None, 0, C.byref(ret), None); check(ret, 21)
+    ses, keep = export(mask)
+    ins = (SeriesExport * len(ses))(*ses)
+    ret = SeriesExport(); fn(ins, len(ses), None, 0, C.byref(ret), None); check(ret, default)
+    if has_tp:
+        ses, keep = export(mask)
+        ins = (SeriesExport * len(ses))(*ses)
+        kw = pickle.dumps({"timeperiod": 9})
+        ret = SeriesExport(); fn(ins, len(ses), kw, len(kw), C.byref(ret), None); check(ret, 9)
+        ses, keep = export(mask)
+        se1, keep1 = _export([pa.array([21], type=pa.int64())], "literal")
+        ins = (SeriesExport * (len(ses) + 1))(*ses, se1)
+        ret = SeriesExport(); fn(ins, len(ses) + 1, None, 0, C.byref(ret), None); check(ret, 21)
     out_field = ArrowSchema()
-    getattr(L, "_polars_plugin_field_" + name)(se0.field, 1, C.byref(out_field), None, 0)
-    assert out_field.format == b"g" and out_field.name == b"close"
+    getattr(L, "_polars_plugin_field_" + name)(ses[0].field, 1, C.byref(out_field), None, 0)
+    assert out_field.format == b"g" and out_field.name == cols[0].encode()
