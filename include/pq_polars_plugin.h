@@ -54,7 +54,7 @@ const char *_polars_plugin_get_last_error_message(void);        /* thread-local,
  *       (release != NULL), left zeroed on failure with the message in _polars_plugin_get_last_error_message().  A null in the
  *       input of a function that goes through `rechunk().cont_slice()?` in the reference (momentum / cycle family) is such a failure.
  *   _polars_plugin_field_<f>(fields, n_fields, return_value, kwargs, kwargs_len)
- *       output field: the first input's name, Float64 (`#[polars_expr(output_type=Float64)]`)
+ *       output field: the first input's name, Float64 (`#[polars_expr(output_type=Float64)]`; Int32 for the patterns)
  * reference: overlap.rs:494 sma, :127 ema, :531 wma, :119 dema, :513 tema, :522 trima, :137 kama, :180 midpoint, :281 midprice;
  *   momentum.rs:507 rsi, :181 cmo, :384 mom, :439 roc, :456 rocp, :473 rocr, :490 rocr100, :544 trix, :11 adx, :32 adxr, :226 dx,
  *   :400 plus_di, :345 minus_di, :414 plus_dm, :359 minus_dm, :113 bop, :138 cci, :286 mfi, :630 willr;
@@ -75,6 +75,26 @@ PQ_PLUGIN_DECL(aroonosc) PQ_PLUGIN_DECL(medprice) PQ_PLUGIN_DECL(obv) PQ_PLUGIN_
 PQ_PLUGIN_DECL(plus_di) PQ_PLUGIN_DECL(minus_di) PQ_PLUGIN_DECL(cci) PQ_PLUGIN_DECL(willr) PQ_PLUGIN_DECL(atr) PQ_PLUGIN_DECL(natr)
 PQ_PLUGIN_DECL(trange) PQ_PLUGIN_DECL(typprice) PQ_PLUGIN_DECL(wclprice) PQ_PLUGIN_DECL(mfi) PQ_PLUGIN_DECL(bop) PQ_PLUGIN_DECL(ad)
 PQ_PLUGIN_DECL(avgprice)
+
+/* the 61 candlestick recognisers (pattern.rs:10-2062): inputs open, high, low, close[, penetration as a Float64 literal, default 0.3];
+ * Int32 output, never null; a null in an input is an error (cont_slice) */
+PQ_PLUGIN_DECL(cdl2crows) PQ_PLUGIN_DECL(cdl3blackcrows) PQ_PLUGIN_DECL(cdl3inside) PQ_PLUGIN_DECL(cdl3linestrike)
+PQ_PLUGIN_DECL(cdl3outside) PQ_PLUGIN_DECL(cdl3starsinsouth) PQ_PLUGIN_DECL(cdl3whitesoldiers)
+PQ_PLUGIN_DECL(cdlabandonedbaby) PQ_PLUGIN_DECL(cdladvanceblock) PQ_PLUGIN_DECL(cdlbelthold) PQ_PLUGIN_DECL(cdlbreakaway)
+PQ_PLUGIN_DECL(cdlclosingmarubozu) PQ_PLUGIN_DECL(cdlconcealbabyswall) PQ_PLUGIN_DECL(cdlcounterattack)
+PQ_PLUGIN_DECL(cdldarkcloudcover) PQ_PLUGIN_DECL(cdldoji) PQ_PLUGIN_DECL(cdldojistar) PQ_PLUGIN_DECL(cdldragonflydoji)
+PQ_PLUGIN_DECL(cdlengulfing) PQ_PLUGIN_DECL(cdleveningdojistar) PQ_PLUGIN_DECL(cdleveningstar)
+PQ_PLUGIN_DECL(cdlgapsidesidewhite) PQ_PLUGIN_DECL(cdlgravestonedoji) PQ_PLUGIN_DECL(cdlhammer)
+PQ_PLUGIN_DECL(cdlhangingman) PQ_PLUGIN_DECL(cdlharami) PQ_PLUGIN_DECL(cdlharamicross) PQ_PLUGIN_DECL(cdlhighwave)
+PQ_PLUGIN_DECL(cdlhikkake) PQ_PLUGIN_DECL(cdlhikkakemod) PQ_PLUGIN_DECL(cdlhomingpigeon) PQ_PLUGIN_DECL(cdlidentical3crows)
+PQ_PLUGIN_DECL(cdlinneck) PQ_PLUGIN_DECL(cdlinvertedhammer) PQ_PLUGIN_DECL(cdlkicking) PQ_PLUGIN_DECL(cdlkickingbylength)
+PQ_PLUGIN_DECL(cdlladderbottom) PQ_PLUGIN_DECL(cdllongleggeddoji) PQ_PLUGIN_DECL(cdllongline) PQ_PLUGIN_DECL(cdlmarubozu)
+PQ_PLUGIN_DECL(cdlmatchinglow) PQ_PLUGIN_DECL(cdlmathold) PQ_PLUGIN_DECL(cdlmorningdojistar) PQ_PLUGIN_DECL(cdlmorningstar)
+PQ_PLUGIN_DECL(cdlonneck) PQ_PLUGIN_DECL(cdlpiercing) PQ_PLUGIN_DECL(cdlrickshawman) PQ_PLUGIN_DECL(cdlrisefall3methods)
+PQ_PLUGIN_DECL(cdlseparatinglines) PQ_PLUGIN_DECL(cdlshootingstar) PQ_PLUGIN_DECL(cdlshortline)
+PQ_PLUGIN_DECL(cdlspinningtop) PQ_PLUGIN_DECL(cdlstalledpattern) PQ_PLUGIN_DECL(cdlsticksandwich) PQ_PLUGIN_DECL(cdltakuri)
+PQ_PLUGIN_DECL(cdltasukigap) PQ_PLUGIN_DECL(cdlthrusting) PQ_PLUGIN_DECL(cdltristar) PQ_PLUGIN_DECL(cdlunique3river)
+PQ_PLUGIN_DECL(cdlupsidegap2crows) PQ_PLUGIN_DECL(cdlxsidegap3methods)
 
 /* host-only helper behind the kwargs path (CPU-testable): the int64 value of `key` in a pickled dict of scalars.
  * returns 1 found, 0 absent or None, -1 malformed / unsupported pickle */

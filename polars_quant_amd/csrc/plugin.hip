@@ -80,13 +80,13 @@ extern "C" int32_t pq_plugin_kwargs_i64(const uint8_t *pickle, size_t len, const
 
 // ---- export side: one Float64 chunk owning its two buffers
 namespace {
-struct OutPriv { std::vector<uint8_t> validity; std::vector<double> values; const void *bufs[2]; std::string name; };
+struct OutPriv { std::vector<uint8_t> validity; std::vector<double> values; std::vector<int32_t> ivalues; const void *bufs[2]; std::string name; };
 void release_array(ArrowArray *a) { if (a && a->release) { delete (OutPriv *)a->private_data; a->release = nullptr; } }
 void release_schema(ArrowSchema *s) { if (s && s->release) { delete (std::string *)s->private_data; s->release = nullptr; } }
-void fill_schema(ArrowSchema *s, const std::string &name) {
+void fill_schema(ArrowSchema *s, const std::string &name, const char *format = "g") {
     std::string *keep = new std::string(name);
     memset(s, 0, sizeof *s);
-    s->format = "g"; s->name = keep->c_str(); s->flags = 2 /* ARROW_FLAG_NULLABLE */; s->release = release_schema; s->private_data = keep;
+    s->format = format; s->name = keep->c_str(); s->flags = 2 /* ARROW_FLAG_NULLABLE */; s->release = release_schema; s->private_data = keep;
 }
 void release_series(pq_series_export *e) {
     if (!e || !e->release) return;
@@ -207,6 +207,62 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     ret->len = 1;
     ret->release = release_series;
 }
+// the 61 candlestick recognisers: (open, high, low, close[, penetration literal]) -> Int32, never null (pattern.rs:10-2062; inputs go
+// through cont_slice(): a null is an error; penetration = inputs.get(4) as f64, default 0.3, pattern.rs:529-532)
+void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_series_export *ret) {
+    if (ret) memset(ret, 0, sizeof *ret);
+    g_plugin_err.clear();
+    if (!inputs || n_inputs < 4 || !ret) { plugin_fail("plugin: bad arguments (open, high, low, close expected)"); return; }
+    for (int k = 0; k < 4; k++) {
+        if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
+        if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+    }
+    double pen = 0.3;
+    if (n_inputs >= 5 && inputs[4].len >= 1 && inputs[4].arrays && inputs[4].arrays[0] && inputs[4].arrays[0]->length >= 1 && inputs[4].field &&
+        inputs[4].field->format && !strcmp(inputs[4].field->format, "g") && inputs[4].arrays[0]->n_buffers >= 2 && inputs[4].arrays[0]->buffers[1])
+        pen = ((const double *)inputs[4].arrays[0]->buffers[1])[inputs[4].arrays[0]->offset];
+    const int64_t n = series_len(inputs[0]);
+    std::vector<double> host[4];
+    std::vector<uint8_t> valid;
+    bool any_null = false;
+    for (int k = 0; k < 4; k++) {
+        if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
+        if (!gather_f64(inputs[k], n, host[k], valid, any_null)) { plugin_fail("plugin: malformed Float64 chunk"); return; }
+    }
+    if (any_null) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
+    OutPriv *op = new OutPriv();
+    op->ivalues.resize((size_t)(n > 0 ? n : 1));
+    if (n > 0) {
+        pq_ctx *ctx = plugin_ctx();
+        if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
+        void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
+        pq_status st = pq_malloc(ctx, (size_t)n * 4, &d_out);
+        for (int k = 0; k < 4 && st == PQ_OK; k++) {
+            st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
+            if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
+        }
+        const pq_batch b{1, n, n};
+        if (st == PQ_OK) st = pq_cdl(ctx, &b, id, (const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3], pen, (int32_t *)d_out);
+        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->ivalues.data(), d_out, (size_t)n * 4);
+        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out}) if (q) (void)pq_free(ctx, q);
+        if (st != PQ_OK) { delete op; plugin_fail("pq_cdl"); return; }
+    }
+    ArrowArray *arr = new ArrowArray();
+    memset(arr, 0, sizeof *arr);
+    op->bufs[0] = nullptr;
+    op->bufs[1] = op->ivalues.data();
+    arr->length = n; arr->null_count = 0; arr->n_buffers = 2; arr->buffers = op->bufs; arr->release = release_array; arr->private_data = op;
+    ret->field = new ArrowSchema();
+    fill_schema(ret->field, inputs[0].field->name ? inputs[0].field->name : "", "i");
+    ret->arrays = new ArrowArray *[1];
+    ret->arrays[0] = arr;
+    ret->len = 1;
+    ret->release = release_series;
+}
+void field_i32(ArrowSchema *fields, size_t n_fields, ArrowSchema *ret) {
+    if (!ret) return;
+    fill_schema(ret, (fields && n_fields >= 1 && fields[0].name) ? fields[0].name : "", "i");
+}
 void field_f64(ArrowSchema *fields, size_t n_fields, ArrowSchema *ret) {
     if (!ret) return;
     fill_schema(ret, (fields && n_fields >= 1 && fields[0].name) ? fields[0].name : "");
@@ -248,5 +304,27 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_
     }                                                                                                                          \
     void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
 PQ_PLUGIN_FUNCS(X)
+#undef X
+// the 61 recognisers in id order (pq_pattern_name)
+#define PQ_PLUGIN_PATTERNS(X) \
+    X(cdl2crows, 0) X(cdl3blackcrows, 1) X(cdl3inside, 2) X(cdl3linestrike, 3) X(cdl3outside, 4) X(cdl3starsinsouth, 5) \
+    X(cdl3whitesoldiers, 6) X(cdlabandonedbaby, 7) X(cdladvanceblock, 8) X(cdlbelthold, 9) X(cdlbreakaway, 10) \
+    X(cdlclosingmarubozu, 11) X(cdlconcealbabyswall, 12) X(cdlcounterattack, 13) X(cdldarkcloudcover, 14) \
+    X(cdldoji, 15) X(cdldojistar, 16) X(cdldragonflydoji, 17) X(cdlengulfing, 18) X(cdleveningdojistar, 19) \
+    X(cdleveningstar, 20) X(cdlgapsidesidewhite, 21) X(cdlgravestonedoji, 22) X(cdlhammer, 23) X(cdlhangingman, 24) \
+    X(cdlharami, 25) X(cdlharamicross, 26) X(cdlhighwave, 27) X(cdlhikkake, 28) X(cdlhikkakemod, 29) \
+    X(cdlhomingpigeon, 30) X(cdlidentical3crows, 31) X(cdlinneck, 32) X(cdlinvertedhammer, 33) X(cdlkicking, 34) \
+    X(cdlkickingbylength, 35) X(cdlladderbottom, 36) X(cdllongleggeddoji, 37) X(cdllongline, 38) X(cdlmarubozu, 39) \
+    X(cdlmatchinglow, 40) X(cdlmathold, 41) X(cdlmorningdojistar, 42) X(cdlmorningstar, 43) X(cdlonneck, 44) \
+    X(cdlpiercing, 45) X(cdlrickshawman, 46) X(cdlrisefall3methods, 47) X(cdlseparatinglines, 48) \
+    X(cdlshootingstar, 49) X(cdlshortline, 50) X(cdlspinningtop, 51) X(cdlstalledpattern, 52) X(cdlsticksandwich, 53) \
+    X(cdltakuri, 54) X(cdltasukigap, 55) X(cdlthrusting, 56) X(cdltristar, 57) X(cdlunique3river, 58) \
+    X(cdlupsidegap2crows, 59) X(cdlxsidegap3methods, 60)
+#define X(NAME, ID)                                                                                                            \
+    void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *, size_t, pq_series_export *ret, void *) { \
+        run_pattern(ID, inputs, n_inputs, ret);                                                                                \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_i32(fields, n, ret); }
+PQ_PLUGIN_PATTERNS(X)
 #undef X
 }

@@ -50,10 +50,11 @@ def _lib():
     L._polars_plugin_get_version.restype = C.c_uint32
     L._polars_plugin_get_last_error_message.restype = C.c_char_p
     L.pq_plugin_kwargs_i64.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int64)]
-    for f in ("_polars_plugin_" + n for n in TP_FUNCS):
+    from polars_quant_amd._spec import PATTERN_NAMES
+    for f in ("_polars_plugin_" + n for n in list(TP_FUNCS) + list(PATTERN_NAMES)):
         getattr(L, f).argtypes = [C.POINTER(SeriesExport), C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(SeriesExport), C.c_void_p]
         getattr(L, f).restype = None
-    for f in ("_polars_plugin_field_" + n for n in TP_FUNCS):
+    for f in ("_polars_plugin_field_" + n for n in list(TP_FUNCS) + list(PATTERN_NAMES)):
         getattr(L, f).argtypes = [C.POINTER(ArrowSchema), C.c_size_t, C.POINTER(ArrowSchema), C.c_char_p, C.c_size_t]
         getattr(L, f).restype = None
     return L
@@ -67,7 +68,8 @@ def test_plugin_symbols_and_version():
         if n != "NAME":                                           # (the macro's own parameter)
             declared |= {"_polars_plugin_" + n, "_polars_plugin_field_" + n}
     declared = {n for n in declared if "##" not in n and not n.endswith("_")}
-    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in PLUGIN_FUNCS}
+    from polars_quant_amd._spec import PATTERN_NAMES
+    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in list(PLUGIN_FUNCS) + list(PATTERN_NAMES)}
     declared = sorted(declared)
     assert {"_polars_plugin_get_version", "_polars_plugin_get_last_error_message", "_polars_plugin_ema", "_polars_plugin_field_ema"} <= set(declared)
     L = _lib()
@@ -222,3 +224,50 @@ def test_every_exported_function_through_its_plugin_symbol(oracle, name):
     out_field = ArrowSchema()
     getattr(L, "_polars_plugin_field_" + name)(ses[0].field, 1, C.byref(out_field), None, 0)
     assert out_field.format == b"g" and out_field.name == cols[0].encode()
+
+
+@pytest.mark.gpu
+def test_every_pattern_through_its_plugin_symbol(oracle):
+    """The 61 recognisers: (open, high, low, close) in two chunks -> Int32, penetration default 0.3 (pattern.rs:529-532) and as a
+    Float64 literal; a null is refused (cont_slice)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from polars_quant_amd._spec import PATTERN_NAMES
+    L = _lib()
+    d = oracle.gen_ohlcv(0x5EED0005, 1, 600, 1)             # the pattern-rich variant of the generator
+    cols = ("open", "high", "low", "close")
+    fired = 0
+    for name in PATTERN_NAMES:
+        fn = getattr(L, "_polars_plugin_" + name)
+        for pen in (None, 0.5):
+            ses, keep = [], []
+            for c in cols:
+                arr = pa.array(d[c][0])
+                se, k = _export([arr.slice(0, 250), arr.slice(250)], c)
+                ses.append(se); keep.append(k)
+            if pen is not None:
+                se, k = _export([pa.array([pen], type=pa.float64())], "literal")
+                ses.append(se); keep.append(k)
+            ins = (SeriesExport * len(ses))(*ses)
+            ret = SeriesExport(); fn(ins, len(ses), None, 0, C.byref(ret), None)
+            assert ret.release, L._polars_plugin_get_last_error_message()
+            assert ret.field.contents.format == b"i" and ret.field.contents.name == b"open"
+            arr_out = _import(ret)
+            assert arr_out.type == pa.int32() and arr_out.null_count == 0 and len(arr_out) == 600
+            got = arr_out.to_numpy()
+            exp = oracle.pattern(name, d["open"][0], d["high"][0], d["low"][0], d["close"][0], penetration=0.3 if pen is None else pen)
+            assert (got == exp.reshape(-1)).all(), (name, pen)
+            fired += int((got != 0).any())
+    assert fired >= 70          # (two runs per recogniser; a single 600-row series does not trigger the rarest ones)
+    # a null anywhere is an error, as in the reference
+    ses, keep = [], []
+    for c in cols:
+        m = np.zeros(600, bool); m[17] = c == "low"
+        se, k = _export([pa.array(d[c][0], mask=m)], c); ses.append(se); keep.append(k)
+    ins = (SeriesExport * 4)(*ses)
+    ret = SeriesExport(); L._polars_plugin_cdldoji(ins, 4, None, 0, C.byref(ret), None)
+    assert not ret.release and b"nulls" in L._polars_plugin_get_last_error_message()
+    out_field = ArrowSchema()
+    L._polars_plugin_field_cdldoji(ses[0].field, 1, C.byref(out_field), None, 0)
+    assert out_field.format == b"i"
