@@ -76,6 +76,15 @@ PQ_PLUGIN_DECL(plus_di) PQ_PLUGIN_DECL(minus_di) PQ_PLUGIN_DECL(cci) PQ_PLUGIN_D
 PQ_PLUGIN_DECL(trange) PQ_PLUGIN_DECL(typprice) PQ_PLUGIN_DECL(wclprice) PQ_PLUGIN_DECL(mfi) PQ_PLUGIN_DECL(bop) PQ_PLUGIN_DECL(ad)
 PQ_PLUGIN_DECL(avgprice)
 
+/* functions with other scalar parameters: each from the pickled kwargs by name, else from its trailing literal input (in this order),
+ * else the reference's default.  ma(timeperiod 30, matype 0) overlap.rs:146; t3(timeperiod 5, vfactor 0.0) :503;
+ * sar(acceleration 0.0, maximum 0.0) :437; sarext(startvalue, offsetonreverse, accelerationinitlong, accelerationlong,
+ * accelerationmaxlong, accelerationinitshort, accelerationshort, accelerationmaxshort: all 0.0) :457;
+ * ultosc(timeperiod1 7, timeperiod2 14, timeperiod3 28) momentum.rs:572; adosc(fastperiod 3, slowperiod 10) volume.rs:34;
+ * ht_trendmode -> Int32 cycle.rs:377 */
+PQ_PLUGIN_DECL(ma) PQ_PLUGIN_DECL(t3) PQ_PLUGIN_DECL(ultosc) PQ_PLUGIN_DECL(adosc) PQ_PLUGIN_DECL(sar) PQ_PLUGIN_DECL(sarext)
+PQ_PLUGIN_DECL(ht_trendmode)
+
 /* the 61 candlestick recognisers (pattern.rs:10-2062): inputs open, high, low, close[, penetration as a Float64 literal, default 0.3];
  * Int32 output, never null; a null in an input is an error (cont_slice) */
 PQ_PLUGIN_DECL(cdl2crows) PQ_PLUGIN_DECL(cdl3blackcrows) PQ_PLUGIN_DECL(cdl3inside) PQ_PLUGIN_DECL(cdl3linestrike)

@@ -78,6 +78,20 @@ extern "C" int32_t pq_plugin_kwargs_i64(const uint8_t *pickle, size_t len, const
     return 0;
 }
 
+// 1 found (value as double: ints up to 2^53 are exact), 0 absent or None, -1 malformed
+static int kwargs_scalar(const uint8_t *pickle, size_t len, const char *key, double *out) {
+    if (!pickle || !len) return 0;
+    std::vector<std::pair<std::string, PVal>> items;
+    if (!pickle_scalars(pickle, len, items)) return -1;
+    for (auto &kv : items)
+        if (kv.first == key) {
+            if (kv.second.kind == PVal::INT) { *out = (double)kv.second.i; return 1; }
+            if (kv.second.kind == PVal::FLOAT) { *out = kv.second.f; return 1; }
+            return 0;
+        }
+    return 0;
+}
+
 // ---- export side: one Float64 chunk owning its two buffers
 namespace {
 struct OutPriv { std::vector<uint8_t> validity; std::vector<double> values; std::vector<int32_t> ivalues; const void *bufs[2]; std::string name; };
@@ -100,8 +114,10 @@ pq_ctx *plugin_ctx() { // one context per host thread (Polars calls plugins from
     return c;
 }
 // one adapter per exported function: `in` = the NIN device columns in the reference's input order
-typedef pq_status (*col_fn)(pq_ctx *, const pq_batch *, const double *const *in, int64_t timeperiod, double *out);
-struct PlugFn { const char *name; int nin; bool has_tp; int64_t default_tp; bool reject_nulls; col_fn call; };
+// pv = the scalar parameters in the reference's order (integers as exact doubles)
+typedef pq_status (*col_fn)(pq_ctx *, const pq_batch *, const double *const *in, const double *pv, void *out);
+struct PParam { const char *name; bool is_float; double def; };
+struct PlugFn { const char *name; int nin; int nparams; PParam params[8]; bool reject_nulls; bool out_i32; col_fn call; };
 
 // gather the chunks of one exported Float64 Series into a host column + a validity bitmap (bit = 1: valid)
 bool gather_f64(const pq_series_export &in, int64_t n, std::vector<double> &host, std::vector<uint8_t> &validity, bool &any_null) {
@@ -136,22 +152,29 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
         if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
     }
-    // parameter: pickled kwargs first (overlap.rs:18-22), else the trailing literal input (overlap.py:36-43), else the default
-    int64_t period = f.default_tp;
-    if (f.has_tp) {
-        int64_t v = 0;
-        const int32_t kw = pq_plugin_kwargs_i64(kwargs, kwargs_len, "timeperiod", &v);
+    // every parameter: pickled kwargs first (overlap.rs:18-22), else its trailing literal input (overlap.py:36-43; momentum.rs reads
+    // inputs[nin + k] in declaration order), else the reference's default
+    double pv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < f.nparams; k++) {
+        pv[k] = f.params[k].def;
+        double v = 0.0;
+        const int kw = kwargs_scalar(kwargs, kwargs_len, f.params[k].name, &v);
         if (kw < 0) { plugin_fail("plugin: cannot parse the pickled kwargs"); return; }
-        const pq_series_export *lit = (int)n_inputs > f.nin ? &inputs[f.nin] : nullptr;
-        if (kw == 1) period = v;
+        const pq_series_export *lit = (int)n_inputs > f.nin + k ? &inputs[f.nin + k] : nullptr;
+        if (kw == 1) pv[k] = v;
         else if (lit && lit->len >= 1 && lit->arrays && lit->arrays[0] && lit->arrays[0]->length >= 1 && lit->field && lit->field->format) {
             const ArrowArray *a = lit->arrays[0];
             const char *fm = lit->field->format;
             const void *data = a->n_buffers >= 2 ? a->buffers[1] : nullptr;
-            if (data && !strcmp(fm, "l")) period = ((const int64_t *)data)[a->offset];
-            else if (data && !strcmp(fm, "i")) period = ((const int32_t *)data)[a->offset];
-            else if (data && !strcmp(fm, "g")) period = (int64_t)((const double *)data)[a->offset];
+            const uint8_t *vb = a->n_buffers >= 1 ? (const uint8_t *)a->buffers[0] : nullptr;
+            const bool is_null = vb && a->null_count != 0 && !((vb[a->offset >> 3] >> (a->offset & 7)) & 1); // a null literal = the default
+            if (data && !is_null) {
+                if (!strcmp(fm, "l")) pv[k] = (double)((const int64_t *)data)[a->offset];
+                else if (!strcmp(fm, "i")) pv[k] = (double)((const int32_t *)data)[a->offset];
+                else if (!strcmp(fm, "g")) pv[k] = ((const double *)data)[a->offset];
+            }
         }
+        if (!f.params[k].is_float) pv[k] = (double)(int64_t)pv[k];
     }
     const int64_t n = series_len(inputs[0]);
     for (int k = 1; k < f.nin; k++)
@@ -166,7 +189,7 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     // the momentum / cycle families go through rechunk().cont_slice()? in the reference (momentum.rs:12-13): a null is an error there
     if (any_null && f.reject_nulls) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
     OutPriv *op = new OutPriv();
-    op->values.resize((size_t)(n > 0 ? n : 1));
+    if (f.out_i32) op->ivalues.resize((size_t)(n > 0 ? n : 1)); else op->values.resize((size_t)(n > 0 ? n : 1));
     op->validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
     int64_t null_count = 0;
     if (n > 0) {
@@ -187,28 +210,33 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
         }
         const pq_batch b{1, n, n};
         const double *cols[4] = {(const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3]};
-        if (st == PQ_OK) st = f.call(ctx, &b, cols, period, (double *)d_out);
-        if (st == PQ_OK) st = pq_validity_to_arrow(ctx, (const double *)d_out, n, (uint8_t *)d_bits, (int64_t *)d_cnt);
-        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->values.data(), d_out, (size_t)n * 8);
-        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->validity.data(), d_bits, nb);
-        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count, d_cnt, 8);
+        if (st == PQ_OK) st = f.call(ctx, &b, cols, pv, d_out);
+        if (f.out_i32) { // Int32 results of this library are never null on non-null input rows beyond the warm-up: PQ_NULL_I32 marks the rest
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->ivalues.data(), d_out, (size_t)n * 4);
+            if (st == PQ_OK)
+                for (int64_t i = 0; i < n; i++)
+                    if (op->ivalues[(size_t)i] == PQ_NULL_I32) { op->validity[(size_t)(i >> 3)] &= (uint8_t)~(1u << (i & 7)); null_count++; }
+        } else {
+            if (st == PQ_OK) st = pq_validity_to_arrow(ctx, (const double *)d_out, n, (uint8_t *)d_bits, (int64_t *)d_cnt);
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->values.data(), d_out, (size_t)n * 8);
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->validity.data(), d_bits, nb);
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count, d_cnt, 8);
+        }
         for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_bits, d_cnt}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail(f.name); return; }
     }
     ArrowArray *arr = new ArrowArray();
     memset(arr, 0, sizeof *arr);
     op->bufs[0] = null_count ? op->validity.data() : nullptr;
-    op->bufs[1] = op->values.data();
+    op->bufs[1] = f.out_i32 ? (const void *)op->ivalues.data() : (const void *)op->values.data();
     arr->length = n; arr->null_count = null_count; arr->n_buffers = 2; arr->buffers = op->bufs; arr->release = release_array; arr->private_data = op;
     ret->field = new ArrowSchema();
-    fill_schema(ret->field, inputs[0].field->name ? inputs[0].field->name : "");
+    fill_schema(ret->field, inputs[0].field->name ? inputs[0].field->name : "", f.out_i32 ? "i" : "g");
     ret->arrays = new ArrowArray *[1];
     ret->arrays[0] = arr;
     ret->len = 1;
     ret->release = release_series;
 }
-// the 61 candlestick recognisers: (open, high, low, close[, penetration literal]) -> Int32, never null (pattern.rs:10-2062; inputs go
-// through cont_slice(): a null is an error; penetration = inputs.get(4) as f64, default 0.3, pattern.rs:529-532)
 void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_series_export *ret) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
@@ -290,21 +318,51 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_
 #define PQ_ARGS_2(in) in[0], in[1]
 #define PQ_ARGS_3(in) in[0], in[1], in[2]
 #define PQ_ARGS_4(in) in[0], in[1], in[2], in[3]
-#define PQ_CALL_1(NAME, NIN) pq_##NAME(ctx, b, PQ_ARGS_##NIN(in), tp, out)
-#define PQ_CALL_0(NAME, NIN) pq_##NAME(ctx, b, PQ_ARGS_##NIN(in), out)
+#define PQ_CALL_1(NAME, NIN) pq_##NAME(ctx, b, PQ_ARGS_##NIN(in), (int64_t)pv[0], (double *)out)
+#define PQ_CALL_0(NAME, NIN) pq_##NAME(ctx, b, PQ_ARGS_##NIN(in), (double *)out)
 #define X(NAME, NIN, HAS_TP, DEFAULT, NB)                                                                                      \
-    static pq_status plug_call_##NAME(pq_ctx *ctx, const pq_batch *b, const double *const *in, int64_t tp, double *out) {       \
-        (void)tp;                                                                                                              \
+    static pq_status plug_call_##NAME(pq_ctx *ctx, const pq_batch *b, const double *const *in, const double *pv, void *out) {   \
+        (void)pv;                                                                                                              \
         return PQ_CALL_##HAS_TP(NAME, NIN);                                                                                    \
     }                                                                                                                          \
     void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
                                pq_series_export *ret, void *) {                                                                \
-        static const PlugFn f = {"pq_" #NAME, NIN, HAS_TP != 0, DEFAULT, NB, &plug_call_##NAME};                               \
+        static const PlugFn f = {"pq_" #NAME, NIN, HAS_TP, {{"timeperiod", false, (double)DEFAULT}}, NB, false, &plug_call_##NAME}; \
         run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);                                                                \
     }                                                                                                                          \
     void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
 PQ_PLUGIN_FUNCS(X)
 #undef X
+// functions with other scalar parameters (reference defaults; overlap.rs:146-151 ma, :503-507 t3, :437-443 sar, :457-469 sarext;
+// momentum.rs:572 ultosc; volume.rs:34 adosc; cycle.rs:377 ht_trendmode -> Int32)
+#define PQ_PLUGIN_DEFINE(NAME, NIN, NPARAMS, PARAMS, NB, I32, CALL, FIELD)                                                       \
+    static pq_status plug_call_##NAME(pq_ctx *ctx, const pq_batch *b, const double *const *in, const double *pv, void *out) {   \
+        (void)pv;                                                                                                              \
+        return CALL;                                                                                                           \
+    }                                                                                                                          \
+    void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
+                               pq_series_export *ret, void *) {                                                                \
+        static const PlugFn f = {"pq_" #NAME, NIN, NPARAMS, PARAMS, NB, I32, &plug_call_##NAME};                               \
+        run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);                                                                \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { FIELD(fields, n, ret); }
+#define PQ_P(...) {__VA_ARGS__}
+PQ_PLUGIN_DEFINE(ma, 1, 2, PQ_P({"timeperiod", false, 30.0}, {"matype", false, 0.0}), false, false,
+                 pq_ma(ctx, b, in[0], (int64_t)pv[0], (int64_t)pv[1], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(t3, 1, 2, PQ_P({"timeperiod", false, 5.0}, {"vfactor", true, 0.0}), false, false,
+                 pq_t3(ctx, b, in[0], (int64_t)pv[0], pv[1], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(ultosc, 3, 3, PQ_P({"timeperiod1", false, 7.0}, {"timeperiod2", false, 14.0}, {"timeperiod3", false, 28.0}), true, false,
+                 pq_ultosc(ctx, b, in[0], in[1], in[2], (int64_t)pv[0], (int64_t)pv[1], (int64_t)pv[2], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(adosc, 4, 2, PQ_P({"fastperiod", false, 3.0}, {"slowperiod", false, 10.0}), false, false,
+                 pq_adosc(ctx, b, in[0], in[1], in[2], in[3], (int64_t)pv[0], (int64_t)pv[1], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(sar, 2, 2, PQ_P({"acceleration", true, 0.0}, {"maximum", true, 0.0}), false, false,
+                 pq_sar(ctx, b, in[0], in[1], pv[0], pv[1], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(sarext, 2, 8,
+                 PQ_P({"startvalue", true, 0.0}, {"offsetonreverse", true, 0.0}, {"accelerationinitlong", true, 0.0}, {"accelerationlong", true, 0.0},
+                      {"accelerationmaxlong", true, 0.0}, {"accelerationinitshort", true, 0.0}, {"accelerationshort", true, 0.0},
+                      {"accelerationmaxshort", true, 0.0}), false, false,
+                 pq_sarext(ctx, b, in[0], in[1], pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(ht_trendmode, 1, 0, PQ_P({nullptr, false, 0.0}), true, true, pq_ht_trendmode(ctx, b, in[0], (int32_t *)out), field_i32)
 // the 61 recognisers in id order (pq_pattern_name)
 #define PQ_PLUGIN_PATTERNS(X) \
     X(cdl2crows, 0) X(cdl3blackcrows, 1) X(cdl3inside, 2) X(cdl3linestrike, 3) X(cdl3outside, 4) X(cdl3starsinsouth, 5) \

@@ -34,7 +34,18 @@ PLUGIN_FUNCS = ["sma", "ema", "wma", "dema", "tema", "trima", "kama", "midpoint"
                 "trix", "ht_dcperiod", "ht_dcphase", "ht_trendline", "midprice", "plus_dm", "minus_dm", "aroonosc", "medprice", "obv",
                 "adx", "adxr", "dx", "plus_di", "minus_di", "cci", "willr", "atr", "natr", "trange", "typprice", "wclprice", "mfi", "bop",
                 "ad", "avgprice"]
-TP_FUNCS = PLUGIN_FUNCS   # (name kept for the argtypes loops below)
+# ... and the functions with other scalar parameters: name -> (input columns, [(parameter, reference default, a test value)])
+MULTI_FUNCS = {"ma": (["real"], [("timeperiod", 30, 12), ("matype", 0, 1)]),
+               "t3": (["real"], [("timeperiod", 5, 7), ("vfactor", 0.0, 0.7)]),
+               "ultosc": (["high", "low", "close"], [("timeperiod1", 7, 5), ("timeperiod2", 14, 9), ("timeperiod3", 28, 20)]),
+               "adosc": (["high", "low", "close", "volume"], [("fastperiod", 3, 4), ("slowperiod", 10, 13)]),
+               "sar": (["high", "low"], [("acceleration", 0.0, 0.02), ("maximum", 0.0, 0.2)]),
+               "sarext": (["high", "low"], [("startvalue", 0.0, 0.0), ("offsetonreverse", 0.0, 0.01), ("accelerationinitlong", 0.0, 0.02),
+                                            ("accelerationlong", 0.0, 0.02), ("accelerationmaxlong", 0.0, 0.2),
+                                            ("accelerationinitshort", 0.0, 0.03), ("accelerationshort", 0.0, 0.03),
+                                            ("accelerationmaxshort", 0.0, 0.3)]),
+               "ht_trendmode": (["real"], [])}
+TP_FUNCS = PLUGIN_FUNCS + list(MULTI_FUNCS)   # (every symbol pair with the common signature: the argtypes loops below)
 
 
 def _lib():
@@ -69,7 +80,7 @@ def test_plugin_symbols_and_version():
             declared |= {"_polars_plugin_" + n, "_polars_plugin_field_" + n}
     declared = {n for n in declared if "##" not in n and not n.endswith("_")}
     from polars_quant_amd._spec import PATTERN_NAMES
-    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in list(PLUGIN_FUNCS) + list(PATTERN_NAMES)}
+    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in list(TP_FUNCS) + list(PATTERN_NAMES)}
     declared = sorted(declared)
     assert {"_polars_plugin_get_version", "_polars_plugin_get_last_error_message", "_polars_plugin_ema", "_polars_plugin_field_ema"} <= set(declared)
     L = _lib()
@@ -271,3 +282,53 @@ def test_every_pattern_through_its_plugin_symbol(oracle):
     out_field = ArrowSchema()
     L._polars_plugin_field_cdldoji(ses[0].field, 1, C.byref(out_field), None, 0)
     assert out_field.format == b"i"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(MULTI_FUNCS))
+def test_functions_with_several_parameters_through_their_plugin_symbols(oracle, name):
+    """ma / t3 / ultosc / adosc / sar / sarext / ht_trendmode: the reference's defaults, every parameter from the pickled kwargs,
+    every parameter as a trailing literal, and a mix (first from kwargs, rest literal) -- against the oracle."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    cols, params = MULTI_FUNCS[name]
+    d = oracle.gen_ohlcv(0x5EED000D, 1, 300, 0)
+    data = {c: d["close" if c == "real" else c][0] for c in cols}
+    fn = getattr(L, "_polars_plugin_" + name)
+    i32 = name == "ht_trendmode"
+
+    def lit(v):
+        return _export([pa.array([v], type=pa.float64() if isinstance(v, float) else pa.int64())], "literal")
+
+    def run(kwargs, literals):
+        ses, keep = [], []
+        for c in cols:
+            arr = pa.array(data[c])
+            se, k = _export([arr.slice(0, 100), arr.slice(100)], c); ses.append(se); keep.append(k)
+        for v in literals:
+            se, k = lit(v); ses.append(se); keep.append(k)
+        ins = (SeriesExport * len(ses))(*ses)
+        kw = pickle.dumps(kwargs) if kwargs else None
+        ret = SeriesExport(); fn(ins, len(ses), kw, len(kw) if kw else 0, C.byref(ret), None)
+        assert ret.release, L._polars_plugin_get_last_error_message()
+        return _import(ret)
+
+    def check(got, values):
+        (exp,) = oracle.call(name, *[data[c] for c in cols], **{p[0]: v for p, v in zip(params, values)})
+        if i32:
+            en = exp == np.int32(-2147483648)
+            assert got.type == pa.int32() and (np.asarray(got.is_null()) == en).all()
+            assert (got.to_numpy(zero_copy_only=False)[~en].astype(np.int32) == exp[~en]).all()
+            return
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert (np.asarray(got.is_null()) == en).all(), name
+        assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all(), name
+
+    defaults, tests = [p[1] for p in params], [p[2] for p in params]
+    check(run(None, []), defaults)
+    if params:
+        check(run({p[0]: v for p, v in zip(params, tests)}, []), tests)
+        check(run(None, tests), tests)
+        check(run({params[0][0]: tests[0]}, [defaults[0]] + tests[1:]), tests)     # kwargs win over the literal of the same parameter
