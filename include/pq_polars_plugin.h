@@ -85,6 +85,13 @@ PQ_PLUGIN_DECL(avgprice)
 PQ_PLUGIN_DECL(ma) PQ_PLUGIN_DECL(t3) PQ_PLUGIN_DECL(ultosc) PQ_PLUGIN_DECL(adosc) PQ_PLUGIN_DECL(sar) PQ_PLUGIN_DECL(sarext)
 PQ_PLUGIN_DECL(ht_trendmode)
 
+/* Struct-valued functions: return_value is one "+s" array whose children are Float64 columns; struct and field names are the
+ * reference's: bbands{bb_upper, bb_middle, bb_lower}(timeperiod 20, nbdevup 2.0, nbdevdn 2.0) overlap.rs:30-47;
+ * mama{mama, fama}(fastlimit 0.0, slowlimit 0.0) :40-44,:156; aroon{aroon_up, aroon_down}(timeperiod 14) momentum.rs:63-70;
+ * macd_res{macd, macd_signal, macd_hist}(fastperiod 12, slowperiod 26, signalperiod 9) :239-250; ht_phasor{inphase, quadrature}
+ * cycle.rs:149-159; ht_sine{sine, leadsine} :229-236.  _polars_plugin_field_<f> returns the same Struct field. */
+PQ_PLUGIN_DECL(bbands) PQ_PLUGIN_DECL(mama) PQ_PLUGIN_DECL(aroon) PQ_PLUGIN_DECL(macd) PQ_PLUGIN_DECL(ht_phasor) PQ_PLUGIN_DECL(ht_sine)
+
 /* the 61 candlestick recognisers (pattern.rs:10-2062): inputs open, high, low, close[, penetration as a Float64 literal, default 0.3];
  * Int32 output, never null; a null in an input is an error (cont_slice) */
 PQ_PLUGIN_DECL(cdl2crows) PQ_PLUGIN_DECL(cdl3blackcrows) PQ_PLUGIN_DECL(cdl3inside) PQ_PLUGIN_DECL(cdl3linestrike)

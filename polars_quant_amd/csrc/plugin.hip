@@ -116,6 +116,7 @@ pq_ctx *plugin_ctx() { // one context per host thread (Polars calls plugins from
 // one adapter per exported function: `in` = the NIN device columns in the reference's input order
 // pv = the scalar parameters in the reference's order (integers as exact doubles)
 typedef pq_status (*col_fn)(pq_ctx *, const pq_batch *, const double *const *in, const double *pv, void *out);
+typedef pq_status (*cols_fn)(pq_ctx *, const pq_batch *, const double *const *in, const double *pv, double *const *out);
 struct PParam { const char *name; bool is_float; double def; };
 struct PlugFn { const char *name; int nin; int nparams; PParam params[8]; bool reject_nulls; bool out_i32; col_fn call; };
 
@@ -144,6 +145,8 @@ int64_t series_len(const pq_series_export &in) {
     return n;
 }
 
+bool read_params(const PParam *params, int nparams, int nin, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
+                 size_t kwargs_len, double (&pv)[8]);
 void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
@@ -152,30 +155,8 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
         if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
     }
-    // every parameter: pickled kwargs first (overlap.rs:18-22), else its trailing literal input (overlap.py:36-43; momentum.rs reads
-    // inputs[nin + k] in declaration order), else the reference's default
-    double pv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < f.nparams; k++) {
-        pv[k] = f.params[k].def;
-        double v = 0.0;
-        const int kw = kwargs_scalar(kwargs, kwargs_len, f.params[k].name, &v);
-        if (kw < 0) { plugin_fail("plugin: cannot parse the pickled kwargs"); return; }
-        const pq_series_export *lit = (int)n_inputs > f.nin + k ? &inputs[f.nin + k] : nullptr;
-        if (kw == 1) pv[k] = v;
-        else if (lit && lit->len >= 1 && lit->arrays && lit->arrays[0] && lit->arrays[0]->length >= 1 && lit->field && lit->field->format) {
-            const ArrowArray *a = lit->arrays[0];
-            const char *fm = lit->field->format;
-            const void *data = a->n_buffers >= 2 ? a->buffers[1] : nullptr;
-            const uint8_t *vb = a->n_buffers >= 1 ? (const uint8_t *)a->buffers[0] : nullptr;
-            const bool is_null = vb && a->null_count != 0 && !((vb[a->offset >> 3] >> (a->offset & 7)) & 1); // a null literal = the default
-            if (data && !is_null) {
-                if (!strcmp(fm, "l")) pv[k] = (double)((const int64_t *)data)[a->offset];
-                else if (!strcmp(fm, "i")) pv[k] = (double)((const int32_t *)data)[a->offset];
-                else if (!strcmp(fm, "g")) pv[k] = ((const double *)data)[a->offset];
-            }
-        }
-        if (!f.params[k].is_float) pv[k] = (double)(int64_t)pv[k];
-    }
+    double pv[8];
+    if (!read_params(f.params, f.nparams, f.nin, inputs, n_inputs, kwargs, kwargs_len, pv)) return;
     const int64_t n = series_len(inputs[0]);
     for (int k = 1; k < f.nin; k++)
         if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
@@ -237,6 +218,146 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     ret->len = 1;
     ret->release = release_series;
 }
+// every scalar parameter of a function: pickled kwargs by name first (overlap.rs:18-22), else its trailing literal input
+// (overlap.py:36-43; momentum.rs reads inputs[nin + k] in declaration order), else the reference's default
+bool read_params(const PParam *params, int nparams, int nin, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
+                 size_t kwargs_len, double (&pv)[8]) {
+    for (int k = 0; k < 8; k++) pv[k] = 0.0;
+    for (int k = 0; k < nparams; k++) {
+        pv[k] = params[k].def;
+        double v = 0.0;
+        const int kw = kwargs_scalar(kwargs, kwargs_len, params[k].name, &v);
+        if (kw < 0) { plugin_fail("plugin: cannot parse the pickled kwargs"); return false; }
+        const pq_series_export *lit = (int)n_inputs > nin + k ? &inputs[nin + k] : nullptr;
+        if (kw == 1) pv[k] = v;
+        else if (lit && lit->len >= 1 && lit->arrays && lit->arrays[0] && lit->arrays[0]->length >= 1 && lit->field && lit->field->format) {
+            const ArrowArray *a = lit->arrays[0];
+            const char *fm = lit->field->format;
+            const void *data = a->n_buffers >= 2 ? a->buffers[1] : nullptr;
+            const uint8_t *vb = a->n_buffers >= 1 ? (const uint8_t *)a->buffers[0] : nullptr;
+            const bool is_null = vb && a->null_count != 0 && !((vb[a->offset >> 3] >> (a->offset & 7)) & 1); // a null literal = the default
+            if (data && !is_null) {
+                if (!strcmp(fm, "l")) pv[k] = (double)((const int64_t *)data)[a->offset];
+                else if (!strcmp(fm, "i")) pv[k] = (double)((const int32_t *)data)[a->offset];
+                else if (!strcmp(fm, "g")) pv[k] = ((const double *)data)[a->offset];
+            }
+        }
+        if (!params[k].is_float) pv[k] = (double)(int64_t)pv[k];
+    }
+    return true;
+}
+
+// ---- Struct-valued functions (bbands, mama, aroon, macd, ht_phasor, ht_sine): a "+s" array whose children are Float64 columns
+struct StructFn { const char *name; const char *struct_name; int nin; int nparams; PParam params[4]; bool reject_nulls; int nout;
+                  const char *fields[3]; cols_fn call; };
+struct StructPriv { ArrowArray *kids[3]; const void *bufs[1]; };
+void release_struct_array(ArrowArray *a) {
+    if (!a || !a->release) return;
+    StructPriv *sp = (StructPriv *)a->private_data;
+    for (int64_t k = 0; k < a->n_children; k++)
+        if (sp->kids[k]) { if (sp->kids[k]->release) sp->kids[k]->release(sp->kids[k]); delete sp->kids[k]; }
+    delete sp;
+    a->release = nullptr;
+}
+struct SchemaPriv { std::string name; ArrowSchema *kids[3]; int n; };
+void release_struct_schema(ArrowSchema *s) {
+    if (!s || !s->release) return;
+    SchemaPriv *sp = (SchemaPriv *)s->private_data;
+    for (int k = 0; k < sp->n; k++)
+        if (sp->kids[k]) { if (sp->kids[k]->release) sp->kids[k]->release(sp->kids[k]); delete sp->kids[k]; }
+    delete sp;
+    s->release = nullptr;
+}
+void fill_struct_schema(ArrowSchema *s, const StructFn &f) {
+    SchemaPriv *sp = new SchemaPriv();
+    sp->name = f.struct_name; sp->n = f.nout;
+    for (int k = 0; k < f.nout; k++) { sp->kids[k] = new ArrowSchema(); fill_schema(sp->kids[k], f.fields[k], "g"); }
+    memset(s, 0, sizeof *s);
+    s->format = "+s"; s->name = sp->name.c_str(); s->flags = 2; s->n_children = f.nout; s->children = sp->kids;
+    s->release = release_struct_schema; s->private_data = sp;
+}
+void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret) {
+    if (ret) memset(ret, 0, sizeof *ret);
+    g_plugin_err.clear();
+    if (!inputs || (int)n_inputs < f.nin || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
+    for (int k = 0; k < f.nin; k++) {
+        if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
+        if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+    }
+    double pv[8];
+    if (!read_params(f.params, f.nparams, f.nin, inputs, n_inputs, kwargs, kwargs_len, pv)) return;
+    const int64_t n = series_len(inputs[0]);
+    std::vector<double> host[2];
+    std::vector<uint8_t> valid[2];
+    bool nulls[2] = {false, false}, any_null = false;
+    for (int k = 0; k < f.nin; k++) {
+        if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
+        if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed Float64 chunk"); return; }
+        any_null |= nulls[k];
+    }
+    if (any_null && f.reject_nulls) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
+    OutPriv *op[3] = {nullptr, nullptr, nullptr};
+    int64_t null_count[3] = {0, 0, 0};
+    for (int k = 0; k < f.nout; k++) {
+        op[k] = new OutPriv();
+        op[k]->values.resize((size_t)(n > 0 ? n : 1));
+        op[k]->validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
+    }
+    auto drop = [&]() { for (int k = 0; k < f.nout; k++) delete op[k]; };
+    if (n > 0) {
+        pq_ctx *ctx = plugin_ctx();
+        if (!ctx) { drop(); plugin_fail("plugin: no HIP device / context"); return; }
+        void *d_in[2] = {nullptr, nullptr}, *d_out[3] = {nullptr, nullptr, nullptr}, *d_bits = nullptr, *d_cnt = nullptr;
+        const size_t nb = (size_t)((n + 7) / 8);
+        pq_status st = pq_malloc(ctx, nb, &d_bits);
+        if (st == PQ_OK) st = pq_malloc(ctx, 8, &d_cnt);
+        for (int k = 0; k < f.nout && st == PQ_OK; k++) st = pq_malloc(ctx, (size_t)n * 8, &d_out[k]);
+        for (int k = 0; k < f.nin && st == PQ_OK; k++) {
+            st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
+            if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
+            if (st == PQ_OK && nulls[k]) {
+                st = pq_memcpy_h2d(ctx, d_bits, valid[k].data(), nb);
+                if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in[k], (const uint8_t *)d_bits, 0, n);
+            }
+        }
+        const pq_batch b{1, n, n};
+        const double *cols[2] = {(const double *)d_in[0], (const double *)d_in[1]};
+        double *outs[3] = {(double *)d_out[0], (double *)d_out[1], (double *)d_out[2]};
+        if (st == PQ_OK) st = f.call(ctx, &b, cols, pv, outs);
+        for (int k = 0; k < f.nout && st == PQ_OK; k++) {
+            st = pq_validity_to_arrow(ctx, (const double *)d_out[k], n, (uint8_t *)d_bits, (int64_t *)d_cnt);
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op[k]->values.data(), d_out[k], (size_t)n * 8);
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op[k]->validity.data(), d_bits, nb);
+            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count[k], d_cnt, 8);
+        }
+        for (void *q : {d_in[0], d_in[1], d_out[0], d_out[1], d_out[2], d_bits, d_cnt}) if (q) (void)pq_free(ctx, q);
+        if (st != PQ_OK) { drop(); plugin_fail(f.name); return; }
+    }
+    StructPriv *sp = new StructPriv();
+    memset(sp, 0, sizeof *sp);
+    for (int k = 0; k < f.nout; k++) {
+        ArrowArray *kid = new ArrowArray();
+        memset(kid, 0, sizeof *kid);
+        op[k]->bufs[0] = null_count[k] ? op[k]->validity.data() : nullptr;
+        op[k]->bufs[1] = op[k]->values.data();
+        kid->length = n; kid->null_count = null_count[k]; kid->n_buffers = 2; kid->buffers = op[k]->bufs; kid->release = release_array; kid->private_data = op[k];
+        sp->kids[k] = kid;
+    }
+    ArrowArray *arr = new ArrowArray();
+    memset(arr, 0, sizeof *arr);
+    sp->bufs[0] = nullptr; // the struct itself is never null: the nulls live in its fields
+    arr->length = n; arr->null_count = 0; arr->n_buffers = 1; arr->buffers = sp->bufs; arr->n_children = f.nout; arr->children = sp->kids;
+    arr->release = release_struct_array; arr->private_data = sp;
+    ret->field = new ArrowSchema();
+    fill_struct_schema(ret->field, f);
+    ret->arrays = new ArrowArray *[1];
+    ret->arrays[0] = arr;
+    ret->len = 1;
+    ret->release = release_series;
+}
+
+// the 61 candlestick recognisers: (open, high, low, close[, penetration literal]) -> Int32, never null (pattern.rs:10-2062; inputs go
+// through cont_slice(): a null is an error; penetration = inputs.get(4) as f64, default 0.3, pattern.rs:529-532)
 void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_series_export *ret) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
@@ -363,6 +484,32 @@ PQ_PLUGIN_DEFINE(sarext, 2, 8,
                       {"accelerationmaxshort", true, 0.0}), false, false,
                  pq_sarext(ctx, b, in[0], in[1], pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7], (double *)out), field_f64)
 PQ_PLUGIN_DEFINE(ht_trendmode, 1, 0, PQ_P({nullptr, false, 0.0}), true, true, pq_ht_trendmode(ctx, b, in[0], (int32_t *)out), field_i32)
+// Struct-valued functions: the struct and field names are the reference's (overlap.rs:30-44 bbands / mama, momentum.rs:63-66 aroon,
+// :239-246 macd -> "macd_res", cycle.rs:149-155 ht_phasor, :229-232 ht_sine)
+#define PQ_PLUGIN_STRUCT(NAME, SNAME, NIN, NPARAMS, PARAMS, NB, NOUT, FIELDS, CALL)                                              \
+    static pq_status plug_call_##NAME(pq_ctx *ctx, const pq_batch *b, const double *const *in, const double *pv, double *const *out) { \
+        (void)pv;                                                                                                              \
+        return CALL;                                                                                                           \
+    }                                                                                                                          \
+    static const StructFn k_struct_##NAME = {"pq_" #NAME, SNAME, NIN, NPARAMS, PARAMS, NB, NOUT, FIELDS, &plug_call_##NAME};   \
+    void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
+                               pq_series_export *ret, void *) {                                                                \
+        run_struct(k_struct_##NAME, inputs, n_inputs, kwargs, kwargs_len, ret);                                                \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *, size_t, ArrowSchema *ret, const uint8_t *, size_t) {                       \
+        if (ret) fill_struct_schema(ret, k_struct_##NAME);                                                                     \
+    }
+PQ_PLUGIN_STRUCT(bbands, "bbands", 1, 3, PQ_P({"timeperiod", false, 20.0}, {"nbdevup", true, 2.0}, {"nbdevdn", true, 2.0}), false, 3,
+                 PQ_P("bb_upper", "bb_middle", "bb_lower"), pq_bbands(ctx, b, in[0], (int64_t)pv[0], pv[1], pv[2], out[0], out[1], out[2]))
+PQ_PLUGIN_STRUCT(mama, "mama", 1, 2, PQ_P({"fastlimit", true, 0.0}, {"slowlimit", true, 0.0}), false, 2, PQ_P("mama", "fama"),
+                 pq_mama(ctx, b, in[0], pv[0], pv[1], out[0], out[1]))
+PQ_PLUGIN_STRUCT(aroon, "aroon", 2, 1, PQ_P({"timeperiod", false, 14.0}), true, 2, PQ_P("aroon_up", "aroon_down"),
+                 pq_aroon(ctx, b, in[0], in[1], (int64_t)pv[0], out[0], out[1]))
+PQ_PLUGIN_STRUCT(macd, "macd_res", 1, 3, PQ_P({"fastperiod", false, 12.0}, {"slowperiod", false, 26.0}, {"signalperiod", false, 9.0}), true, 3,
+                 PQ_P("macd", "macd_signal", "macd_hist"), pq_macd(ctx, b, in[0], (int64_t)pv[0], (int64_t)pv[1], (int64_t)pv[2], out[0], out[1], out[2]))
+PQ_PLUGIN_STRUCT(ht_phasor, "ht_phasor", 1, 0, PQ_P({nullptr, false, 0.0}), true, 2, PQ_P("inphase", "quadrature"),
+                 pq_ht_phasor(ctx, b, in[0], out[0], out[1]))
+PQ_PLUGIN_STRUCT(ht_sine, "ht_sine", 1, 0, PQ_P({nullptr, false, 0.0}), true, 2, PQ_P("sine", "leadsine"), pq_ht_sine(ctx, b, in[0], out[0], out[1]))
 // the 61 recognisers in id order (pq_pattern_name)
 #define PQ_PLUGIN_PATTERNS(X) \
     X(cdl2crows, 0) X(cdl3blackcrows, 1) X(cdl3inside, 2) X(cdl3linestrike, 3) X(cdl3outside, 4) X(cdl3starsinsouth, 5) \

@@ -45,7 +45,14 @@ MULTI_FUNCS = {"ma": (["real"], [("timeperiod", 30, 12), ("matype", 0, 1)]),
                                             ("accelerationinitshort", 0.0, 0.03), ("accelerationshort", 0.0, 0.03),
                                             ("accelerationmaxshort", 0.0, 0.3)]),
                "ht_trendmode": (["real"], [])}
-TP_FUNCS = PLUGIN_FUNCS + list(MULTI_FUNCS)   # (every symbol pair with the common signature: the argtypes loops below)
+# ... and the Struct-valued ones: name -> (struct name, input columns, [(parameter, reference default, a test value)], field names)
+STRUCT_FUNCS = {"bbands": ("bbands", ["real"], [("timeperiod", 20, 10), ("nbdevup", 2.0, 1.5), ("nbdevdn", 2.0, 2.5)], ["bb_upper", "bb_middle", "bb_lower"]),
+                "mama": ("mama", ["real"], [("fastlimit", 0.0, 0.5), ("slowlimit", 0.0, 0.05)], ["mama", "fama"]),
+                "aroon": ("aroon", ["high", "low"], [("timeperiod", 14, 9)], ["aroon_up", "aroon_down"]),
+                "macd": ("macd_res", ["real"], [("fastperiod", 12, 5), ("slowperiod", 26, 13), ("signalperiod", 9, 4)], ["macd", "macd_signal", "macd_hist"]),
+                "ht_phasor": ("ht_phasor", ["real"], [], ["inphase", "quadrature"]),
+                "ht_sine": ("ht_sine", ["real"], [], ["sine", "leadsine"])}
+TP_FUNCS = PLUGIN_FUNCS + list(MULTI_FUNCS) + list(STRUCT_FUNCS)   # (every symbol pair with the common signature: the argtypes loops below)
 
 
 def _lib():
@@ -332,3 +339,57 @@ def test_functions_with_several_parameters_through_their_plugin_symbols(oracle, 
         check(run({p[0]: v for p, v in zip(params, tests)}, []), tests)
         check(run(None, tests), tests)
         check(run({params[0][0]: tests[0]}, [defaults[0]] + tests[1:]), tests)     # kwargs win over the literal of the same parameter
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(STRUCT_FUNCS))
+def test_struct_valued_functions_through_their_plugin_symbols(oracle, name):
+    """bbands / mama / aroon / macd / ht_phasor / ht_sine: one Struct array with the reference's struct and field names; defaults,
+    kwargs and trailing literals -- every field against the oracle."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    sname, cols, params, fields = STRUCT_FUNCS[name]
+    d = oracle.gen_ohlcv(0x5EED000E, 1, 300, 0)
+    data = {c: d["close" if c == "real" else c][0] for c in cols}
+    fn = getattr(L, "_polars_plugin_" + name)
+
+    def run(kwargs, literals):
+        ses, keep = [], []
+        for c in cols:
+            arr = pa.array(data[c])
+            se, k = _export([arr.slice(0, 100), arr.slice(100)], c); ses.append(se); keep.append(k)
+        for v in literals:
+            se, k = _export([pa.array([v], type=pa.float64() if isinstance(v, float) else pa.int64())], "literal"); ses.append(se); keep.append(k)
+        ins = (SeriesExport * len(ses))(*ses)
+        kw = pickle.dumps(kwargs) if kwargs else None
+        ret = SeriesExport(); fn(ins, len(ses), kw, len(kw) if kw else 0, C.byref(ret), None)
+        assert ret.release, L._polars_plugin_get_last_error_message()
+        assert ret.field.contents.name == sname.encode() and ret.field.contents.format == b"+s"
+        return _import(ret)
+
+    def check(got, values):
+        assert pa.types.is_struct(got.type) and [got.type.field(i).name for i in range(got.type.num_fields)] == fields
+        exp = oracle.call(name, *[data[c] for c in cols], **{p[0]: v for p, v in zip(params, values)})
+        for i, e in enumerate(exp):
+            g = got.field(i)
+            en = e.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+            assert (np.asarray(g.is_null()) == en).all(), (name, fields[i])
+            gv = g.to_numpy(zero_copy_only=False)[~en]
+            if name in ("ht_phasor", "ht_sine", "mama"):        # transcendental class
+                np.testing.assert_allclose(gv, e[~en], rtol=1e-12, atol=1e-12)
+            else:
+                assert (gv.view(np.uint64) == e[~en].view(np.uint64)).all(), (name, fields[i])
+
+    defaults, tests = [p[1] for p in params], [p[2] for p in params]
+    if name != "mama":                       # (fastlimit = slowlimit = 0.0, the reference's default, is degenerate: tested with values)
+        check(run(None, []), defaults)
+    if params:
+        check(run({p[0]: v for p, v in zip(params, tests)}, []), tests)
+        check(run(None, tests), tests)
+    out_field = ArrowSchema()
+    getattr(L, "_polars_plugin_field_" + name)(None, 0, C.byref(out_field), None, 0)
+    assert out_field.format == b"+s" and out_field.name == sname.encode() and out_field.n_children == len(fields)
+    kids = C.cast(out_field.children, C.POINTER(C.POINTER(ArrowSchema)))
+    assert [kids[i].contents.name.decode() for i in range(len(fields))] == fields and all(kids[i].contents.format == b"g" for i in range(len(fields)))
