@@ -84,6 +84,8 @@ PQ_PLUGIN_DECL(avgprice)
  * ht_trendmode -> Int32 cycle.rs:377 */
 PQ_PLUGIN_DECL(ma) PQ_PLUGIN_DECL(t3) PQ_PLUGIN_DECL(ultosc) PQ_PLUGIN_DECL(adosc) PQ_PLUGIN_DECL(sar) PQ_PLUGIN_DECL(sarext)
 PQ_PLUGIN_DECL(ht_trendmode)
+/* mavp(real, periods; minperiod 2, maxperiod 30, matype 0) overlap.rs:407: the period column may be Int64 / Int32 / Float64 */
+PQ_PLUGIN_DECL(mavp)
 
 /* Struct-valued functions: return_value is one "+s" array whose children are Float64 columns; struct and field names are the
  * reference's: bbands{bb_upper, bb_middle, bb_lower}(timeperiod 20, nbdevup 2.0, nbdevdn 2.0) overlap.rs:30-47;

@@ -118,17 +118,21 @@ pq_ctx *plugin_ctx() { // one context per host thread (Polars calls plugins from
 typedef pq_status (*col_fn)(pq_ctx *, const pq_batch *, const double *const *in, const double *pv, void *out);
 typedef pq_status (*cols_fn)(pq_ctx *, const pq_batch *, const double *const *in, const double *pv, double *const *out);
 struct PParam { const char *name; bool is_float; double def; };
-struct PlugFn { const char *name; int nin; int nparams; PParam params[8]; bool reject_nulls; bool out_i32; col_fn call; };
+struct PlugFn { const char *name; int nin; int nparams; PParam params[8]; bool reject_nulls; bool out_i32; col_fn call;
+                unsigned int_inputs; /* bit k: input k may be an Int64 / Int32 column (it is converted to f64) */ };
 
 // gather the chunks of one exported Float64 Series into a host column + a validity bitmap (bit = 1: valid)
 bool gather_f64(const pq_series_export &in, int64_t n, std::vector<double> &host, std::vector<uint8_t> &validity, bool &any_null) {
+    const char fmt = in.field && in.field->format ? in.field->format[0] : 'g'; // 'g' f64, 'l' i64, 'i' i32
     host.resize((size_t)(n > 0 ? n : 1));
     validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
     int64_t pos = 0;
     for (size_t c = 0; c < in.len; c++) {
         const ArrowArray *a = in.arrays[c];
         if (a->n_buffers < 2 || (!a->buffers[1] && a->length)) return false;
-        if (a->length) memcpy(host.data() + pos, (const double *)a->buffers[1] + a->offset, (size_t)a->length * 8);
+        if (fmt == 'l') for (int64_t i = 0; i < a->length; i++) host[(size_t)(pos + i)] = (double)((const int64_t *)a->buffers[1])[a->offset + i];
+        else if (fmt == 'i') for (int64_t i = 0; i < a->length; i++) host[(size_t)(pos + i)] = (double)((const int32_t *)a->buffers[1])[a->offset + i];
+        else if (a->length) memcpy(host.data() + pos, (const double *)a->buffers[1] + a->offset, (size_t)a->length * 8);
         const uint8_t *vb = (const uint8_t *)a->buffers[0];
         if (vb && a->null_count != 0)
             for (int64_t i = 0; i < a->length; i++) {
@@ -153,7 +157,9 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     if (!inputs || (int)n_inputs < f.nin || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
     for (int k = 0; k < f.nin; k++) {
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
-        if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+        const char *fm = inputs[k].field->format;
+        const bool int_ok = ((f.int_inputs >> k) & 1) && (!strcmp(fm, "l") || !strcmp(fm, "i"));
+        if (strcmp(fm, "g") != 0 && !int_ok) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
     }
     double pv[8];
     if (!read_params(f.params, f.nparams, f.nin, inputs, n_inputs, kwargs, kwargs_len, pv)) return;
@@ -483,6 +489,15 @@ PQ_PLUGIN_DEFINE(sarext, 2, 8,
                       {"accelerationmaxlong", true, 0.0}, {"accelerationinitshort", true, 0.0}, {"accelerationshort", true, 0.0},
                       {"accelerationmaxshort", true, 0.0}), false, false,
                  pq_sarext(ctx, b, in[0], in[1], pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7], (double *)out), field_f64)
+// mavp: the period column is cast to Int64 by the reference (overlap.rs:407-414): Int64 / Int32 / Float64 are accepted
+static pq_status plug_call_mavp(pq_ctx *ctx, const pq_batch *b, const double *const *in, const double *pv, void *out) {
+    return pq_mavp(ctx, b, in[0], in[1], (int64_t)pv[0], (int64_t)pv[1], (int64_t)pv[2], (double *)out);
+}
+void _polars_plugin_mavp(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, void *) {
+    static const PlugFn f = {"pq_mavp", 2, 3, {{"minperiod", false, 2.0}, {"maxperiod", false, 30.0}, {"matype", false, 0.0}}, false, false, &plug_call_mavp, 2u};
+    run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);
+}
+void _polars_plugin_field_mavp(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
 PQ_PLUGIN_DEFINE(ht_trendmode, 1, 0, PQ_P({nullptr, false, 0.0}), true, true, pq_ht_trendmode(ctx, b, in[0], (int32_t *)out), field_i32)
 // Struct-valued functions: the struct and field names are the reference's (overlap.rs:30-44 bbands / mama, momentum.rs:63-66 aroon,
 // :239-246 macd -> "macd_res", cycle.rs:149-155 ht_phasor, :229-232 ht_sine)

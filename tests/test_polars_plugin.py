@@ -44,7 +44,8 @@ MULTI_FUNCS = {"ma": (["real"], [("timeperiod", 30, 12), ("matype", 0, 1)]),
                                             ("accelerationlong", 0.0, 0.02), ("accelerationmaxlong", 0.0, 0.2),
                                             ("accelerationinitshort", 0.0, 0.03), ("accelerationshort", 0.0, 0.03),
                                             ("accelerationmaxshort", 0.0, 0.3)]),
-               "ht_trendmode": (["real"], [])}
+               "ht_trendmode": (["real"], []),
+               "mavp": (["real", "periods"], [("minperiod", 2, 3), ("maxperiod", 30, 20), ("matype", 0, 1)])}
 # ... and the Struct-valued ones: name -> (struct name, input columns, [(parameter, reference default, a test value)], field names)
 STRUCT_FUNCS = {"bbands": ("bbands", ["real"], [("timeperiod", 20, 10), ("nbdevup", 2.0, 1.5), ("nbdevdn", 2.0, 2.5)], ["bb_upper", "bb_middle", "bb_lower"]),
                 "mama": ("mama", ["real"], [("fastlimit", 0.0, 0.5), ("slowlimit", 0.0, 0.05)], ["mama", "fama"]),
@@ -302,7 +303,7 @@ def test_functions_with_several_parameters_through_their_plugin_symbols(oracle, 
     L = _lib()
     cols, params = MULTI_FUNCS[name]
     d = oracle.gen_ohlcv(0x5EED000D, 1, 300, 0)
-    data = {c: d["close" if c == "real" else c][0] for c in cols}
+    data = {c: (2 + np.arange(300) % 29).astype(np.float64) if c == "periods" else d["close" if c == "real" else c][0] for c in cols}
     fn = getattr(L, "_polars_plugin_" + name)
     i32 = name == "ht_trendmode"
 
@@ -312,7 +313,7 @@ def test_functions_with_several_parameters_through_their_plugin_symbols(oracle, 
     def run(kwargs, literals):
         ses, keep = [], []
         for c in cols:
-            arr = pa.array(data[c])
+            arr = pa.array(data[c].astype(np.int64)) if c == "periods" else pa.array(data[c])   # the period column as Int64
             se, k = _export([arr.slice(0, 100), arr.slice(100)], c); ses.append(se); keep.append(k)
         for v in literals:
             se, k = lit(v); ses.append(se); keep.append(k)
