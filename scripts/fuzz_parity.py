@@ -47,7 +47,16 @@ def _case(rng, name, log) -> int:
     except Exception as e:  # noqa: BLE001
         log("oracle error", name, params, e)
         return 1
-    got = api.call(name, *[torch.from_numpy(np.ascontiguousarray(d[c])).cuda() for c in cols], **params)
+    # the device layout: dense, or a row pitch larger than the row (even pitch: tiled bodies incl. the pair-mode storer and the ragged
+    # tail; odd pitch: gather bodies; a multiple of 16 elements: the 128-byte pitch bench.py uses); the padding holds a poison value
+    pitch = T + int(rng.choice([0, 0, 0, 1, 2, 6, 8, 15, 16])) if rng.random() < 0.5 else (T + 15) // 16 * 16
+    def dev(a):
+        if pitch == T:
+            return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        buf = torch.full((N, pitch), 1e300, dtype=torch.float64, device="cuda")
+        buf[:, :T] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return buf[:, :T]
+    got = api.call(name, *[dev(d[c]) for c in cols], **params)
     bad = 0
     for (oname, dt), g, e in zip(outs, got, exp):
         g = g.cpu().numpy()
