@@ -31,11 +31,16 @@ def t_event(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-out = {"days": T, "symbols_total": 5000, "backtest_macd_cross_ms": {}, "suite_step_ms": {}}
+PITCH = (T + 15) // 16 * 16     # device columns pitched to 128 B, as in bench.py
+out = {"days": T, "row_pitch_elements": PITCH, "symbols_total": 5000, "backtest_macd_cross_ms": {}, "suite_step_ms": {}}
 for n in (5000, 2500, 1250, 625):
-    g = {k: torch.from_numpy(v[:n].copy()).cuda() for k, v in full.items()}
+    g = {}
+    for k, v in full.items():
+        buf = torch.zeros((n, PITCH), dtype=torch.float64, device="cuda")
+        buf[:, :T] = torch.from_numpy(v[:n].copy()).cuda()
+        g[k] = buf[:, :T]
     out["backtest_macd_cross_ms"][n] = t_event(lambda: api.backtest_macd_cross(g["close"], want_curves=True), 20)
-    st = Suite(n, T, "cuda")
+    st = Suite(n, T, "cuda", stride=PITCH)
     st.record(g)
     out["suite_step_ms"][n] = t_event(lambda: st.run(), 20)
     st.close()
