@@ -262,6 +262,16 @@ def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, wan
     return f(pos), f(cash), f(eq), f(summ)
 
 
+def backtest_wave_stats(reset: bool = False, device=None):
+    """(symbols run by the wave-per-symbol backtest, speculative chunks that failed the bit test, chunk re-runs) since the last
+    reset -- pq_backtest_wave_stats (csrc/ops_backtest_wave.h).  Synchronises the stream."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = (C.c_int64 * 3)()
+    with torch.cuda.device(dev):
+        check(lib().pq_backtest_wave_stats(ctx(dev.index), out, 1 if reset else 0))
+    return tuple(int(v) for v in out)
+
+
 def factor_ic(factor, fwd_return, method: int = 0):
     """D-12: per-day cross-sectional IC of factor vs forward return, both [N, T] -> (ic [T], n_valid [T]) device tensors.
     method 0 = Pearson IC, 1 = Spearman Rank-IC"""

@@ -4,7 +4,8 @@
 // SEQ shape: one symbol per lane; the scan is branchy and strictly serial in time, so the parallel
 // axis is the symbol axis only.  The lane writes position/cash/equity as it goes and then re-reads its
 // own equity (and benchmark) rows for the two-pass mean/variance exactly as calculate_summary does.
-#include "ops_backtest.h"
+#include "ops_backtest_wave.h"
+#include <stdlib.h>
 
 template <bool M, bool S>
 static pq_status bt_launch(pq_ctx *ctx, const pq_batch *b, const BtArgs &a) {
@@ -19,7 +20,69 @@ static pq_status bt_launch(pq_ctx *ctx, const pq_batch *b, const BtArgs &a) {
     return PQ_OK;
 }
 
+// ---- wave-per-symbol form (ops_backtest_wave.h): one workgroup of one wavefront per symbol
+struct BtWaveBlob {
+    BtWaveArgs a;
+    pq_batch b;
+    unsigned lds;
+    int macd;
+};
+static void btw_launch_blob(const void *blob, hipStream_t stream) {
+    const BtWaveBlob &w = *reinterpret_cast<const BtWaveBlob *>(blob);
+    static bool big_lds[2] = {false, false}; // above 64 KB of dynamic LDS a kernel has to opt in once
+    if (w.lds > 64 * 1024 && !big_lds[w.macd]) {
+        if (w.macd) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds[w.macd] = true;
+    }
+    const dim3 grid((unsigned)w.b.n_series);
+    if (w.macd) hipLaunchKernelGGL(bt_wave_kernel<true>, grid, dim3(64), w.lds, stream, w.a, dims_of(&w.b));
+    else hipLaunchKernelGGL(bt_wave_kernel<false>, grid, dim3(64), w.lds, stream, w.a, dims_of(&w.b));
+}
+// true: handled (launched or recorded, *st holds the status); false: the shape is outside the wave form
+static bool bt_wave(pq_ctx *ctx, const pq_batch *b, bool macd, const BtArgs &g, pq_status *st) {
+    if (getenv("PQ_BT_LANE_FORM")) return false; // A/B and tests: force the lane-per-symbol form
+    BtWaveBlob w{};
+    size_t lds = 0;
+    if (b->n_series > 0x7fffffffLL || !btw_plan(b, g.fast, g.slow, g.sig, macd, w.a, lds, g.bench != nullptr)) return false;
+    *st = PQ_OK;
+    if (b->n_series == 0) return true;
+    w.a.price = g.price; w.a.buy = g.buy; w.a.sell = g.sell; w.a.bench = g.bench;
+    w.a.position = g.position; w.a.cash = g.cash; w.a.equity = g.equity; w.a.summary = g.summary;
+    w.a.prm = g.prm; w.a.fast = (int32_t)g.fast; w.a.slow = (int32_t)g.slow; w.a.sig = (int32_t)g.sig;
+    w.a.stats = reinterpret_cast<unsigned long long *>(ctx->d_flag) + 4;
+    w.b = *b; w.lds = (unsigned)lds; w.macd = macd ? 1 : 0;
+    if (ctx->rec) {
+        static_assert(sizeof(BtWaveBlob) <= sizeof(RowThunk::blob), "wave backtest blob too large");
+        RowThunk t{};
+        t.launch = &btw_launch_blob;
+        t.row_id = 0;
+        t.blob_bytes = (int)sizeof w;
+        t.dims = dims_of(b);
+        memcpy(t.blob, &w, sizeof w);
+        const void *rd[4] = {g.price, g.buy, g.sell, g.bench};
+        for (int k = 0; k < 4; k++) if (rd[k]) t.reads[t.n_reads++] = rd[k];
+        void *wr[4] = {g.position, g.cash, g.equity, g.summary};
+        for (int k = 0; k < 4; k++) if (wr[k]) t.writes[t.n_writes++] = wr[k];
+        *st = rec_add_row(ctx, t);
+        return true;
+    }
+    btw_launch_blob(&w, ctx->stream);
+    if (hipGetLastError() != hipSuccess) { pq_set_error("wave backtest launch failed"); *st = PQ_ERR_HIP; }
+    return true;
+}
+
 extern "C" {
+
+// [0] symbols run by the wave form since the last reset, [1] speculative chunks that failed the bit test, [2] chunk re-runs
+pq_status pq_backtest_wave_stats(pq_ctx *ctx, int64_t *out3, int32_t reset) {
+    PQ_REQUIRE(ctx && out3, "pq_backtest_wave_stats: null pointer");
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PQ_HIP_TRY(hipMemcpy(out3, ctx->d_flag + 4, 3 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (reset) PQ_HIP_TRY(hipMemset(ctx->d_flag + 4, 0, 3 * sizeof(int64_t)));
+    return PQ_OK;
+}
 
 pq_status pq_backtest_vectorized(pq_ctx *ctx, const pq_batch *b, const double *price, const uint8_t *buy,
                                  const uint8_t *sell, const double *benchmark, const pq_bt_params *params,
@@ -29,8 +92,10 @@ pq_status pq_backtest_vectorized(pq_ctx *ctx, const pq_batch *b, const double *p
     BtArgs a{};
     a.price = price; a.buy = buy; a.sell = sell; a.bench = benchmark;
     a.position = position; a.cash = cash; a.summary = summary; a.prm = *params;
-    if (equity) a.equity = equity;
-    else {
+    a.equity = equity;
+    pq_status wst;
+    if (bt_wave(ctx, b, false, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
+    if (!equity) {
         PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
         a.equity = pq_ws_col(ctx, b, 0);
         if (!a.equity) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
@@ -46,6 +111,9 @@ pq_status pq_backtest_macd_cross(pq_ctx *ctx, const pq_batch *b, const double *c
     BtArgs a{};
     a.price = close; a.position = position; a.cash = cash; a.summary = summary; a.prm = *params;
     a.fast = fast; a.slow = slow; a.sig = sig;
+    a.equity = equity;
+    pq_status wst;
+    if (bt_wave(ctx, b, true, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
     if (position && cash && equity) { // all three state columns: the tiled SEQ op (coalesced column traffic)
         BtMacdOp op{};
         op.prm = *params; op.fast = fast; op.slow = slow; op.sig = sig; op.summary = summary;

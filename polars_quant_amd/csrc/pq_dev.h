@@ -26,7 +26,7 @@ struct pq_ctx {
     bool own_stream;
     void *ws;        // scratch workspace (device)
     size_t ws_bytes;
-    int64_t *d_flag; // 1 x int64 device scalar for reductions
+    int64_t *d_flag; // 8 x int64 device scalars: [0] reductions, [4..6] statistics of the wave-per-symbol backtest
     Recorder *rec;   // non-null while a suite is being recorded
 };
 
