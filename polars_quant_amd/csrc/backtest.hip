@@ -83,6 +83,14 @@ pq_status pq_backtest_wave_stats(pq_ctx *ctx, int64_t *out3, int32_t reset) {
     if (reset) PQ_HIP_TRY(hipMemset(ctx->d_flag + 4, 0, 3 * sizeof(int64_t)));
     return PQ_OK;
 }
+#ifdef PQ_BTW_PROF
+pq_status pq_backtest_wave_prof(pq_ctx *ctx, int64_t *out5, int32_t reset) {
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PQ_HIP_TRY(hipMemcpy(out5, ctx->d_flag + 8, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (reset) PQ_HIP_TRY(hipMemset(ctx->d_flag + 8, 0, 16 * sizeof(int64_t)));
+    return PQ_OK;
+}
+#endif
 
 pq_status pq_backtest_vectorized(pq_ctx *ctx, const pq_batch *b, const double *price, const uint8_t *buy,
                                  const uint8_t *sell, const double *benchmark, const pq_bt_params *params,

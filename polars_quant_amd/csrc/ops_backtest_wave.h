@@ -26,7 +26,7 @@
 #include "ops_backtest.h"
 
 constexpr int BTW_MAX_C = 64;            // rows per lane chunk: one 64-bit signal mask per lane => len <= 4096
-constexpr int BTW_TAB = 66;              // event table of one 64-row block: state before the block + at most 64 events
+constexpr int BTW_NG = 8;                // register groups of 64 events each: the dense form holds <= 512 events per symbol
 
 struct BtWaveArgs {
     const double *price;
@@ -36,6 +36,7 @@ struct BtWaveArgs {
     pq_bt_params prm;
     int32_t fast, slow, sig;
     int32_t C, P, nW;          // chunk rows, chunk pitch in LDS (odd: conflict-free per-lane reads), warm-up chunks
+    int32_t kcap;              // capacity of the event lists in LDS (more events: the block form)
     uint32_t magic;            // ceil(2^20 / C): i / C == (i * magic) >> 20 for i < 64 * C
     unsigned long long *stats; // nullable: [0] symbols, [1] speculative chunks that failed the bit test, [2] chunk re-runs
 };
@@ -50,7 +51,9 @@ __device__ __forceinline__ double btw_readlane(double v, int l) {
     return __longlong_as_double((long long)btw_readlane((unsigned long long)__double_as_longlong(v), l));
 }
 __device__ __forceinline__ unsigned long long btw_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
-__device__ __forceinline__ void btw_lds_sync() { __syncthreads(); } // one wave per workgroup: orders LDS traffic for the compiler
+// One wave per workgroup: its LDS operations execute in program order, so lanes exchange data through LDS without a barrier;
+// the compiler only has to keep the accesses in order (__syncthreads would also wait for every outstanding global store).
+__device__ __forceinline__ void btw_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 // The MACD-cross state machine of one lane (BtMacdOp::step without the trade part)
 struct BtwMacd {
@@ -79,14 +82,29 @@ struct BtwMacd {
         prev_m = m;
     }
 };
+// EmaCore::step on a non-null value when `cnt` (valid rows seen including this one) and the period are wave-uniform
+__device__ __forceinline__ double btw_ema_lock(EmaCore &e, double v, int cnt, int p) {
+    if (cnt < p) { e.sum += v; return pq_null(); }
+    if (cnt == p) { e.sum += v; e.ema = e.sum / (double)p; return e.ema; }
+    e.ema = fma(e.alpha, v - e.ema, e.ema);
+    return e.ema;
+}
 __device__ __forceinline__ void btw_bcast_ema(EmaCore &e, int l) { // every lane receives lane l's core
     e.count = (int64_t)btw_readlane((unsigned long long)e.count, l);
     e.ema = btw_readlane(e.ema, l);
     e.sum = btw_readlane(e.sum, l);
 }
 
+#ifdef PQ_BTW_PROF // scripts/ab_build.sh only: per-phase device time summed over the waves, stats[4 + k] in 10 ns ticks
+#define BTW_T(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && a.stats) atomicAdd(a.stats + 4 + (k), t__ - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BTW_T(k)
+#endif
 template <bool MACD>
 __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
+#ifdef PQ_BTW_PROF
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __align__(16) unsigned char btw_lds[];
     const int lane = (int)threadIdx.x;
     const int64_t s = blockIdx.x;
@@ -95,7 +113,9 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     const int64_t base = s * d.stride;
     double *px = reinterpret_cast<double *>(btw_lds);   // [64 * P]: row i at i + (i / C) * (P - C); later the equity row, then r
     double *bm = px + 64 * P;                           // [64 * P] when a.bench
-    double *tab = bm + (a.bench ? 64 * P : 0);          // [2][BTW_TAB]
+    unsigned long long *evw = reinterpret_cast<unsigned long long *>(bm + (a.bench ? 64 * P : 0)); // [64] event flags per block
+    double *evp = reinterpret_cast<double *>(evw + 64); // [kcap] event prices, then the cash after each event
+    double *evr = evp + a.kcap;                         // [kcap] 1 / exec of the buys, then the position after each event
     auto addr = [&](int i) { return i + (int)(((unsigned)i * magic) >> 20) * PC; };
     const pq_bt_params prm = a.prm;
     if (T == 0) {
@@ -106,24 +126,76 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     // ---- phase 0: the symbol's rows, coalesced, into LDS; signal masks when the signals are inputs
     unsigned long long bmask = 0, smask = 0; // MACD: bit b of lane c = row c*C + b; else: bit b of lane w = row 64*w + b
     bool null_seen = false;
-#pragma unroll 4
-    for (int j = 0; j < C; j++) {
-        const int i = 64 * j + lane;
-        double v = pq_null();
-        if (i < T) v = a.price[base + i];
-        px[addr(i)] = v;
-        null_seen |= (i < T) && pq_isnull(v);
-        if (a.bench) bm[addr(i)] = i < T ? a.bench[base + i] : 0.0;
-        if (!MACD) {
-            const bool valid = !(isnan(v) || v <= 0.0); // vectorized.rs:141: such rows leave the state untouched (a NULL is a NaN)
-            bool b = false, se = false;
-            if (i < T) { b = a.buy[base + i] != 0; se = a.sell[base + i] != 0; }
-            const unsigned long long bb = btw_ballot(b && valid), sb = btw_ballot(se && valid);
-            if (lane == j) { bmask = bb; smask = sb; }
+    auto stage = [&](const double *src, double *dst, double fill, bool count_nulls) {
+        if (((reinterpret_cast<uintptr_t>(src + base) & 15) == 0)) { // 16 bytes per lane: rows 128 * j + 2 * lane, + 1
+            const int npair = (T + 127) / 128;
+            for (int j0 = 0; j0 < npair; j0 += 8) {
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 128 * (j0 + u) + 2 * lane;
+                    v[u] = make_double2(fill, fill);
+                    if (j0 + u < npair) {
+                        if (i + 1 < T) v[u] = *reinterpret_cast<const double2 *>(src + base + i);
+                        else if (i < T) v[u].x = src[base + i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 128 * (j0 + u) + 2 * lane;
+                    if (j0 + u < npair && i < 64 * C) {
+                        dst[addr(i)] = v[u].x;
+                        dst[addr(i + 1)] = v[u].y;
+                        if (count_nulls) null_seen |= (i < T && pq_isnull(v[u].x)) || (i + 1 < T && pq_isnull(v[u].y));
+                    }
+                }
+            }
+        } else {
+            for (int j0 = 0; j0 < C; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 64 * (j0 + u) + lane;
+                    v[u] = (j0 + u < C && i < T) ? src[base + i] : fill;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 64 * (j0 + u) + lane;
+                    if (j0 + u < C) {
+                        dst[addr(i)] = v[u];
+                        if (count_nulls) null_seen |= i < T && pq_isnull(v[u]);
+                    }
+                }
+            }
+        }
+    };
+    stage(a.price, px, pq_null(), true);
+    if (a.bench) stage(a.bench, bm, 0.0, false);
+    if (!MACD) {
+        btw_lds_fence();
+        for (int j0 = 0; j0 < C; j0 += 8) {
+            unsigned char bb[8], sb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = 64 * (j0 + u) + lane;
+                const bool in = j0 + u < C && i < T;
+                bb[u] = in ? a.buy[base + i] : 0;
+                sb[u] = in ? a.sell[base + i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (j0 + u < C) {
+                    const double v = px[addr(64 * (j0 + u) + lane)];
+                    const bool valid = !(isnan(v) || v <= 0.0); // vectorized.rs:141: such rows leave the state untouched (a NULL is a NaN)
+                    const unsigned long long wb = btw_ballot(bb[u] != 0 && valid), ws = btw_ballot(sb[u] != 0 && valid);
+                    if (lane == j0 + u) { bmask = wb; smask = ws; }
+                }
+            }
         }
     }
     const bool any_null = btw_ballot(null_seen) != 0;
-    btw_lds_sync();
+    btw_lds_fence();
+    BTW_T(0);
 
     // ---- phase 1 (A): MACD-cross signals by speculative chunks
     if (MACD) {
@@ -134,18 +206,76 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             const int nlive = (T + C - 1) / C;
             const bool live = c < nlive;
             const int nk = nlive < a.nW + 1 ? nlive : a.nW + 1; // chunk iterations
-            // Schedule.  Lanes c > nW ("speculative") start fresh nW chunks early and reach their own chunk in the LAST iteration.
-            // The first nW + 1 chunks have no room for a warm-up: lane 0 walks chunks 0 .. nk-2 serially from row 0 (exact) WHILE
-            // the speculative lanes warm up, and hands its state after chunk k to lane k + 1; in the last iteration the lanes
-            // 1 .. nW run their own chunk from that exact state.  So only iteration 0 sees averages that are not seeded yet
-            // (general path); every later one is straight-line code.
+            // Schedule.  Lanes c > nW ("speculative") start nW chunks early and reach their own chunk in the LAST iteration.  The
+            // first nW + 1 chunks have no room for a warm-up: lane 0 walks them serially from row 0 (exact) WHILE the speculative
+            // lanes warm up, and hands its state after chunk k to lane k + 1; in the last iteration the lanes 1 .. nW run their
+            // own chunk from that exact state.
+            // Null-free series (`head`): lane 0 first does chunk 0 alone -- the rows on which the averages are being seeded
+            // (uniform-count branches), then the rest of the chunk in steady state -- and the speculative lanes start in steady
+            // state from an arbitrary seed (the first price of their warm-up): every iteration of the loop is then straight-line
+            // code.  Otherwise (nulls, or a seeding phase longer than a chunk) the speculative lanes start as if the series began
+            // at their warm-up row and the loop runs the general per-row state machine while any active lane is not seeded.
             const bool spec = live && c > a.nW;
+            const int pf = a.fast, ps = a.slow, pg = a.sig;
+            const int R1 = pf > ps ? pf : ps;  // m = fast - slow exists from the R1-th row on
+            const int H = R1 > pg ? R1 : pg;   // after H rows every average is seeded and prev_m / prev_s are values
+            const bool head = !any_null && H <= C;
+            auto hand_over = [&](int to) { // lane 0's state -> lane `to`: the exact state in front of that lane's chunk
+                BtwMacd h = st;
+                btw_bcast_ema(h.ef, 0); btw_bcast_ema(h.es, 0); btw_bcast_ema(h.eg, 0);
+                h.prev_m = btw_readlane(st.prev_m, 0); h.prev_s = btw_readlane(st.prev_s, 0);
+                if (lane == to) st = h;
+            };
+            // steady rows [b0, C) of chunk `row` with their signals kept: buy = !(m' > g') && (m > g), sell = !(m' < g') && (m < g)
+            // (a NaN average is absorbing -- every later m, g is NaN and both predicates stay false --, so "not greater on the
+            // previous row" can stand for the reference's "less or equal")
+            auto steady_rows_keep = [&](const double *row, int b0) {
+                unsigned long long gt = 0, lt = 0, vm = 0;
+                const bool pgt = st.prev_m > st.prev_s, plt = st.prev_m < st.prev_s;
+                for (int b = b0; b < C; b++) {
+                    const double x = row[b];
+                    st.fast_nosig(x);
+                    gt |= (unsigned long long)(st.prev_m > st.prev_s) << b;
+                    lt |= (unsigned long long)(st.prev_m < st.prev_s) << b;
+                    vm |= (unsigned long long)(x > 0.0) << b; // valid price (NaN / NULL compare false)
+                }
+                const unsigned long long pvg = (gt << 1) | ((unsigned long long)pgt << b0), pvl = (lt << 1) | ((unsigned long long)plt << b0);
+                bmask = gt & ~pvg & vm;
+                smask = lt & ~pvl & vm;
+            };
+            if (head) {
+                if (lane == 0) { // rows 0 .. H-1: no signal is possible yet (prev_m / prev_s are null until row H - 1)
+                    for (int b = 0; b < H; b++) {
+                        const int cnt = b + 1;
+                        const double x = px[b];
+                        const double f = btw_ema_lock(st.ef, x, cnt, pf), sl = btw_ema_lock(st.es, x, cnt, ps);
+                        if (cnt >= R1) { // before that the signal line sees zeros: its sum and its seed stay +0.0
+                            st.prev_m = f - sl;
+                            st.prev_s = btw_ema_lock(st.eg, st.prev_m, cnt, pg);
+                        }
+                    }
+                    st.ef.count = st.es.count = st.eg.count = H;
+                    steady_rows_keep(px, H);
+                }
+                hand_over(1);
+                if (spec) {
+                    const double x0 = px[(c - a.nW) * P];
+                    st.ef.ema = st.es.ema = x0; st.eg.ema = 0.0;
+                    st.ef.count = st.es.count = st.eg.count = H;
+                    st.prev_m = st.prev_s = 0.0;
+                }
+            }
+            BTW_T(5);
             double s_f = 0, s_s = 0, s_g = 0, s_pm = 0, s_ps = 0;
             bool s_steady = false;
-            for (int k = 0; k < nk; k++) {
+            for (int kk = 0; kk < nk; kk++) {
+                const int k = __builtin_amdgcn_readfirstlane(kk); // (the compiler otherwise keeps the counter in a VGPR and treats
+                                                                  // everything derived from it as divergent)
                 const bool last = k == nk - 1;
-                const int q = last ? c : (spec ? c - a.nW + k : k);
-                const bool active = live && (last ? (c > 0 || nk == 1) : (spec || c == 0));
+                const int q = last ? c : (spec ? c - a.nW + k : (head ? k + 1 : k));
+                const bool lane0_active = head ? k + 2 < nk : true; // wave-uniform: lane 0 walks a chunk in this iteration
+                const bool lane0 = c == 0 && lane0_active;
+                const bool active = live && (last ? (c > 0 || (nk == 1 && !head)) : (spec || lane0));
                 const bool rec = active && q == c; // this lane's own rows: their signals are kept
                 if (last) { s_f = st.ef.ema; s_s = st.es.ema; s_g = st.eg.ema; s_pm = st.prev_m; s_ps = st.prev_s; s_steady = st.steady(); }
                 const double *row = px + (active ? q : 0) * P;
@@ -165,23 +295,9 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     }
                 } else if (fastk) {
                     if (active) {
-                        // buy = !(m' > g') && (m > g), sell = !(m' < g') && (m < g) on non-NaN values: two predicates per row
-                        unsigned long long gt = 0, lt = 0, vm = 0;
-                        const bool pgt = st.prev_m > st.prev_s, plt = st.prev_m < st.prev_s;
-                        for (int b = 0; b < C; b++) {
-                            const double x = row[b];
-                            st.fast_nosig(x);
-                            gt |= (unsigned long long)(st.prev_m > st.prev_s) << b;
-                            lt |= (unsigned long long)(st.prev_m < st.prev_s) << b;
-                            vm |= (unsigned long long)(x > 0.0) << b; // valid price (NaN / NULL compare false)
-                        }
-                        // (a NaN average is absorbing -- every later m, g is NaN and both predicates stay false --, so "not greater on
-                        // the previous row" can stand for the reference's "less or equal")
-                        if (rec) {
-                            const unsigned long long pg = (gt << 1) | (unsigned long long)pgt, pl = (lt << 1) | (unsigned long long)plt;
-                            bmask = gt & ~pg & vm;
-                            smask = lt & ~pl & vm;
-                        }
+                        const unsigned long long kb = bmask, ks = smask;
+                        steady_rows_keep(row, 0);
+                        if (!rec) { bmask = kb; smask = ks; }
                     }
                 } else {
                     if (active)
@@ -196,12 +312,10 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                             }
                         }
                 }
-                if (!last) { // lane 0 -> lane k + 1: the exact state in front of chunk k + 1
-                    BtwMacd h = st;
-                    btw_bcast_ema(h.ef, 0); btw_bcast_ema(h.es, 0); btw_bcast_ema(h.eg, 0);
-                    h.prev_m = btw_readlane(st.prev_m, 0); h.prev_s = btw_readlane(st.prev_s, 0);
-                    if (lane == k + 1) st = h;
-                }
+#ifdef PQ_BTW_PROF
+                if (k == nk - 2) BTW_T(6); else if (last) BTW_T(7);
+#endif
+                if (!last && lane0_active) hand_over(head ? k + 2 : k + 1);
             }
             // verification: my state at my first row == my predecessor's state after its last row, as raw bits
             auto mismatch = [&]() {
@@ -225,14 +339,16 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     s_f = st.ef.ema; s_s = st.es.ema; s_g = st.eg.ema; s_pm = st.prev_m; s_ps = st.prev_s; s_steady = true;
                     bmask = 0; smask = 0;
                     const double *row = px + cs * P;
-                    for (int b = 0; b < C; b++) {
-                        const double x = row[b];
-                        bool bu, se;
-                        st.step(cs * C + b, x, bu, se);
-                        const bool valid = !(isnan(x) || x <= 0.0);
-                        bmask |= (unsigned long long)(bu && valid) << b;
-                        smask |= (unsigned long long)(se && valid) << b;
-                    }
+                    if (!any_null && st.steady()) steady_rows_keep(row, 0);
+                    else
+                        for (int b = 0; b < C; b++) {
+                            const double x = row[b];
+                            bool bu, se;
+                            st.step(cs * C + b, x, bu, se);
+                            const bool valid = !(isnan(x) || x <= 0.0);
+                            bmask |= (unsigned long long)(bu && valid) << b;
+                            smask |= (unsigned long long)(se && valid) << b;
+                        }
                 }
                 n_rerun++;
                 // the re-run changed lane cs's end state: its successor is tested again
@@ -246,13 +362,218 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
         }
     }
     if (a.stats && lane == 0) atomicAdd(a.stats + 0, 1ULL);
+    BTW_T(4);
 
-    // ---- phases 2 + 3 (B, C): per 64-row block, walk the block's events, then fill its rows
+    // ---- phase 2 (B): which rows are events?  A row is an event iff its signal finds the pool in the right state: flat for a
+    // buy, long for a sell.  Assuming every buy can afford a share, that is a two-state automaton over the rows; automata
+    // compose associatively, so the per-lane transfer functions are combined by a wave prefix scan and every lane marks the
+    // events among its own rows.  (A pool that cannot afford one share makes a buy signal a non-event: the walks below notice
+    // -- qty <= 0 -- and fall back to searching the signal masks row by row from there.)
     const int CQ = MACD ? C : 64;
+    unsigned long long myword; // lane j: bit l = row 64 * j + l is an event
+    unsigned long long evm;    // the same events in the mapping of bmask / smask
+    int K = 0, kexcl = 0;      // events of the symbol; events in front of my rows
+    {
+        unsigned long long m = bmask | smask, ev0 = 0, ev1 = 0; // events among my rows if the pool arrives flat / long
+        int st0 = 0, st1 = 1;                                   // state after my rows
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const bool isb = (bmask >> b) & 1, iss = (smask >> b) & 1;
+            if (st0 ? iss : isb) { st0 ^= 1; ev0 |= 1ULL << b; }
+            if (st1 ? iss : isb) { st1 ^= 1; ev1 |= 1ULL << b; }
+        }
+        int f0 = st0, f1 = st1; // inclusive scan of the composition: state after lanes 0..c given the state in front of lane 0
+        for (int off = 1; off < 64; off <<= 1) {
+            const int p0 = __shfl_up(f0, off), p1 = __shfl_up(f1, off);
+            if (lane >= off) { const int n0 = p0 ? f1 : f0, n1 = p1 ? f1 : f0; f0 = n0; f1 = n1; }
+        }
+        const int in = __shfl_up(f0, 1);
+        evm = (lane > 0 && in) ? ev1 : ev0;
+        int cnt = __popcll(evm);
+        const int mine = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(cnt, off);
+            if (lane >= off) cnt += t;
+        }
+        kexcl = cnt - mine;
+        K = __builtin_amdgcn_readlane(cnt, 63);
+        if (MACD) { // chunk-mapped bits -> block words, through LDS
+            evw[lane] = 0;
+            unsigned long long e = evm;
+            while (e) {
+                const int row = lane * C + __builtin_ctzll(e);
+                e &= e - 1;
+                atomicOr(&evw[row >> 6], 1ULL << (row & 63));
+            }
+            btw_lds_fence();
+            myword = evw[lane];
+        } else myword = evm;
+    }
+    BTW_T(1);
+
     double pos = 0.0, avail = prm.initial_capital, entry_cost = 0.0;
     int trades = 0, wins = 0;
     bool flat = true;
-    int cq = 0, cb = 0; // search cursor: chunk / word, bit
+    // The serial part of a symbol is the cash recurrence through its ~100 round trips, and an f64 operation that waits for its
+    // predecessor costs ~22 cycles on this chip (scripts/ubench/f64lat.hip): the IEEE division in qty = floor(cash * size / exec)
+    // alone is 13 dependent operations.  exec depends on the price only, so its reciprocal is taken lane-parallel, OFF the chain,
+    // and the chain uses q~ = deploy * (1 / exec): two roundings instead of one, |q~ - RN(deploy / exec)| <= 1.5 * 2^-52 * q.
+    // floor(q~) can differ from floor(RN(deploy / exec)) only if q~ lies within that distance of an integer; such a row
+    // (probability ~1e-11), a non-finite / huge q~ and a buy that cannot afford a share are not decided by the fast forms: they
+    // set `bad`, and the walk is then repeated from its saved state with the reference's own operations.  No branch in the chain.
+    bool bad = false;
+    auto buy_fast = [&](double p, double r) { // vectorized.rs:146-161 on a flat pool (pos == +0.0: cash + pos * price == cash)
+        const double exec = p + prm.buy_slippage;
+        const double deploy = avail * prm.position_size;
+        const double qa = deploy * r;
+        const double qty = floor(qa);
+        // decided here only if 1 <= q~ < 2^28 and its fraction lies in (2^-22, 1 - 2^-22) (the admissible error is q~ * 2^-51 <=
+        // 2^-23); the two range tests are integer compares on the high words, off the f64 dependency chain
+        const unsigned hq = (unsigned)(btw_bits(qa) >> 32), hf = (unsigned)(btw_bits(qa - qty) >> 32);
+        bad |= (hq - 0x3FF00000u) >= (0x41B00000u - 0x3FF00000u) || (hf - 0x3E900000u) >= (0x3FEFFFFEu - 0x3E900000u);
+        const double cost = qty * exec;
+        const double fee = fmax(cost * prm.buy_commission_rate, prm.min_commission);
+        pos += qty;
+        avail -= cost + fee;
+        entry_cost = pos * p;
+        trades += 1;
+    };
+    auto sell_fast = [&](double p) { // :162-175
+        const double exec = p - prm.sell_slippage;
+        const double revenue = pos * exec;
+        const double fee = fmax(revenue * prm.sell_commission_rate, prm.min_commission);
+        const double net = revenue - fee;
+        wins += net > entry_cost ? 1 : 0;
+        avail += net;
+        pos = 0.0;
+    };
+    // The reference's own operations (an infinite price makes qty NaN there and 0 here: no trade either way).
+    auto trade = [&](double p) -> bool { // false: a buy that cannot afford one share, nothing changes
+        if (flat) {
+            const double exec = p + prm.buy_slippage;
+            const double deploy = avail * prm.position_size;
+            const double qty = floor(deploy / exec);
+            if (!(qty > 0.0)) return false;
+            const double cost = qty * exec;
+            const double fee = fmax(cost * prm.buy_commission_rate, prm.min_commission);
+            pos += qty;
+            avail -= cost + fee;
+            entry_cost = pos * p;
+            trades += 1;
+            flat = false;
+        } else {
+            sell_fast(p);
+            flat = true;
+        }
+        return true;
+    };
+
+    // ---- phases 3 + 4, dense form (the usual case): the events' prices are gathered into a list, the chain runs over the list,
+    // the rows are filled from the list of states afterwards -- the chain sees no stores and the stores are 16 bytes per lane.
+    bool dense = K <= a.kcap;
+    if (dense) {
+        { // event k of the symbol -> evp[k] = its price (the lane that owns the row knows k)
+            unsigned long long e = evm;
+            int k = kexcl;
+            while (e) {
+                const int b = __builtin_ctzll(e);
+                e &= e - 1;
+                evp[k++] = MACD ? px[lane * P + b] : px[addr(64 * lane + b)];
+            }
+        }
+        btw_lds_fence();
+        // event k lives in lane k & 63 of register group k >> 6: the chain takes its inputs with v_readlane and leaves its results
+        // with a lane-select -- no LDS round trip, no wait inside the recurrence
+        double ev[BTW_NG], rv[BTW_NG], tpv[BTW_NG], tcv[BTW_NG];
+#pragma unroll
+        for (int g = 0; g < BTW_NG; g++) {
+            ev[g] = 1.0; rv[g] = 1.0; tpv[g] = 0.0; tcv[g] = 0.0;
+            if (64 * g < K) {
+                if (64 * g + lane < K) ev[g] = evp[64 * g + lane];
+                rv[g] = 1.0 / (ev[g] + prm.buy_slippage); // the pool starts flat: even events are buys (odd lanes: unused)
+            }
+        }
+        BTW_T(8);
+        // One round trip = one basic block: the sell's arithmetic overlaps the tail of the buy's dependency chain.
+#pragma unroll
+        for (int g = 0; g < BTW_NG; g++) {
+            if (64 * g < K) {
+                const int n = K - 64 * g < 64 ? K - 64 * g : 64;
+                for (int t0 = 0; t0 + 1 < n; t0 += 2) {
+                    const int t = __builtin_amdgcn_readfirstlane(t0);
+                    const double pb = btw_readlane(ev[g], t), rb = btw_readlane(rv[g], t), psl = btw_readlane(ev[g], t + 1);
+                    buy_fast(pb, rb);
+                    if (lane == t) { tpv[g] = pos; tcv[g] = avail; }
+                    sell_fast(psl);
+                    if (lane == t + 1) tcv[g] = avail; // the position after a sell is 0.0
+                }
+                if (n & 1) { // last event of the series: the position stays open
+                    buy_fast(btw_readlane(ev[g], n - 1), btw_readlane(rv[g], n - 1));
+                    if (lane == n - 1) { tpv[g] = pos; tcv[g] = avail; }
+                }
+            }
+        }
+        // after event k: evr[k] = position, evp[k] = cash (the fill looks states up by event count)
+#pragma unroll
+        for (int g = 0; g < BTW_NG; g++)
+            if (64 * g + lane < K) { evr[64 * g + lane] = tpv[g]; evp[64 * g + lane] = tcv[g]; }
+        flat = !(K & 1);
+        btw_lds_fence();
+        BTW_T(9);
+        if (bad) { // wave-uniform: start over in the block form below
+            dense = false;
+            pos = 0.0; avail = prm.initial_capital; entry_cost = 0.0; trades = 0; wins = 0; flat = true;
+        }
+    }
+    if (dense) { // fill: 128 rows per step, lane l = rows 128 * jj + 2 * l, + 1
+        const int nb2 = (T + 127) / 128;
+        const bool wide = (((a.position ? reinterpret_cast<uintptr_t>(a.position + base) : 0) | (a.cash ? reinterpret_cast<uintptr_t>(a.cash + base) : 0) |
+                            (a.equity ? reinterpret_cast<uintptr_t>(a.equity + base) : 0)) & 15) == 0;
+        int kbase = 0;
+        const int b0 = (2 * lane) & 63;
+        const bool upper = lane >= 32;
+        for (int jj0 = 0; jj0 < nb2; jj0++) {
+            const int jj = __builtin_amdgcn_readfirstlane(jj0);
+            const unsigned long long w0 = btw_readlane(myword, 2 * jj), w1 = btw_readlane(myword, 2 * jj + 1);
+            const int i0 = 128 * jj + 2 * lane;
+            const unsigned long long ws = upper ? w1 : w0;
+            const int c0 = __popcll(w0);
+            const int idx0 = kbase + (upper ? c0 : 0) + __popcll(ws & ((2ULL << b0) - 1ULL)); // events at rows <= i0
+            const int idx1 = idx0 + (int)((ws >> (b0 + 1)) & 1ULL);
+            const int a0 = addr(i0), a1 = addr(i0 + 1);
+            double x0 = px[a0], x1 = px[a1];
+            double p0 = 0.0, c_0 = prm.initial_capital, p1 = 0.0, c_1 = prm.initial_capital;
+            if (idx0 > 0) { p0 = evr[idx0 - 1]; c_0 = evp[idx0 - 1]; }
+            if (idx1 > 0) { p1 = evr[idx1 - 1]; c_1 = evp[idx1 - 1]; }
+            if (pq_isnull(x0)) x0 = __longlong_as_double(0x7FF8000000000000LL); // null -> NaN (vectorized.rs:70-78)
+            if (pq_isnull(x1)) x1 = __longlong_as_double(0x7FF8000000000000LL);
+            const double e0 = c_0 + p0 * x0, e1 = c_1 + p1 * x1;
+            if (wide && i0 + 1 < T) {
+                if (a.position) nt_store2(a.position + base + i0, make_double2(p0, p1));
+                if (a.cash) nt_store2(a.cash + base + i0, make_double2(c_0, c_1));
+                if (a.equity) nt_store2(a.equity + base + i0, make_double2(e0, e1));
+            } else {
+                if (i0 < T) {
+                    if (a.position) __builtin_nontemporal_store(p0, &a.position[base + i0]);
+                    if (a.cash) __builtin_nontemporal_store(c_0, &a.cash[base + i0]);
+                    if (a.equity) __builtin_nontemporal_store(e0, &a.equity[base + i0]);
+                }
+                if (i0 + 1 < T) {
+                    if (a.position) __builtin_nontemporal_store(p1, &a.position[base + i0 + 1]);
+                    if (a.cash) __builtin_nontemporal_store(c_1, &a.cash[base + i0 + 1]);
+                    if (a.equity) __builtin_nontemporal_store(e1, &a.equity[base + i0 + 1]);
+                }
+            }
+            if (i0 < 64 * C) { px[a0] = e0; px[a1] = e1; }
+            kbase += c0 + __popcll(w1);
+        }
+    }
+
+    // ---- phases 3 + 4, block form (more events than the lists hold, or a row the fast chain could not decide): per 64-row
+    // block, the block's events in order with the reference's operations, then its rows
+    bool searching = false; // true after a buy failed: the precomputed events no longer hold, search the signal masks instead
+    int cq = 0, cb = 0;     // search cursor: chunk / word, bit
     auto find = [&]() -> int { // next row >= cursor whose (valid-price) signal the pool can act on; -1 if none
         unsigned long long m = flat ? bmask : smask;
         if (lane < cq) m = 0;
@@ -264,66 +585,47 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
         cq = c1; cb = b1 + 1;
         return c1 * CQ + b1;
     };
-    int r = find();
-    const int nblk = (T + 63) / 64;
-    for (int j = 0; j < nblk; j++) {
-        int nev = 0;
-        if (lane == 0) { tab[0] = pos; tab[BTW_TAB] = avail; }
-        bool evb = false;
-        const int rend = 64 * (j + 1);
-        while (r >= 0 && r < rend) {
-            const double p = px[addr(r)]; // wave-uniform address
-            bool ev = false;
-            if (flat) { // vectorized.rs:146-161
-                const double exec = p + prm.buy_slippage;
-                const double cur_eq = avail + pos * p;
-                const double deploy = cur_eq * prm.position_size;
-                const double qty = floor(deploy / exec);
-                if (qty > 0.0) {
-                    const double cost = qty * exec;
-                    const double fee = fmax(cost * prm.buy_commission_rate, prm.min_commission);
-                    pos += qty;
-                    avail -= cost + fee;
-                    entry_cost = pos * p;
-                    trades += 1;
-                    ev = true;
-                    flat = false;
-                }
-            } else { // :162-175
-                const double exec = p - prm.sell_slippage;
-                const double revenue = pos * exec;
-                const double fee = fmax(revenue * prm.sell_commission_rate, prm.min_commission);
-                const double net = revenue - fee;
-                if (net > entry_cost) wins += 1;
-                avail += net;
-                pos = 0.0;
-                ev = true;
-                flat = true;
-            }
-            if (ev) {
-                nev++;
-                if (lane == 0) { tab[nev] = pos; tab[BTW_TAB + nev] = avail; }
-                evb |= lane == (r & 63);
-            }
-            r = find();
-        }
-        btw_lds_sync();
+    int r = -1;
+    const int nblk = dense ? 0 : (T + 63) / 64;
+    for (int j0 = 0; j0 < nblk; j0++) {
+        const int j = __builtin_amdgcn_readfirstlane(j0);
         const int i = 64 * j + lane;
-        const unsigned long long bal = btw_ballot(evb);
-        const int idx = __popcll(bal & ((2ULL << lane) - 1ULL)); // events at rows <= mine in this block
-        const double pi = tab[idx], ci = tab[BTW_TAB + idx];
         const int ai = addr(i);
         double x = px[ai];
+        double tp = pos, tc = avail; // state after the last event at or before my row
+        unsigned long long w = searching ? 0ULL : btw_readlane(myword, j);
+        while (w) {
+            const int l = __builtin_ctzll(w);
+            if (!trade(btw_readlane(x, l))) {
+                searching = true;
+                const int nxt = 64 * j + l + 1;
+                cq = MACD ? (int)(((unsigned)nxt * magic) >> 20) : nxt >> 6;
+                cb = nxt - cq * CQ;
+                r = find();
+                break;
+            }
+            w &= w - 1;
+            if (lane >= l) { tp = pos; tc = avail; }
+        }
+        if (searching) {
+            const int rend = 64 * (j + 1);
+            while (r >= 0 && r < rend) {
+                const int l = r & 63;
+                if (trade(btw_readlane(x, l)) && lane >= l) { tp = pos; tc = avail; }
+                r = find();
+            }
+        }
         if (pq_isnull(x)) x = __longlong_as_double(0x7FF8000000000000LL); // null -> NaN (vectorized.rs:70-78)
-        const double eq = ci + pi * x;
+        const double eq = tc + tp * x;
         if (i < T) {
-            if (a.position) __builtin_nontemporal_store(pi, &a.position[base + i]);
-            if (a.cash) __builtin_nontemporal_store(ci, &a.cash[base + i]);
+            if (a.position) __builtin_nontemporal_store(tp, &a.position[base + i]);
+            if (a.cash) __builtin_nontemporal_store(tc, &a.cash[base + i]);
             if (a.equity) __builtin_nontemporal_store(eq, &a.equity[base + i]);
         }
         px[ai] = eq;
-        btw_lds_sync();
     }
+    btw_lds_fence();
+    BTW_T(2);
     if (!a.summary) return;
 
     // ---- summary (metrics.rs:7-152): lane c owns rows [c*C, (c+1)*C) of the equity row now in LDS
@@ -345,15 +647,27 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     if (c > 0 && nrow > 0) prev = px[addr(lo - 1)];
     const double last_eq = px[addr(T - 1)];
     double max_dd = 0.0, rs = 0.0;
-    for (int b = 0; b < nrow; b++) { // metrics.rs:26-49
-        const double e = erow[b];
-        if (e > max_eq) max_eq = e;
-        const double dd = (max_eq > 0.0) ? (max_eq - e) / max_eq : 0.0;
-        if (dd > max_dd) max_dd = dd;
-        const double rr = (prev > 0.0) ? (e - prev) / prev : 0.0;
-        rs += rr;
-        erow[b] = rr;
-        prev = e;
+    for (int b0 = 0; b0 < nrow; b0 += 4) { // metrics.rs:26-49, four rows at a time: their eight divisions overlap
+        double e[4], mx[4], pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = b0 + u < nrow ? erow[b0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (b0 + u < nrow && e[u] > max_eq) max_eq = e[u];
+            mx[u] = max_eq;
+            pv[u] = prev;
+            if (b0 + u < nrow) prev = e[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double dd = (mx[u] > 0.0) ? (mx[u] - e[u]) / mx[u] : 0.0;
+            const double rr = (pv[u] > 0.0) ? (e[u] - pv[u]) / pv[u] : 0.0;
+            if (b0 + u < nrow) {
+                if (dd > max_dd) max_dd = dd;
+                rs += rr;
+                erow[b0 + u] = rr;
+            }
+        }
     }
     auto wave_sum = [&](double v) { // fixed order, the same value on every lane
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -410,6 +724,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
         sm[0] = ann; sm[1] = max_dd; sm[2] = alpha; sm[3] = beta; sm[4] = sharpe;
         sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
     }
+    BTW_T(3);
 }
 
 // host side: shape of the wave form for a batch, or false when it does not apply (len > 64 * BTW_MAX_C)
@@ -434,6 +749,8 @@ static inline bool btw_plan(const pq_batch *b, int64_t fast, int64_t slow, int64
         if (nW < 1) nW = 1;
         a.nW = (int32_t)(nW > 64 ? 64 : nW);
     }
-    lds_bytes = (size_t)64 * a.P * 8 * (bench ? 2 : 1) + 2 * BTW_TAB * 8;
+    a.kcap = 8 * C < T + 1 ? 8 * C : T + 1; // ~12 % of the rows may be events (MACD(12,26,9): 8 %) before the block form takes over
+    if (a.kcap > 64 * BTW_NG) a.kcap = 64 * BTW_NG;
+    lds_bytes = (size_t)64 * a.P * 8 * (bench ? 2 : 1) + 64 * 8 + 2 * (size_t)a.kcap * 8;
     return true;
 }

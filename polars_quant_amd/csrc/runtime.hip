@@ -97,8 +97,8 @@ pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out) {
     c->rec = nullptr;
     c->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
     c->own_stream = false;
-    hipError_t e = hipMalloc((void **)&c->d_flag, 8 * sizeof(int64_t)); // [0] reduction scalar, [4..6] wave-backtest statistics
-    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 8 * sizeof(int64_t));
+    hipError_t e = hipMalloc((void **)&c->d_flag, 32 * sizeof(int64_t)); // [0] reduction scalar, [4..6] wave-backtest statistics (+ [8..23] profiling builds)
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 32 * sizeof(int64_t));
     if (e != hipSuccess) { if (c->own_stream) (void)hipStreamDestroy(c->stream); delete c; pq_set_error("hipMalloc: %s", hipGetErrorString(e)); return PQ_ERR_NOMEM; }
     *out = c;
     return PQ_OK;
