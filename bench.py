@@ -109,6 +109,57 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
     return res
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: N child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    as torch.distributed.run would set them).  The parent has made no HIP call (torch.cuda.device_count() does not initialise
+    the runtime), so the children are ordinary fresh processes; rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n and not args.dry_run:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this host shows {have}; not running a {have}-GPU job under the name "
+              f"of an {n}-GPU one", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
+def dry_run(args):
+    """What each rank would own, through the same rendezvous (gloo, CPU only): rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    from polars_quant_amd.distributed import shard_range
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if args.scaling == "strong":
+        lo, hi = shard_range(args.symbols, rank, world)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "symbols": [lo, hi], "seed": SEED}
+    else:
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "symbols": [rank * args.symbols, (rank + 1) * args.symbols],
+                "seed": SEED + rank}
+    shards = [mine]
+    if world > 1:
+        shards = [None] * world
+        dist.all_gather_object(shards, mine)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": args.scaling, "days": args.days,
+                          "symbols_total": args.symbols if args.scaling == "strong" else args.symbols * world,
+                          "world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": "gloo" if world > 1 else None,
+                          "shards": shards}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +172,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stride", type=int, default=0,
                     help="row pitch of the device columns in elements (0 = days rounded up to a multiple of 16 = 128 B; = days: dense)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / shard ranges only (gloo on the CPU, no GPU work): what `--gpus N` would run where")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))   # this process never touches the GPU: it starts one fresh process per rank
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} (launch with --nproc-per-node {args.gpus})", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -186,6 +247,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the same exchange through the C ABI's own entry point (pq_comm_init + pq_gather_summaries: what a non-Python host calls),
+    # once, outside the timed region, checked against the torch.distributed result
+    cabi_gather = None
+    if world > 1:
+        try:
+            from polars_quant_amd.distributed import CabiComm
+            ref = gather_summaries(suite.summary, n_total)
+            comm = CabiComm(dev, rank, world)
+            got = comm.gather_summaries(suite.summary, n_total)
+            torch.cuda.synchronize()
+            cabi_gather = "ok" if torch.equal(got.view(torch.int64), ref.view(torch.int64)) else "MISMATCH"
+            comm.close()
+        except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for the measurement
+            cabi_gather = f"failed: {e}"
+
     # ---- roofline of the dominant kernel ----------------------------------------------------------------
     # The step's device time is dominated by seq_jobs_kernel<0>: the tiled bodies of all sequential jobs, two launches per
     # step (one per LDS class) that run CONCURRENTLY with each other, with seq_jobs_kernel<1> (register-heavy jobs) and with
@@ -228,6 +304,9 @@ def main():
             "value": rows_total / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "collective": ({"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                            "per_step": "one all_gather of the [n_local, 8] summary rows", "c_abi_gather": cabi_gather}
+                           if world > 1 else None),
             "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
                                    f"recognisers) + fused MACD-cross backtest with summary, {n_local} symbols x {T} days "
                                    "f64 OHLCV per GPU, inputs resident in HBM",

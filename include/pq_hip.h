@@ -281,6 +281,21 @@ pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close,
  * reset, [1] chunks that failed the bit test, [2] chunk re-runs.  Synchronises the context's stream. */
 pq_status pq_backtest_wave_stats(pq_ctx *, int64_t *out3, int32_t reset);
 
+/* ---- multi-GPU: symbols are split statically over the ranks -- rank r of G owns [floor(N r / G), floor(N (r + 1) / G)),
+ * a contiguous byte range of every symbol-major column -- and every rank runs the calls above on its own shard with no
+ * communication.  The one exchange is the per-symbol summary table (reference: the dict of vectorized.rs:204-223 per symbol):
+ *   pq_comm_unique_id   rank 0 makes the 128-byte rendezvous id; the HOST ships it to the other ranks (its own channel)
+ *   pq_comm_init        collective over the `world` ranks (one process per GPU); RCCL is bound at run time (dlopen)
+ *   pq_gather_summaries local [n_local][8] (this rank's shard, device) -> all [n_symbols][8] (device, symbol order) on every
+ *                       rank, on the context's stream: one ncclAllGather when the shards are equal, else one grouped broadcast
+ *                       per rank */
+#define PQ_COMM_ID_BYTES 128
+pq_status pq_comm_unique_id(void *id128);
+pq_status pq_comm_init(pq_ctx *, int32_t rank, int32_t world, const void *id128);
+pq_status pq_comm_destroy(pq_ctx *);
+pq_status pq_shard_range(int64_t n_symbols, int32_t rank, int32_t world, int64_t *lo, int64_t *hi);
+pq_status pq_gather_summaries(pq_ctx *, const double *local, int64_t n_symbols, double *all);
+
 /* ---- the README's `Strategy` signal rules (README.md:862-994; README-only, decision D-11 in
  * oracle/backtest.c): indicator columns -> uint8 buy / sell columns for the backtests above.  Row-parallel.
  *   cross:   buy = a[i-1] <= b[i-1] && a[i] > b[i];  sell mirrored            (MA / MACD / STOCH / trend strategies)

@@ -87,6 +87,16 @@ def lib() -> C.CDLL:
         L.pq_backtest_macd_cross.restype = C.c_int32
         L.pq_backtest_macd_cross.argtypes = [vp, C.POINTER(Batch), vp, C.c_int64, C.c_int64, C.c_int64,
                                              C.POINTER(BtParams), vp, vp, vp, vp]
+        L.pq_comm_unique_id.restype = C.c_int32
+        L.pq_comm_unique_id.argtypes = [vp]
+        L.pq_comm_init.restype = C.c_int32
+        L.pq_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
+        L.pq_comm_destroy.restype = C.c_int32
+        L.pq_comm_destroy.argtypes = [vp]
+        L.pq_shard_range.restype = C.c_int32
+        L.pq_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.pq_gather_summaries.restype = C.c_int32
+        L.pq_gather_summaries.argtypes = [vp, vp, C.c_int64, vp]
         L.pq_backtest_wave_stats.restype = C.c_int32
         L.pq_backtest_wave_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
         L.pq_macd_cross_signals.restype = C.c_int32

@@ -1,0 +1,132 @@
+// comm.hip -- the ONE exchange of the path: the per-symbol summary rows [n_local][8] of every rank's shard to every
+// rank, by RCCL over xGMI on the context's stream.  Symbols are split statically -- rank r of G owns [floor(N r / G),
+// floor(N (r + 1) / G)) -- and nothing else of the hot path communicates.  RCCL is bound at run time (dlopen) on the first
+// pq_comm_* call: the single-GPU library has no link-time dependency on it, and a host process that already carries an RCCL
+// (PyTorch bundles one) shares that copy instead of loading a second one.
+#include "pq_dev.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and enums only
+
+namespace {
+struct Rccl {
+    void *so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+pq_status rccl_load() {
+    if (g_rccl.so) return PQ_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void *so = nullptr;
+    for (const char *n : names) {
+        so = dlopen(n, RTLD_NOW | RTLD_NOLOAD); // a copy the process already holds (PyTorch's) comes first
+        if (so) break;
+    }
+    for (size_t k = 0; !so && k < sizeof names / sizeof *names; k++) so = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+    if (!so) { pq_set_error("RCCL is not loadable (librccl.so): %s", dlerror()); return PQ_ERR_UNSUPPORTED; }
+    Rccl r;
+    r.so = so;
+#define PQ_SYM(field, name)                                                                     \
+    *reinterpret_cast<void **>(&r.field) = dlsym(so, name);                                     \
+    if (!r.field) { pq_set_error("RCCL symbol %s not found", name); dlclose(so); return PQ_ERR_UNSUPPORTED; }
+    PQ_SYM(GetUniqueId, "ncclGetUniqueId")
+    PQ_SYM(CommInitRank, "ncclCommInitRank")
+    PQ_SYM(CommDestroy, "ncclCommDestroy")
+    PQ_SYM(GroupStart, "ncclGroupStart")
+    PQ_SYM(GroupEnd, "ncclGroupEnd")
+    PQ_SYM(AllGather, "ncclAllGather")
+    PQ_SYM(Broadcast, "ncclBroadcast")
+    PQ_SYM(GetErrorString, "ncclGetErrorString")
+#undef PQ_SYM
+    g_rccl = r;
+    return PQ_OK;
+}
+#define PQ_NCCL_TRY(expr)                                                                                        \
+    do {                                                                                                         \
+        ncclResult_t r__ = (expr);                                                                               \
+        if (r__ != ncclSuccess) { pq_set_error("%s failed: %s", #expr, g_rccl.GetErrorString(r__)); return PQ_ERR_HIP; } \
+    } while (0)
+} // namespace
+
+extern "C" {
+
+pq_status pq_comm_unique_id(void *id128) {
+    PQ_REQUIRE(id128, "pq_comm_unique_id: null pointer");
+    PQ_TRY(rccl_load());
+    static_assert(sizeof(ncclUniqueId) == PQ_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    PQ_NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return PQ_OK;
+}
+
+pq_status pq_comm_init(pq_ctx *ctx, int32_t rank, int32_t world, const void *id128) {
+    PQ_REQUIRE(ctx && id128, "pq_comm_init: null pointer");
+    PQ_REQUIRE(world >= 1 && rank >= 0 && rank < world, "pq_comm_init: need 0 <= rank < world");
+    PQ_REQUIRE(!ctx->comm, "pq_comm_init: the context already has a communicator");
+    PQ_TRY(rccl_load());
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    PQ_NCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return PQ_OK;
+}
+
+pq_status pq_comm_destroy(pq_ctx *ctx) {
+    PQ_REQUIRE(ctx, "pq_comm_destroy: null pointer");
+    if (!ctx->comm) return PQ_OK;
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PQ_NCCL_TRY(g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(ctx->comm)));
+    ctx->comm = nullptr;
+    ctx->comm_world = 0;
+    return PQ_OK;
+}
+
+pq_status pq_shard_range(int64_t n_symbols, int32_t rank, int32_t world, int64_t *lo, int64_t *hi) {
+    PQ_REQUIRE(lo && hi && n_symbols >= 0 && world >= 1 && rank >= 0 && rank < world, "pq_shard_range: bad argument");
+    *lo = (int64_t)((__int128)n_symbols * rank / world);
+    *hi = (int64_t)((__int128)n_symbols * (rank + 1) / world);
+    return PQ_OK;
+}
+
+pq_status pq_gather_summaries(pq_ctx *ctx, const double *local, int64_t n_symbols, double *all) {
+    PQ_REQUIRE(ctx && all, "pq_gather_summaries: null pointer");
+    PQ_REQUIRE(n_symbols >= 0, "pq_gather_summaries: n_symbols < 0");
+    PQ_REQUIRE(ctx->comm, "pq_gather_summaries: call pq_comm_init first");
+    PQ_REQUIRE(!ctx->rec, "pq_gather_summaries cannot be recorded into a suite (call it after pq_suite_run)");
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    const int G = ctx->comm_world;
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(ctx->comm);
+    int64_t lo, hi;
+    PQ_TRY(pq_shard_range(n_symbols, ctx->comm_rank, G, &lo, &hi));
+    PQ_REQUIRE(local || hi == lo, "pq_gather_summaries: null pointer");
+    if (n_symbols % G == 0) { // equal shards: one all-gather
+        if (n_symbols > 0)
+            PQ_NCCL_TRY(g_rccl.AllGather(local, all, (size_t)(hi - lo) * PQ_SUMMARY_COLS, ncclFloat64, comm, ctx->stream));
+        return PQ_OK;
+    }
+    // ragged shards: every rank's rows are broadcast into their place, as one group (one launch per peer, all links busy at once)
+    if (hi > lo) PQ_HIP_TRY(hipMemcpyAsync(all + lo * PQ_SUMMARY_COLS, local, (size_t)(hi - lo) * PQ_SUMMARY_COLS * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    PQ_NCCL_TRY(g_rccl.GroupStart());
+    for (int r = 0; r < G; r++) {
+        int64_t a, b;
+        PQ_TRY(pq_shard_range(n_symbols, r, G, &a, &b));
+        if (b == a) continue;
+        double *dst = all + a * PQ_SUMMARY_COLS;
+        PQ_NCCL_TRY(g_rccl.Broadcast(dst, dst, (size_t)(b - a) * PQ_SUMMARY_COLS, ncclFloat64, r, comm, ctx->stream));
+    }
+    PQ_NCCL_TRY(g_rccl.GroupEnd());
+    return PQ_OK;
+}
+
+} // extern "C"

@@ -28,6 +28,8 @@ struct pq_ctx {
     size_t ws_bytes;
     int64_t *d_flag; // 8 x int64 device scalars: [0] reductions, [4..6] statistics of the wave-per-symbol backtest
     Recorder *rec;   // non-null while a suite is being recorded
+    void *comm;      // ncclComm_t of pq_comm_init (comm.hip), or null
+    int comm_rank, comm_world;
 };
 
 void pq_set_error(const char *fmt, ...);

@@ -95,6 +95,9 @@ pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out) {
     c->ws_bytes = 0;
     c->d_flag = nullptr;
     c->rec = nullptr;
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 0;
     c->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
     c->own_stream = false;
     hipError_t e = hipMalloc((void **)&c->d_flag, 32 * sizeof(int64_t)); // [0] reduction scalar, [4..6] wave-backtest statistics (+ [8..23] profiling builds)
@@ -107,6 +110,7 @@ pq_status pq_ctx_destroy(pq_ctx *ctx) {
     if (!ctx) return PQ_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)pq_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -88,3 +88,42 @@ def factor_ic_day_sharded(factor_local, fwd_local, n_symbols: int, method: int =
     r = days_all_to_all(fwd_local, n_symbols, group)
     ic, nv = compute(f, r, method)
     return gather_day_series(ic, T, group), gather_day_series(nv, T, group)
+
+
+class CabiComm:
+    """The C ABI's own communicator (pq_comm_init / pq_gather_summaries, csrc/comm.hip): what a non-Python host uses.  The
+    128-byte rendezvous id is made by rank 0 and shipped here through torch.distributed (a Rust host would use its own channel)."""
+
+    def __init__(self, device, rank: int, world: int, group=None):
+        import ctypes as C
+
+        from . import api
+        from ._lib import check, lib
+        self._C, self._check, self._lib = C, check, lib()
+        self.device = torch.device(device)
+        self.h = api.ctx(self.device.index)
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_ubyte * 128)()
+            check(self._lib.pq_comm_unique_id(raw))
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        if world > 1:
+            on = idbuf.to(self.device) if dist.get_backend(group) == "nccl" else idbuf
+            dist.broadcast(on, src=0, group=group)
+            idbuf = on.cpu()
+        raw = (C.c_ubyte * 128)(*idbuf.tolist())
+        with torch.cuda.device(self.device):
+            check(self._lib.pq_comm_init(self.h, rank, world, raw))
+        self.rank, self.world = rank, world
+
+    def gather_summaries(self, local: torch.Tensor, n_symbols: int) -> torch.Tensor:
+        C = self._C
+        out = torch.empty((n_symbols, local.shape[1]), dtype=local.dtype, device=local.device)
+        loc = local.contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.pq_gather_summaries(self.h, C.c_void_p(loc.data_ptr()), n_symbols, C.c_void_p(out.data_ptr())))
+        return out
+
+    def close(self):
+        with torch.cuda.device(self.device):
+            self._check(self._lib.pq_comm_destroy(self.h))

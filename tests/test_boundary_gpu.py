@@ -223,3 +223,21 @@ def test_returns_reference_vector_and_parity(oracle):
                 np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-12, atol=1e-15)
     with pytest.raises(ValueError):
         pq.returns(x, method="geometric")
+
+
+def test_c_abi_communicator_and_summary_gather_single_rank(L):
+    """pq_comm_unique_id / pq_comm_init / pq_gather_summaries / pq_comm_destroy through RCCL with a world of one (the only world a
+    one-GPU box has): the call sequence a non-Python host performs; ranks > 1 differ only in the peers RCCL connects."""
+    import polars_quant_amd as pq
+    from polars_quant_amd.distributed import CabiComm
+    s = torch.arange(13 * 8, dtype=torch.float64, device="cuda").reshape(13, 8) * 0.5
+    comm = CabiComm("cuda:0", 0, 1)
+    out = comm.gather_summaries(s, 13)
+    torch.cuda.synchronize()
+    assert torch.equal(out, s) and out.data_ptr() != s.data_ptr()
+    with pytest.raises(pq.PqError):          # a second communicator on the same context is an error, not a leak
+        CabiComm("cuda:0", 0, 1)
+    comm.close()
+    comm = CabiComm("cuda:0", 0, 1)          # and it can be created again after the destroy
+    assert torch.equal(comm.gather_summaries(s[:5], 5), s[:5])
+    comm.close()

@@ -104,3 +104,56 @@ def test_two_rank_day_sharded_factor_ic(n_sym, T, oracle):
         gic, gnv = got[m]
         assert (gnv == env).all()
         assert ((gic.view(np.uint64) == eic.view(np.uint64)) | (np.isnan(gic) & np.isnan(eic))).all()
+
+
+def _run_bench(*argv, env=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, str(root / "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=e)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_gpus_flag_launches_one_process_per_rank():
+    """`python bench.py --gpus N` (no launcher) starts N ranks with the right shards; BASELINE config 3's strong split."""
+    p, lines = _run_bench("--gpus", "2", "--dry-run", "--scaling", "strong")
+    assert p.returncode == 0, p.stderr
+    assert len(lines) == 1, "rank 0 prints exactly one line"
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["symbols_total"] == 5000
+    assert [s["symbols"] for s in d["shards"]] == [[0, 2500], [2500, 5000]]
+    assert [s["rank"] for s in d["shards"]] == [0, 1] and [s["local_rank"] for s in d["shards"]] == [0, 1]
+    p, lines = _run_bench("--gpus", "3", "--dry-run", "--scaling", "strong", "--symbols", "1000")
+    assert [s["symbols"] for s in lines[0]["shards"]] == [[0, 333], [333, 666], [666, 1000]]       # ragged: floor(N r / G)
+    p, lines = _run_bench("--gpus", "2", "--dry-run")                                               # weak: 5000 per rank, own seeds
+    assert [s["symbols"] for s in lines[0]["shards"]] == [[0, 5000], [5000, 10000]] and lines[0]["symbols_total"] == 10000
+    assert lines[0]["shards"][0]["seed"] != lines[0]["shards"][1]["seed"]
+
+
+def test_bench_refuses_to_run_fewer_gpus_than_asked():
+    import torch
+    have = torch.cuda.device_count()
+    p, lines = _run_bench("--gpus", str(have + 2), "--steps", "1")
+    assert p.returncode != 0 and not lines, "an N-GPU run on fewer devices must fail loudly, not print n_gpus: 1"
+    assert "visible GPUs" in p.stderr
+    # under an external launcher the flag must agree with WORLD_SIZE
+    p, lines = _run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_shard_range_of_the_c_abi_matches_python():
+    import ctypes as C
+    from polars_quant_amd._lib import lib
+    from polars_quant_amd.distributed import shard_range
+    L = lib()
+    for n, g in ((5000, 8), (1000, 3), (7, 8), (0, 4), (10**12, 7)):
+        for r in range(g):
+            lo, hi = C.c_int64(), C.c_int64()
+            assert L.pq_shard_range(n, r, g, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == shard_range(n, r, g)
