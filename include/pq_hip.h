@@ -42,11 +42,20 @@ enum {
 
 typedef struct pq_ctx pq_ctx; /* device + stream + scratch workspace; one per host thread/stream */
 
-/* n_series series of `len` rows; consecutive series start `stride` elements apart (stride >= len) */
+/* n_series series of `len` rows; consecutive series start `stride` elements apart (stride >= len).
+ * RAGGED batches (offsets != NULL): what the reference sees under `.over("symbol")` -- one plugin call per group of whatever
+ * length the group has (python/polars_quant/talib/momentum.py:13-16, is_elementwise=False).  The columns are the LONG columns
+ * sorted by symbol; `offsets` is a DEVICE array of n_series + 1 row indices, series s = rows [offsets[s], offsets[s + 1]);
+ * `len` = the longest series, `stride` = the total row count offsets[n_series].  Every series is computed as if it were
+ * passed alone (a series shorter than a warm-up is all-null, as in the reference); output columns have the same long layout.
+ * Accepted by every indicator / pattern entry point, pq_backtest_vectorized, pq_backtest_macd_cross, pq_macd_cross_signals, the
+ * signal rules and pq_returns; the cross-sectional calls (pq_factor_ic, pq_portfolio_metrics, pq_backtest_leveraged with a
+ * benchmark) and suite recording return PQ_ERR_UNSUPPORTED. */
 typedef struct {
     int64_t n_series;
     int64_t len;
     int64_t stride;
+    const int64_t *offsets; /* NULL: the regular [n_series][stride] layout */
 } pq_batch;
 
 /* ---- runtime ---- */

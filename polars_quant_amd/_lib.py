@@ -28,7 +28,9 @@ class NullsNotAllowed(PqError):
 
 
 class Batch(C.Structure):
-    _fields_ = [("n_series", C.c_int64), ("len", C.c_int64), ("stride", C.c_int64)]
+    # offsets: device pointer to n_series + 1 int64 row indices of a RAGGED batch (then len = the longest series, stride = the
+    # total row count), or None for the regular [n_series][stride] layout (include/pq_hip.h)
+    _fields_ = [("n_series", C.c_int64), ("len", C.c_int64), ("stride", C.c_int64), ("offsets", C.c_void_p)]
 
 
 class BtParams(C.Structure):

@@ -138,16 +138,52 @@ def count_nulls(t: torch.Tensor) -> int:
     return n.value
 
 
-def call(name: str, *inputs, check_nulls: bool = False, **params):
-    """Run indicator `name` (lower-case plugin name, e.g. "ema") -> tuple of outputs."""
+def ragged_batch(offsets, device):
+    """offsets: n + 1 ascending row indices (series s = rows [offsets[s], offsets[s + 1]) of the long columns, sorted by symbol:
+    the groups of `.over("symbol")`) -> (Batch, the device copy it points at)."""
+    off = torch.as_tensor(np.asarray(offsets.cpu() if isinstance(offsets, torch.Tensor) else offsets), dtype=torch.int64).reshape(-1)
+    if off.numel() < 1 or (off.numel() > 1 and bool((off[1:] < off[:-1]).any())) or int(off[0]) < 0:
+        raise PqError("offsets must be n + 1 ascending, non-negative row indices")
+    n = off.numel() - 1
+    longest = int((off[1:] - off[:-1]).max()) if n else 0
+    total = int(off[-1])
+    dev_off = off.to(device)
+    return Batch(n, longest, total, C.c_void_p(dev_off.data_ptr())), dev_off
+
+
+def call(name: str, *inputs, check_nulls: bool = False, offsets=None, **params):
+    """Run indicator `name` (lower-case plugin name, e.g. "ema") -> tuple of outputs.
+    offsets: run it over the groups of LONG columns ([rows], sorted by symbol) instead of [N, T] matrices -- every group as if it
+    were passed alone, one launch for all of them (what the reference does with one plugin call per group under .over("symbol"))."""
     if name in PATTERN_NAMES:
-        return (cdl(name, *inputs, **params),)
+        return (cdl(name, *inputs, offsets=offsets, **params),)
     cols, pspec, outs, fam = SPEC[name] if name in SPEC else EXTRA[name]
     if len(inputs) != len(cols):
         raise TypeError(f"{name}() takes inputs {cols}")
     conv = [_to_device(x) for x in inputs]
     kind, squeeze = conv[0][1], conv[0][2]
     ts = _same_layout([c[0] for c in conv])
+    if offsets is not None:
+        if not squeeze:
+            raise PqError("with offsets the inputs are long columns [rows]")
+        ts = [t.contiguous() for t in ts]
+        dev = ts[0].device
+        b, keep = ragged_batch(offsets, dev)
+        if b.stride != ts[0].shape[1]:
+            raise PqError(f"offsets end at row {b.stride} but the columns have {ts[0].shape[1]} rows")
+        pvals = []
+        for pname, k, default in pspec:
+            v = params.pop(pname, default)
+            pvals.append(C.c_int64(int(v)) if k == I else C.c_double(float(v)))
+        if params:
+            raise TypeError(f"{name}() got unexpected parameters {sorted(params)}")
+        res = [torch.empty((1, b.stride), dtype=torch.float64 if dt == "f8" else torch.int32, device=dev) for _, dt in outs]
+        with torch.cuda.device(dev):
+            if b.n_series and b.stride:
+                check(getattr(lib(), "pq_" + name)(ctx(dev.index), C.byref(b), *[C.c_void_p(t.data_ptr()) for t in ts], *pvals,
+                                                   *[C.c_void_p(r.data_ptr()) for r in res]))
+        del keep
+        return tuple(_from_device(r, kind, True, oname) for r, (oname, _) in zip(res, outs))
     if fam == NB and (check_nulls or kind in (_Kind.ARROW, _Kind.POLARS)):
         for t in ts:
             if count_nulls(t):
@@ -171,12 +207,23 @@ def call(name: str, *inputs, check_nulls: bool = False, **params):
     return tuple(_from_device(r, kind, squeeze, oname) for r, (oname, _) in zip(res, outs))
 
 
-def cdl(name: str, open, high, low, close, penetration: float | None = None):
+def cdl(name: str, open, high, low, close, penetration: float | None = None, offsets=None):
     pid = PATTERN_NAMES.index(name)
     pen = PATTERN_PEN_DEFAULT[name] if penetration is None else float(penetration)
     conv = [_to_device(x) for x in (open, high, low, close)]
     kind, squeeze = conv[0][1], conv[0][2]
     ts = _same_layout([c[0] for c in conv])
+    if offsets is not None:
+        ts = [t.contiguous() for t in ts]
+        dev = ts[0].device
+        b, keep = ragged_batch(offsets, dev)
+        out = torch.zeros((1, b.stride), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            if b.n_series and b.stride:
+                check(lib().pq_cdl(ctx(dev.index), C.byref(b), pid, *[C.c_void_p(t.data_ptr()) for t in ts], C.c_double(pen),
+                                   C.c_void_p(out.data_ptr())))
+        del keep
+        return _from_device(out, kind, True, name)
     if kind in (_Kind.ARROW, _Kind.POLARS):
         for t in ts:
             if count_nulls(t):
@@ -208,8 +255,9 @@ def cdl_all(open, high, low, close, penetrations: dict | None = None, names=None
     return {nm: _from_device(o, kind, squeeze, nm) for nm, o in outs.items()}
 
 
-def backtest_vectorized(price, buy, sell, benchmark=None, want_curves: bool = True, **kw):
-    """Batched VectorizedBacktester.run(): -> (position, cash, equity, summary[N,8]) (curves None if not wanted)."""
+def backtest_vectorized(price, buy, sell, benchmark=None, want_curves: bool = True, offsets=None, **kw):
+    """Batched VectorizedBacktester.run(): -> (position, cash, equity, summary[N,8]) (curves None if not wanted).
+    offsets: the columns are long columns of ragged groups (see call()); summary [n_groups, 8]."""
     prm = BtParams(**{**BT_DEFAULTS, **kw})
     p, kind, squeeze = _to_device(price)
     bu, _, _ = _to_device(buy, torch.uint8)
@@ -217,6 +265,23 @@ def backtest_vectorized(price, buy, sell, benchmark=None, want_curves: bool = Tr
     p = p.contiguous(); bu = bu.contiguous(); se = se.contiguous()
     dev = p.device
     n, T = p.shape
+    if offsets is not None:
+        b, keep = ragged_batch(offsets, dev)
+        bm = _to_device(benchmark)[0].contiguous() if benchmark is not None else None
+        for nm, t in (("buy", bu), ("sell", se), ("benchmark", bm)):
+            if t is not None and t.shape != p.shape:
+                raise PqError(f"backtest_vectorized: `{nm}` must be a long column like `price`")
+        mk = lambda: torch.empty((1, b.stride), dtype=torch.float64, device=dev)
+        pos, cash, eq = (mk(), mk(), mk()) if want_curves else (None, None, None)
+        summ = torch.empty((b.n_series, 8), dtype=torch.float64, device=dev)
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(dev):
+            if b.n_series:
+                check(lib().pq_backtest_vectorized(ctx(dev.index), C.byref(b), vp(p), vp(bu), vp(se), vp(bm), C.byref(prm),
+                                                   vp(pos), vp(cash), vp(eq), vp(summ)))
+        del keep
+        f = lambda t, sq: _from_device(t, _Kind.TORCH if kind == _Kind.TORCH else _Kind.NUMPY, sq) if t is not None else None
+        return f(pos, True), f(cash, True), f(eq, True), f(summ, False)
     # the kernel indexes every column as base + s * stride: all of them must be [N, T] like the prices
     for nm, t in (("buy", bu), ("sell", se)):
         if t.shape == (1, T) and n > 1:
@@ -243,23 +308,30 @@ def backtest_vectorized(price, buy, sell, benchmark=None, want_curves: bool = Tr
     return f(pos), f(cash), f(eq), f(summ)
 
 
-def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, want_curves: bool = True, **kw):
-    """Fused MACD-cross strategy + per-symbol backtest + summary (one kernel)."""
+def backtest_macd_cross(close, fastperiod=12, slowperiod=26, signalperiod=9, want_curves: bool = True, offsets=None, **kw):
+    """Fused MACD-cross strategy + per-symbol backtest + summary (one kernel).  offsets: `close` is a long column of ragged
+    groups (see call()); the curves come back as long columns, the summary as [n_groups, 8]."""
     prm = BtParams(**{**BT_DEFAULTS, **kw})
     p, kind, squeeze = _to_device(close)
     p = p.contiguous()
     dev = p.device
     n, T = p.shape
     b = Batch(n, T, T)
-    mk = lambda: torch.empty((n, T), dtype=torch.float64, device=dev)
+    keep = None
+    if offsets is not None:
+        b, keep = ragged_batch(offsets, dev)
+        n = b.n_series
+    mk = lambda: torch.empty(tuple(p.shape), dtype=torch.float64, device=dev)
     pos, cash, eq = (mk(), mk(), mk()) if want_curves else (None, None, None)
     summ = torch.empty((n, 8), dtype=torch.float64, device=dev)
     vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     with torch.cuda.device(dev):
-        check(lib().pq_backtest_macd_cross(ctx(dev.index), C.byref(b), vp(p), fastperiod, slowperiod, signalperiod,
-                                           C.byref(prm), vp(pos), vp(cash), vp(eq), vp(summ)))
-    f = lambda t: _from_device(t, kind if kind in (_Kind.TORCH, _Kind.NUMPY) else _Kind.NUMPY, squeeze) if t is not None else None
-    return f(pos), f(cash), f(eq), f(summ)
+        if n:
+            check(lib().pq_backtest_macd_cross(ctx(dev.index), C.byref(b), vp(p), fastperiod, slowperiod, signalperiod,
+                                               C.byref(prm), vp(pos), vp(cash), vp(eq), vp(summ)))
+    del keep
+    f = lambda t, sq=squeeze: _from_device(t, kind if kind in (_Kind.TORCH, _Kind.NUMPY) else _Kind.NUMPY, sq) if t is not None else None
+    return f(pos), f(cash), f(eq), f(summ, squeeze and offsets is None)
 
 
 def backtest_wave_stats(reset: bool = False, device=None):

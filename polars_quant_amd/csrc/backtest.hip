@@ -104,7 +104,7 @@ pq_status pq_backtest_vectorized(pq_ctx *ctx, const pq_batch *b, const double *p
     pq_status wst;
     if (bt_wave(ctx, b, false, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
     if (!equity) {
-        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
+        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * batch_rows(b) * 8));
         a.equity = pq_ws_col(ctx, b, 0);
         if (!a.equity) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
     }
@@ -131,7 +131,7 @@ pq_status pq_backtest_macd_cross(pq_ctx *ctx, const pq_batch *b, const double *c
     }
     if (equity) a.equity = equity;
     else {
-        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
+        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * batch_rows(b) * 8));
         a.equity = pq_ws_col(ctx, b, 0);
         if (!a.equity) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
     }
@@ -185,7 +185,8 @@ pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *pr
     a.max_trades = max_trades; a.trade_count = trade_count; a.entry_day = entry_day; a.exit_day = exit_day; a.reason = reason;
     a.entry_price = entry_price; a.exit_price = exit_price; a.quantity = quantity; a.pnl = pnl; a.pnl_pct = pnl_pct;
     a.summary = summary; a.prm = *params;
-    if (b->stride % 8 == 0 && reinterpret_cast<uintptr_t>(buy) % 8 == 0 && reinterpret_cast<uintptr_t>(sell) % 8 == 0) {
+    PQ_REQUIRE(!(b->offsets && benchmark), "pq_backtest_leveraged: a shared benchmark series has no meaning for a ragged batch (pass NULL)");
+    if (!b->offsets && b->stride % 8 == 0 && reinterpret_cast<uintptr_t>(buy) % 8 == 0 && reinterpret_cast<uintptr_t>(sell) % 8 == 0) {
         LevOp op{};                        // tiled path: coalesced column traffic
         op.a = a; op.stride = b->stride;
         return launch_seq(ctx, b, op, InCols<1>{{price}}, OutCols<3>{{cash_net, stock_value, total_value}});
@@ -201,6 +202,7 @@ pq_status pq_portfolio_metrics(pq_ctx *ctx, const pq_batch *b, const double *tot
                                const double *benchmark, double *out) {
     PQ_TRY(pq_check(ctx, b));
     PQ_REQUIRE(total_value && out, "pq_portfolio_metrics: null pointer");
+    PQ_NO_RAGGED(b, "pq_portfolio_metrics");
     if (ctx->rec) { pq_set_error("pq_portfolio_metrics cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
     if (b->len == 0) return PQ_OK;
     const int64_t nblk = (b->n_series + PORTFOLIO_BLOCK - 1) / PORTFOLIO_BLOCK > 0 ? (b->n_series + PORTFOLIO_BLOCK - 1) / PORTFOLIO_BLOCK : 1;

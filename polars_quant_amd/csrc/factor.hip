@@ -372,6 +372,7 @@ pq_status pq_factor_ic(pq_ctx *ctx, const pq_batch *b, const double *factor, con
     PQ_REQUIRE(factor && fwd_return && ic, "pq_factor_ic: null pointer");
     PQ_REQUIRE(method == 0 || method == 1, "pq_factor_ic: method must be 0 (Pearson IC) or 1 (Spearman Rank-IC)");
     if (ctx->rec) { pq_set_error("pq_factor_ic cannot be recorded into a suite"); return PQ_ERR_UNSUPPORTED; }
+    PQ_NO_RAGGED(b, "pq_factor_ic (a cross-section needs every symbol on every day)");
     if (b->len == 0) return PQ_OK;
     const Dims d = dims_of(b);
     if (method == 0 || b->n_series == 0) {

@@ -6,7 +6,7 @@
 
 // ---------------------------------------------------------------- C ABI
 #define CHK(name, cond) PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(cond, name ": null pointer")
-#define WS(ncols) PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8))
+#define WS(ncols) PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * batch_rows(b) * 8))
 
 extern "C" {
 

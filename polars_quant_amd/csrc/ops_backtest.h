@@ -18,7 +18,7 @@ struct BtArgs {
 
 template <bool MACD_SIGNALS, bool SIGNALS_ONLY>
 __device__ __forceinline__ void backtest_body(const BtArgs &a, const Dims &d, int64_t s) {
-    const int64_t base = s * d.stride, T = d.len;
+    const int64_t base = dims_base(d, s), T = dims_len(d, s);
     const double *price = a.price + base;
     const pq_bt_params prm = a.prm;
 
@@ -239,7 +239,7 @@ struct BtMacdOp {
     // called once per live lane after every row of the series has been stored
     __device__ void finish(double *const *outp, const Dims &d, int64_t s) {
         if (summary == nullptr) return;
-        const int64_t T = d.len;
+        const int64_t T = dims_len(d, s);
         double *sm = summary + s * PQ_SUMMARY_COLS;
         if (T == 0) { for (int k = 0; k < 8; k++) sm[k] = 0.0; return; }
         const double DAYS = 252.0, RF = 0.03;
@@ -247,7 +247,7 @@ struct BtMacdOp {
         double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
         double mean = ret_sum / (double)T;
         double dof = fmax((double)T - 1.0, 1.0);
-        const double *eqr = outp[2] + s * d.stride;
+        const double *eqr = outp[2] + dims_base(d, s);
         double vs = 0.0, pe = prm.initial_capital;
         for (int64_t i = 0; i < T; i++) {
             double e = eqr[i];
@@ -346,7 +346,7 @@ struct LevArgs {
 static __global__ __launch_bounds__(SEQ_BLOCK) void lev_backtest_kernel(LevArgs a, Dims d) {
     const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
     if (s >= d.n) return;
-    const int64_t base = s * d.stride, T = d.len;
+    const int64_t base = dims_base(d, s), T = dims_len(d, s);
     const pq_lev_params prm = a.prm;
     double cash = prm.initial_capital, debt = 0.0, shares = 0.0, last_px = 0.0, e_outlay = 0.0, e_price = 0.0;
     int64_t e_day = 0, trades = 0, wins = 0;
@@ -511,7 +511,7 @@ struct LevOp {
     __host__ __device__ void *finish_writes() const { return a.summary; }
     __device__ void finish(double *const *outp, const Dims &d, int64_t s) {
         if (a.trade_count) a.trade_count[s] = (int32_t)trades;
-        if (a.summary) bt_summary_from_row(outp[2] + s * d.stride, d.len, a.prm.initial_capital, trades, wins, a.bench, a.summary + s * PQ_SUMMARY_COLS);
+        if (a.summary) bt_summary_from_row(outp[2] + dims_base(d, s), dims_len(d, s), a.prm.initial_capital, trades, wins, a.bench, a.summary + s * PQ_SUMMARY_COLS);
     }
 };
 

@@ -108,9 +108,9 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     extern __shared__ __align__(16) unsigned char btw_lds[];
     const int lane = (int)threadIdx.x;
     const int64_t s = blockIdx.x;
-    const int T = (int)d.len, C = a.C, P = a.P, PC = P - C;
+    const int T = (int)dims_len(d, s), C = a.C, P = a.P, PC = P - C; // (ragged: C, P, kcap are sized for the longest series)
     const unsigned magic = a.magic;
-    const int64_t base = s * d.stride;
+    const int64_t base = dims_base(d, s);
     double *px = reinterpret_cast<double *>(btw_lds);   // [64 * P]: row i at i + (i / C) * (P - C); later the equity row, then r
     double *bm = px + 64 * P;                           // [64 * P] when a.bench
     unsigned long long *evw = reinterpret_cast<unsigned long long *>(bm + (a.bench ? 64 * P : 0)); // [64] event flags per block

@@ -53,7 +53,7 @@ pq_status pq_t3(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, d
 }
 pq_status pq_trima_chain(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_trima: null pointer");
-    PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
+    PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * batch_rows(b) * 8));
     PQ_WS_COL(tmp, ctx, b, 7); // scratch column 7 is reserved for trima (see pq_ma users)
     int64_t k1, k2;                     // overlap.rs:1313-1326
     if (p % 2 == 1) { k1 = p / 2 + 1; k2 = k1; } else { k1 = p / 2; k2 = k1 + 1; }
@@ -155,7 +155,7 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     case 8: { T3Op t3{}; t3_coeffs(t3, 0.0);
               st = mavp_jobs(ctx, b, r0, periods, minp, maxp, t3, out); break; }
     case 5: { // TRIMA is two chained SMAs: select from a materialised MA column per period
-        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * (size_t)(b->n_series * b->stride) * 8));
+        PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * batch_rows(b) * 8));
         PQ_WS_COL(rz, ctx, b, 5); PQ_WS_COL(ma, ctx, b, 6);
         rec_set_shared_out(ctx, false);
         PQ_TRY(launch_row(ctx, b, ReplaceNullOp{}, IN1(real), OutColsT<ReplaceNullOp, double>{{rz}}));

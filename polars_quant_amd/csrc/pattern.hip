@@ -229,8 +229,9 @@ constexpr int CDL_R = PQ_CDL_R;
 __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, int vec) {
     const int64_t s = blockIdx.y;
     const int64_t t0 = ((int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x) * CDL_R;
-    if (t0 >= d.len) return;
-    const int64_t base = s * d.stride;
+    const int64_t slen = dims_len(d, s);
+    if (t0 >= slen) return;
+    const int64_t base = dims_base(d, s);
     // ~1500 instructions per row: beside the SEQ grids of a suite (whose long jobs raise their own priority) this kernel would
     // otherwise only be issued in the gaps and become the critical path of the step
 #ifndef PQ_CDL_PRIO
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
 #pragma unroll
     for (int k = 0; k < CDL_R + 4; k++) {
         const int64_t q = t0 + CDL_R - 1 - k;
-        w[k] = load_candle(a, base, q < d.len ? q : d.len - 1); // rows past the end (ragged last thread) are never stored
+        w[k] = load_candle(a, base, q < slen ? q : slen - 1); // rows past the end (ragged last thread) are never stored
     }
 #pragma unroll
     for (int id = 0; id < PQ_N_PATTERNS; id++) {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
         if (v[0] == 123456789) a.out[id][base + t0] = v[0];
 #else
         int32_t *dst = &a.out[id][base + t0];
-        if (vec && t0 + CDL_R <= d.len) {
+        if (vec && t0 + CDL_R <= slen) {
             typedef int pq_irv __attribute__((ext_vector_type(CDL_R)));
             pq_irv vv;
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
         } else {
 #pragma unroll
             for (int r = 0; r < CDL_R; r++)
-                if (t0 + r < d.len) __builtin_nontemporal_store(v[r], dst + r);
+                if (t0 + r < slen) __builtin_nontemporal_store(v[r], dst + r);
         }
 #endif
     }
@@ -275,8 +276,8 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
 __global__ __launch_bounds__(ROW_BLOCK) void cdl_one_kernel(CdlArgs a, int id, Dims d) {
     const int64_t s = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
-    if (t >= d.len) return;
-    const int64_t base = s * d.stride;
+    if (t >= dims_len(d, s)) return;
+    const int64_t base = dims_base(d, s);
     Cdl w[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) w[k] = load_candle(a, base, t - k);
@@ -345,13 +346,13 @@ static void cdl_launch_blob(const void *blob, hipStream_t stream) {
     for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
         int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
         CdlArgs a2 = args;
-        int64_t off = s0 * b->stride;
+        int64_t off = b->offsets ? 0 : s0 * b->stride; // (a ragged slice keeps the column pointers: its offsets are absolute rows)
         a2.o += off; a2.h += off; a2.l += off; a2.c += off;
         for (int i = 0; i < PQ_N_PATTERNS; i++) if (a2.out[i]) a2.out[i] += off;
         dim3 grid((unsigned)((b->len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns);
-        Dims d{ns, b->len, b->stride};
+        Dims d{ns, b->len, b->stride, b->offsets ? b->offsets + s0 : nullptr};
         if (id < 0) {
-            int vec = (b->stride % CDL_R) == 0;
+            int vec = (b->stride % CDL_R) == 0 && !b->offsets;
             for (int i = 0; i < PQ_N_PATTERNS; i++)
                 if (a2.out[i] && reinterpret_cast<uintptr_t>(a2.out[i]) % (4 * CDL_R)) vec = 0;
             const int64_t per_block = (int64_t)ROW_BLOCK * CDL_R;

@@ -498,6 +498,12 @@ void _polars_plugin_mavp(pq_series_export *inputs, size_t n_inputs, const uint8_
     run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);
 }
 void _polars_plugin_field_mavp(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+// apo / ppo: registered by the reference's Python (momentum.py:25-30, :136-141: args real, fastperiod, slowperiod, matype) although
+// no Rust function of that name exists; decision D-6 defines them on the reference's own MA family
+PQ_PLUGIN_DEFINE(apo, 1, 3, PQ_P({"fastperiod", false, 12.0}, {"slowperiod", false, 26.0}, {"matype", false, 0.0}), false, false,
+                 pq_apo(ctx, b, in[0], (int64_t)pv[0], (int64_t)pv[1], (int64_t)pv[2], (double *)out), field_f64)
+PQ_PLUGIN_DEFINE(ppo, 1, 3, PQ_P({"fastperiod", false, 12.0}, {"slowperiod", false, 26.0}, {"matype", false, 0.0}), false, false,
+                 pq_ppo(ctx, b, in[0], (int64_t)pv[0], (int64_t)pv[1], (int64_t)pv[2], (double *)out), field_f64)
 PQ_PLUGIN_DEFINE(ht_trendmode, 1, 0, PQ_P({nullptr, false, 0.0}), true, true, pq_ht_trendmode(ctx, b, in[0], (int32_t *)out), field_i32)
 // Struct-valued functions: the struct and field names are the reference's (overlap.rs:30-44 bbands / mama, momentum.rs:63-66 aroon,
 // :239-246 macd -> "macd_res", cycle.rs:149-155 ht_phasor, :229-232 ht_sine)

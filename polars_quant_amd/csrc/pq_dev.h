@@ -77,8 +77,17 @@ __device__ __forceinline__ bool pq_isskip(double x) {
 
 struct Dims {
     int64_t n, len, stride;
+    const int64_t *offs; // ragged batch: series s = rows [offs[s], offs[s + 1]) of the long column (len = the longest); else null
 };
-static inline Dims dims_of(const pq_batch *b) { return Dims{b->n_series, b->len, b->stride}; }
+static inline Dims dims_of(const pq_batch *b) { return Dims{b->n_series, b->len, b->stride, b->offsets}; }
+__device__ __forceinline__ int64_t dims_base(const Dims &d, int64_t s) { return d.offs ? d.offs[s] : s * d.stride; }
+__device__ __forceinline__ int64_t dims_len(const Dims &d, int64_t s) { return d.offs ? d.offs[s + 1] - d.offs[s] : d.len; }
+// rows of one column of the batch (scratch sizing)
+static inline size_t batch_rows(const pq_batch *b) { return b->offsets ? (size_t)b->stride : (size_t)b->n_series * (size_t)b->stride; }
+#define PQ_NO_RAGGED(b, what)                                                                  \
+    do {                                                                                       \
+        if ((b)->offsets) { pq_set_error(what ": ragged batches are not supported"); return PQ_ERR_UNSUPPORTED; } \
+    } while (0)
 
 // Algorithmic column transfers a job is credited with (8 bytes per f64 column and row PER REFERENCE CALL): a plain
 // op is one call (NIN + NOUT); multi-output forms declare / sum the calls they replace.
@@ -194,16 +203,17 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
     constexpr int NTA = NT > 0 ? NT : 1;
     constexpr bool MASKED = IsMasked<Op>::value;
     Row<NIN> r;
-    r.len = d.len;
+    const int64_t sbase = dims_base(d, s);
+    r.len = dims_len(d, s);
 #pragma unroll
-    for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + s * d.stride;
+    for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + sbase;
     double *o[NOUT];
 #pragma unroll
-    for (int k = 0; k < NOUT; k++) o[k] = outp[k] + s * d.stride;
+    for (int k = 0; k < NOUT; k++) o[k] = outp[k] + sbase;
     op.init(r);
     int64_t lag[NTA];
     if constexpr (NT > 0) op.tap_lags(lag);
-    const int64_t T = d.len;
+    const int64_t T = r.len;
     int64_t t0 = 0;
     double xb[NIN][CH], tb[NTA][CH];
     auto load_chunk = [&](int64_t base) {
@@ -741,7 +751,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 // 16-byte accesses need 16-byte aligned rows
 template <int NIN, int NOUT>
 static inline bool seq_cols_aligned(const pq_batch *b, const double *const *in, double *const *out) {
-    if (b->stride % 2) return false;
+    if (b->stride % 2 || b->offsets) return false; // (ragged series start at arbitrary rows: the per-lane body runs them)
     for (int k = 0; k < NIN; k++) if (reinterpret_cast<uintptr_t>(in[k]) % 16) return false;
     for (int k = 0; k < NOUT; k++) if (reinterpret_cast<uintptr_t>(out[k]) % 16) return false;
     return true;
@@ -861,18 +871,19 @@ template <class Op>
 __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> in, OutColsT<Op, typename Op::OutT> out, Dims d) {
     const int64_t s = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
-    if (t >= d.len) return;
+    const int64_t sbase = dims_base(d, s);
     Row<Op::NIN> r;
-    r.len = d.len;
+    r.len = dims_len(d, s);
+    if (t >= r.len) return;
 #pragma unroll
-    for (int k = 0; k < Op::NIN; k++) r.in[k] = in.p[k] + s * d.stride;
+    for (int k = 0; k < Op::NIN; k++) r.in[k] = in.p[k] + sbase;
     typename Op::OutT y[Op::NOUT];
     op.eval(r, t, y);
 #pragma unroll
 #ifdef PQ_EXP_NOSTORE
-    for (int k = 0; k < Op::NOUT; k++) if (y[k] == (typename Op::OutT)123456789) out.p[k][s * d.stride + t] = y[k];
+    for (int k = 0; k < Op::NOUT; k++) if (y[k] == (typename Op::OutT)123456789) out.p[k][sbase + t] = y[k];
 #else
-    for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][s * d.stride + t]); // written once, not re-read
+    for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][sbase + t]); // written once, not re-read
 #endif
 }
 template <class Op, class = void> struct RowId { static constexpr int value = 0; };
@@ -892,10 +903,12 @@ static void row_launch_blob(const void *blob, hipStream_t stream) {
         int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
         InCols<Op::NIN> in2 = rb.in;
         OutColsT<Op, typename Op::OutT> out2 = rb.out;
-        for (int k = 0; k < Op::NIN; k++) in2.p[k] += s0 * b->stride;
-        for (int k = 0; k < Op::NOUT; k++) out2.p[k] += s0 * b->stride;
+        if (!b->offsets) { // (a ragged slice keeps the column pointers: its offsets are absolute rows)
+            for (int k = 0; k < Op::NIN; k++) in2.p[k] += s0 * b->stride;
+            for (int k = 0; k < Op::NOUT; k++) out2.p[k] += s0 * b->stride;
+        }
         dim3 grid((unsigned)((b->len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns);
-        Dims d{ns, b->len, b->stride};
+        Dims d{ns, b->len, b->stride, b->offsets ? b->offsets + s0 : nullptr};
         hipLaunchKernelGGL(row_kernel<Op>, grid, dim3(ROW_BLOCK), 0, stream, rb.op, in2, out2, d);
     }
 }

@@ -17,7 +17,11 @@ void pq_set_error(const char *fmt, ...) {
 pq_status pq_check(pq_ctx *ctx, const pq_batch *b) {
     if (!ctx) { pq_set_error("null context"); return PQ_ERR_ARG; }
     if (!b) { pq_set_error("null batch descriptor"); return PQ_ERR_ARG; }
-    if (b->n_series < 0 || b->len < 0 || b->stride < b->len) {
+    if (b->offsets && (b->n_series < 0 || b->len < 0 || b->stride < 0 || b->len > b->stride)) {
+        pq_set_error("bad ragged batch: n_series=%lld longest=%lld total rows=%lld", (long long)b->n_series, (long long)b->len, (long long)b->stride);
+        return PQ_ERR_ARG;
+    }
+    if (!b->offsets && (b->n_series < 0 || b->len < 0 || b->stride < b->len)) {
         pq_set_error("bad batch: n_series=%lld len=%lld stride=%lld", (long long)b->n_series, (long long)b->len,
                      (long long)b->stride);
         return PQ_ERR_ARG;
@@ -68,7 +72,7 @@ __global__ void validity_to_arrow_kernel(const double *col, int64_t n, uint8_t *
 __global__ void count_nulls_kernel(const double *col, Dims d, unsigned long long *count) {
     const int64_t s = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned nulls = (t < d.len && pq_isnull(col[s * d.stride + t])) ? 1u : 0u;
+    unsigned nulls = (t < dims_len(d, s) && pq_isnull(col[dims_base(d, s) + t])) ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) nulls += __shfl_down(nulls, off, 64);
     if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(count, (unsigned long long)nulls);
 }
@@ -204,9 +208,9 @@ pq_status pq_count_nulls(pq_ctx *ctx, const pq_batch *b, const double *col, int6
     PQ_HIP_TRY(hipMemsetAsync(ctx->d_flag, 0, sizeof(int64_t), ctx->stream));
     for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
         int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
-        Dims d{ns, b->len, b->stride};
+        Dims d{ns, b->len, b->stride, b->offsets ? b->offsets + s0 : nullptr};
         hipLaunchKernelGGL(count_nulls_kernel, dim3((unsigned)((b->len + 255) / 256), (unsigned)ns), dim3(256), 0, ctx->stream,
-                           col + s0 * b->stride, d, (unsigned long long *)ctx->d_flag);
+                           col + (b->offsets ? 0 : s0 * b->stride), d, (unsigned long long *)ctx->d_flag);
         PQ_HIP_TRY(hipGetLastError());
     }
     PQ_HIP_TRY(hipMemcpyAsync(host_count, ctx->d_flag, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -201,7 +201,7 @@ static int phase_for(Recorder &r, const void *const *reads, int nr, void *const 
 }
 
 static pq_status same_batch(Recorder &r, const pq_batch *b) {
-    if (b->n_series != r.b.n_series || b->len != r.b.len || b->stride != r.b.stride) {
+    if (b->n_series != r.b.n_series || b->len != r.b.len || b->stride != r.b.stride || b->offsets != r.b.offsets) {
         pq_set_error("every call recorded into one suite must use the same batch shape");
         return PQ_ERR_ARG;
     }
@@ -273,7 +273,8 @@ struct RowJobDev { int kind; int pad; unsigned char blob[ROW_FUSE_BLOB]; };
 __global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJobDev *jobs, int n_jobs, Dims d, int64_t s_base) {
     const int64_t s = s_base + blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
-    if (t >= d.len) return;
+    const int64_t sbase = dims_base(d, s), slen = dims_len(d, s);
+    if (t >= slen) return;
     for (int j = 0; j < n_jobs; j++) {
         const RowJobDev &job = jobs[j];
         switch (job.kind) {
@@ -283,11 +284,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJobDev *jo
         const RowBlob<OP> &rb = *reinterpret_cast<const RowBlob<OP> *>(job.blob);                                               \
         OP op = rb.op;                                                                                                         \
         Row<OP::NIN> r;                                                                                                        \
-        r.len = d.len;                                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < OP::NIN; k++) r.in[k] = rb.in.p[k] + s * d.stride;                              \
+        r.len = slen;                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < OP::NIN; k++) r.in[k] = rb.in.p[k] + sbase;                                     \
         typename OP::OutT y[OP::NOUT];                                                                                         \
         op.eval(r, t, y);                                                                                                      \
-        _Pragma("unroll") for (int k = 0; k < OP::NOUT; k++) __builtin_nontemporal_store(y[k], &rb.out.p[k][s * d.stride + t]); \
+        _Pragma("unroll") for (int k = 0; k < OP::NOUT; k++) __builtin_nontemporal_store(y[k], &rb.out.p[k][sbase + t]);      \
     } break;
             ROW_OPS(X)
 #undef X
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJobDev *jo
     }
 }
 static bool row_fusable(const RowThunk &t, const Dims &d) {
-    return t.row_id > 0 && t.blob_bytes <= ROW_FUSE_BLOB && t.dims.n == d.n && t.dims.len == d.len && t.dims.stride == d.stride;
+    return t.row_id > 0 && t.blob_bytes <= ROW_FUSE_BLOB && t.dims.n == d.n && t.dims.len == d.len && t.dims.stride == d.stride && t.dims.offs == d.offs;
 }
 
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
@@ -578,7 +579,7 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
 }
 
 double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k) {
-    size_t col = (size_t)(b->n_series * b->stride);
+    size_t col = batch_rows(b);
     if (ctx->rec) { // fresh column per request, owned by the suite
         void *p = nullptr;
         if (hipMalloc(&p, col * sizeof(double)) != hipSuccess) return nullptr;

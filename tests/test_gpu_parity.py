@@ -54,7 +54,10 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint64 if a.dtype == np.float64 else np.uint32)
 
 
-def assert_same(name, got, exp, exact=True):
+from tolerance import SCALE_OF  # which transcendental outputs are judged against a natural scale, and why
+
+
+def assert_same(name, got, exp, exact=True, price=None):
     got = np.asarray(got)
     assert got.shape == exp.shape and got.dtype == exp.dtype, (name, got.shape, exp.shape, got.dtype, exp.dtype)
     if exp.dtype != np.float64:
@@ -68,13 +71,18 @@ def assert_same(name, got, exp, exact=True):
         assert not bad.any(), (f"{name}: {bad.sum()} of {bad.size} not bit-exact; first at {np.argwhere(bad)[:3].tolist()} "
                                f"got {got[bad][:3]} exp {exp[bad][:3]}")
     else:
+        key = name.split("{")[0]
+        scale = SCALE_OF.get(key, 0.0)
+        if isinstance(scale, str):
+            assert price is not None, f"{name}: judged against the price level, which the caller must pass"
+            scale = np.abs(price)
         ok = ~en
         g, e = got[ok], exp[ok]
+        sc = np.broadcast_to(scale, exp.shape)[ok]
         both_nan = np.isnan(g) & np.isnan(e)
-        err = np.abs(g - e) / np.maximum(np.abs(e), 1e-300)
+        err = np.abs(g - e) / np.maximum(np.maximum(np.abs(e), sc), 1e-300)
         err[both_nan] = 0
-        # values that are differences of O(price) quantities are judged against the input scale too
-        assert (err <= RTOL).all() or (np.abs(g - e) <= RTOL * 100.0).all(), f"{name}: max rel err {np.nanmax(err):.3e}"
+        assert (err <= RTOL).all(), f"{name}: max error {np.nanmax(err):.3e} (relative to max(|expected|, scale))"
 
 
 def run_gpu(pq, name, d, **params):
@@ -96,7 +104,7 @@ def test_indicator_defaults(pq, oracle, data, name):
     exp = oracle.call(name, *[data[c] for c in cols])
     got = run_gpu(pq, name, data)
     for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
-        assert_same(f"{name}.{oname}", g, e, exact=name not in TRANSCENDENTAL)
+        assert_same(f"{name}.{oname}", g, e, exact=name not in TRANSCENDENTAL, price=data["close"] if "close" in data else None)
 
 
 PARAM_CASES = [
@@ -144,7 +152,7 @@ def test_indicator_params(pq, oracle, data, name, params):
     exp = oracle.call(name, *[data[c] for c in cols], **params)
     got = run_gpu(pq, name, data, **params)
     for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
-        assert_same(f"{name}.{oname}{params}", g, e, exact=name not in TRANSCENDENTAL)
+        assert_same(f"{name}.{oname}{params}", g, e, exact=name not in TRANSCENDENTAL, price=data["close"])
 
 
 NULL_TOLERANT = [n for n, v in __import__("polars_quant_amd._spec", fromlist=["SPEC"]).SPEC.items()
@@ -169,7 +177,7 @@ def test_null_bearing(pq, oracle, data, name):
     exp = oracle.call(name, *[d[c] for c in cols], **params)
     got = run_gpu(pq, name, d, **params)
     for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
-        assert_same(f"{name}.{oname}", g, e, exact=name not in TRANSCENDENTAL)
+        assert_same(f"{name}.{oname}", g, e, exact=name not in TRANSCENDENTAL, price=data["close"] if "close" in data else None)
 
 
 def test_short_and_empty_series(pq, oracle):
@@ -537,7 +545,7 @@ def _check_suite_replay(pq, oracle, data, stride):
         cols = pq.SPEC[name][0]
         exp = oracle.call(name, *[d[c] for c in cols])
         for (oname, _), got, e in zip(pq.SPEC[name][2], st.out[name], exp):
-            assert_same(f"suite:{name}.{oname}", got.cpu().numpy(), e, exact=name not in TRANSCENDENTAL)
+            assert_same(f"{name}.{oname}{{suite}}", got.cpu().numpy(), e, exact=name not in TRANSCENDENTAL, price=data["close"])
     for nm in pq.PATTERN_NAMES:
         exp = oracle.pattern(nm, data["open"], data["high"], data["low"], data["close"])
         assert (st.pat[nm].cpu().numpy() == exp).all(), nm
@@ -589,7 +597,7 @@ def test_full_size_suite_sampled_parity_and_properties(pq, oracle):
     for name in sorted(pq.SPEC):
         exp = oracle.call(name, *[sub[c] for c in pq.SPEC[name][0]])
         for (oname, _), got, e in zip(pq.SPEC[name][2], st.out[name], exp):
-            assert_same(f"full:{name}.{oname}", got[pick].cpu().numpy(), e, exact=name not in TRANSCENDENTAL)
+            assert_same(f"{name}.{oname}{{full}}", got[pick].cpu().numpy(), e, exact=name not in TRANSCENDENTAL, price=sub["close"])
     for nm in pq.PATTERN_NAMES[::7]:
         assert (st.pat[nm][pick].cpu().numpy() == oracle.pattern(nm, sub["open"], sub["high"], sub["low"], sub["close"])).all(), nm
     ebuy, esell = oracle.macd_cross_signals(sub["close"])
@@ -626,8 +634,9 @@ def test_fused_multi_output_calls(pq, oracle, data):
     check(lib().pq_ht_all(api.ctx(0), C.byref(b), C.c_void_p(g["close"].data_ptr()), *[C.c_void_p(t.data_ptr()) for t in outs]))
     exp = (oracle.call("ht_dcperiod", data["close"]) + oracle.call("ht_dcphase", data["close"]) +
            oracle.call("ht_phasor", data["close"]) + oracle.call("ht_sine", data["close"]))
-    for i, (t, e) in enumerate(zip(outs, exp)):
-        assert_same(f"ht_all[{i}]", t.cpu().numpy(), e, exact=False)
+    names = ("ht_dcperiod.ht_dcperiod", "ht_dcphase.ht_dcphase", "ht_phasor.inphase", "ht_phasor.quadrature", "ht_sine.sine", "ht_sine.leadsine")
+    for nm_, t, e in zip(names, outs, exp):
+        assert_same(nm_ + "{ht_all}", t.cpu().numpy(), e, exact=False, price=data["close"])
     # Fuse2 forms: every column equals the single function's
     g2 = {k: torch.from_numpy(data[k]).cuda() for k in ("open", "high", "low", "close", "volume")}
     P = lambda k: C.c_void_p(g2[k].data_ptr())
@@ -749,7 +758,7 @@ def test_recorded_suite_nulls_and_parameters_on_the_tiled_bodies(pq, oracle):
         for name, prm, src, outs in recorded:
             exp = oracle.call(name, *[src[c] for c in pq.SPEC[name][0]], **prm)
             for (oname, _), g, e in zip(pq.SPEC[name][2], outs, exp):
-                assert_same(f"recorded:{name}.{oname}{prm}", g.cpu().numpy(), e, exact=name not in TRANSCENDENTAL)
+                assert_same(f"{name}.{oname}{{recorded {prm}}}", g.cpu().numpy(), e, exact=name not in TRANSCENDENTAL, price=src["close"])
     finally:
         check(L.pq_suite_destroy(h, suite))
 

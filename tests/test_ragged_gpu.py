@@ -1,0 +1,133 @@
+"""-m gpu: RAGGED batches (pq_batch.offsets, include/pq_hip.h): long columns sorted by symbol + group offsets -- what the reference
+computes with one plugin call per group of whatever length under `.over("symbol")` (python/polars_quant/talib/momentum.py:13-16,
+is_elementwise=False).  Every group must equal the oracle run on that group ALONE: lengths from {0, 1 .. 400},
+including groups shorter than every warm-up (all-null there, as in the reference), bit for bit (transcendental rows at 1e-12)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from tolerance import SCALE_OF  # noqa: E402
+
+SEED = 0x5EED0004
+TRANSCENDENTAL = {"ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine", "mama"}
+NULLB = np.uint64(0x7FF80000504E554C)
+
+
+@pytest.fixture(scope="module")
+def pq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import polars_quant_amd as pq
+    from polars_quant_amd._lib import lib
+    lib()
+    return pq
+
+
+@pytest.fixture(scope="module")
+def groups(oracle):
+    rng = np.random.default_rng(21)
+    lens = np.r_[0, 1, 2, 3, 5, 8, 13, 25, 26, 27, 31, 32, 33, 34, 35, 63, 64, 65, 127, 128, 129, 400, rng.integers(1, 400, size=70), 0, 7]
+    lens = lens.astype(np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    d = oracle.gen_ohlcv(SEED, 1, int(off[-1]), 0)       # one long random walk, cut into the groups
+    d = {k: np.ascontiguousarray(v[0]) for k, v in d.items()}
+    d["real"] = d["close"]
+    d["periods"] = rng.integers(0, 40, size=off[-1]).astype(np.float64)
+    return d, off, lens
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def check(name, g, e, exact, price):
+    assert g.shape == e.shape and g.dtype == e.dtype, (name, g.shape, e.shape)
+    if e.dtype != np.float64:
+        assert (g == e).all(), name
+        return
+    assert ((bits(g) == NULLB) == (bits(e) == NULLB)).all(), f"{name}: null masks differ"
+    if exact:
+        bad = (bits(g) != bits(e)) & ~(np.isnan(g) & np.isnan(e))
+        assert not bad.any(), f"{name}: {bad.sum()} rows not bit-exact, first {np.argwhere(bad)[:3].ravel().tolist()}"
+    else:
+        sc = SCALE_OF.get(name.split("{")[0], 0.0)
+        sc = np.abs(price) if isinstance(sc, str) else sc
+        ok = bits(e) != NULLB
+        err = np.abs(g[ok] - e[ok]) / np.maximum(np.maximum(np.abs(e[ok]), np.broadcast_to(sc, e.shape)[ok]), 1e-300)
+        err[np.isnan(g[ok]) & np.isnan(e[ok])] = 0
+        assert (err <= 1e-12).all(), f"{name}: max error {np.nanmax(err):.3e}"
+
+
+ALL_FUNCS = sorted(__import__("polars_quant_amd._spec", fromlist=["SPEC"]).SPEC)
+
+
+@pytest.mark.parametrize("name", ALL_FUNCS)
+def test_every_function_on_ragged_groups(pq, oracle, groups, name):
+    from polars_quant_amd import api
+    d, off, lens = groups
+    cols = pq.SPEC[name][0]
+    got = api.call(name, *[torch.from_numpy(d[c]).cuda() for c in cols], offsets=off)
+    got = [g.cpu().numpy() for g in got]
+    for s in range(len(lens)):
+        lo, hi = off[s], off[s + 1]
+        if hi == lo:
+            continue
+        exp = oracle.call(name, *[d[c][lo:hi] for c in cols])
+        for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
+            check(f"{name}.{oname}{{group {s} len {hi - lo}}}", g[lo:hi], np.asarray(e).reshape(-1), name not in TRANSCENDENTAL, d["close"][lo:hi])
+
+
+def test_patterns_and_parameters_on_ragged_groups(pq, oracle, groups):
+    from polars_quant_amd import api
+    d, off, lens = groups
+    rich = oracle.gen_ohlcv(SEED + 1, 1, int(off[-1]), 1)
+    o, h, l, c = (np.ascontiguousarray(rich[k][0]) for k in ("open", "high", "low", "close"))
+    T = [torch.from_numpy(x).cuda() for x in (o, h, l, c)]
+    for nm in pq.PATTERN_NAMES[::4]:
+        g = api.cdl(nm, *T, offsets=off).cpu().numpy()
+        for s in range(len(lens)):
+            lo, hi = off[s], off[s + 1]
+            if hi > lo:
+                assert (g[lo:hi] == oracle.pattern(nm, o[lo:hi], h[lo:hi], l[lo:hi], c[lo:hi])).all(), (nm, s)
+    for name, prm in (("ema", dict(timeperiod=5)), ("sma", dict(timeperiod=40)), ("macd", dict(fastperiod=3, slowperiod=7, signalperiod=4)),
+                      ("rsi", dict(timeperiod=2)), ("stoch", dict(fastk_period=7, slowk_period=4, slowk_matype=1, slowd_period=3, slowd_matype=2)),
+                      ("mavp", dict(minperiod=2, maxperiod=12, matype=1)), ("bbands", dict(timeperiod=5, nbdevup=1.5, nbdevdn=2.5))):
+        cols = pq.SPEC[name][0]
+        got = [g.cpu().numpy() for g in api.call(name, *[torch.from_numpy(d[c]).cuda() for c in cols], offsets=off, **prm)]
+        for s in range(len(lens)):
+            lo, hi = off[s], off[s + 1]
+            if hi == lo:
+                continue
+            exp = oracle.call(name, *[d[c][lo:hi] for c in cols], **prm)
+            for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
+                check(f"{name}.{oname}{{{prm} group {s}}}", g[lo:hi], np.asarray(e).reshape(-1), True, d["close"][lo:hi])
+
+
+def test_backtests_on_ragged_groups(pq, oracle):
+    from polars_quant_amd import api
+    rng = np.random.default_rng(5)
+    lens = np.r_[2520, 1, 0, 64, 65, 700, 2000, 4096, 33, rng.integers(1, 3000, size=12)].astype(np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    close = np.ascontiguousarray(oracle.gen_ohlcv(SEED + 2, 1, int(off[-1]), 0)["close"][0])
+    bench = np.ascontiguousarray(oracle.gen_ohlcv(SEED + 3, 1, int(off[-1]), 0)["open"][0])
+    pos, cash, eq, summ = (t.cpu().numpy() for t in api.backtest_macd_cross(torch.from_numpy(close).cuda(), offsets=off))
+    buy = (rng.random(close.shape) < 0.05).astype(np.uint8)
+    sell = (rng.random(close.shape) < 0.05).astype(np.uint8)
+    vpos, vcash, veq, vsumm = (t.cpu().numpy() for t in api.backtest_vectorized(torch.from_numpy(close).cuda(), torch.from_numpy(buy).cuda(),
+                                                                                torch.from_numpy(sell).cuda(), benchmark=torch.from_numpy(bench).cuda(),
+                                                                                offsets=off))
+    assert summ.shape == (len(lens), 8) and vsumm.shape == (len(lens), 8)
+    for s in range(len(lens)):
+        lo, hi = off[s], off[s + 1]
+        if hi == lo:
+            assert (summ[s] == 0).all()
+            continue
+        eb, es_ = oracle.macd_cross_signals(close[lo:hi])
+        for (gp, gc, ge, gs), (ep, ec, ee, es2) in (((pos, cash, eq, summ), oracle.backtest(close[lo:hi], eb, es_)),
+                                                     ((vpos, vcash, veq, vsumm), oracle.backtest(close[lo:hi], buy[lo:hi], sell[lo:hi], benchmark=bench[lo:hi]))):
+            assert (bits(gp[lo:hi]) == bits(ep)).all() and (bits(gc[lo:hi]) == bits(ec)).all() and (bits(ge[lo:hi]) == bits(ee)).all(), s
+            for k in (1, 5, 6, 7):
+                assert bits(gs[s, k:k + 1])[0] == bits(es2[k:k + 1])[0], (s, k)
+            np.testing.assert_allclose(gs[s], es2, rtol=1e-12, atol=1e-13)
