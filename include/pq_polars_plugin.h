@@ -1,8 +1,10 @@
 /*
- * pq_polars_plugin.h -- the Polars expression-plugin symbols of libpolars_quant_hip.so (a spike for two
- * functions): what `polars.plugins.register_plugin_function(plugin_path=<.so>, function_name="ema")` resolves with dlsym
- * (python/polars_quant/talib/overlap.py:36-43) and what `#[polars_expr]` generates in the reference for
- * src/talib/overlap.rs:127-134 (`ema`) and :494-500 (`sma`).
+ * pq_polars_plugin.h -- the Polars expression-plugin symbols of libpolars_quant_hip.so: what
+ * `polars.plugins.register_plugin_function(plugin_path=<.so>, function_name="ema")` resolves with dlsym
+ * (python/polars_quant/talib/overlap.py:36-43) and what `#[polars_expr]` generates in the reference -- one
+ * `_polars_plugin_<f>` / `_polars_plugin_field_<f>` pair for EVERY plugin function the reference's Python registers: the 115 Rust
+ * names + aroonosc, apo, ppo (registered by momentum.py:27,42,138, absent from the Rust library; decision D-6) = 118 pairs, and
+ * for each of them a BATCHED twin `_polars_plugin_<f>_over` (below).
  *
  * ABI: the C structs of pyo3-polars 0.26 / polars-ffi (version 0.1) as far as their published layout is known --
  * UNVERIFIED against the pinned polars 0.53 (Cargo.lock:950-951): no `polars` wheel exists in this image, so the entry
@@ -10,7 +12,14 @@
  *
  * Parameters: both conventions of the reference are accepted: pickled kwargs ({"timeperiod": 20}, the Rust side,
  * overlap.rs:18-22) and a trailing literal input Series of one i64 row (the Python wrapper's `args=[real, timeperiod]`).
- * Each call is ONE series (Polars calls once per expression and once per group under .over("symbol")): n_series = 1.
+ * `_polars_plugin_<f>`: each call is ONE series (Polars calls once per expression and once per group under .over("symbol")):
+ * n_series = 1 -- an H2D copy, a launch and a D2H copy per ~20 KB group.
+ * `_polars_plugin_<f>_over`: the batched form, the only plugin shape worth shipping on a GPU.  inputs = the function's columns (whole
+ * columns of a frame in which equal keys are contiguous, i.e. sorted by symbol), then the KEY column (any integer / float /
+ * utf8 / large_utf8 / string-view / dictionary column; null keys form one group), then the literals.  The group offsets are
+ * derived from the key and every group runs in ONE ragged launch (pq_batch.offsets, pq_hip.h); the result is the concatenation
+ * of the per-group results -- what `.over(key)` assembles from its per-group calls.  Python side:
+ *     register_plugin_function(args=[real, pl.col("symbol"), timeperiod], plugin_path=_LIB, function_name="ema_over", is_elementwise=False)
  */
 #ifndef PQ_POLARS_PLUGIN_H
 #define PQ_POLARS_PLUGIN_H
@@ -46,7 +55,7 @@ typedef struct pq_series_export {
 
 uint32_t _polars_plugin_get_version(void);                       /* (major << 16) | minor = 0.1 */
 const char *_polars_plugin_get_last_error_message(void);        /* thread-local, set when a call leaves return_value empty */
-/* One pair of symbols per reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64 (41 of the 115).
+/* One pair of symbols (+ the _over pair) per reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64.
  *   _polars_plugin_<f>(inputs, n_inputs, kwargs, kwargs_len, return_value, context)
  *       inputs: `n_inputs` exported Series -- the columns in the reference's order (high, low, close, volume ...), optionally
  *       followed by the period as a literal Series (momentum.rs / volatility.rs: `inputs[k].i64()?.get(0)`);
@@ -66,7 +75,11 @@ const char *_polars_plugin_get_last_error_message(void);        /* thread-local,
     void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,            \
                                pq_series_export *return_value, void *context);                                                \
     void _polars_plugin_field_##NAME(struct ArrowSchema *fields, size_t n_fields, struct ArrowSchema *return_value,            \
-                                     const uint8_t *kwargs, size_t kwargs_len);
+                                     const uint8_t *kwargs, size_t kwargs_len);                                               \
+    void _polars_plugin_##NAME##_over(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,     \
+                                      pq_series_export *return_value, void *context);                                         \
+    void _polars_plugin_field_##NAME##_over(struct ArrowSchema *fields, size_t n_fields, struct ArrowSchema *return_value,     \
+                                            const uint8_t *kwargs, size_t kwargs_len);
 PQ_PLUGIN_DECL(sma) PQ_PLUGIN_DECL(ema) PQ_PLUGIN_DECL(wma) PQ_PLUGIN_DECL(dema) PQ_PLUGIN_DECL(tema) PQ_PLUGIN_DECL(trima)
 PQ_PLUGIN_DECL(kama) PQ_PLUGIN_DECL(midpoint) PQ_PLUGIN_DECL(rsi) PQ_PLUGIN_DECL(cmo) PQ_PLUGIN_DECL(mom) PQ_PLUGIN_DECL(roc)
 PQ_PLUGIN_DECL(rocp) PQ_PLUGIN_DECL(rocr) PQ_PLUGIN_DECL(rocr100) PQ_PLUGIN_DECL(trix) PQ_PLUGIN_DECL(ht_dcperiod)
@@ -84,6 +97,8 @@ PQ_PLUGIN_DECL(avgprice)
  * ht_trendmode -> Int32 cycle.rs:377 */
 PQ_PLUGIN_DECL(ma) PQ_PLUGIN_DECL(t3) PQ_PLUGIN_DECL(ultosc) PQ_PLUGIN_DECL(adosc) PQ_PLUGIN_DECL(sar) PQ_PLUGIN_DECL(sarext)
 PQ_PLUGIN_DECL(ht_trendmode)
+/* apo / ppo(real; fastperiod 12, slowperiod 26, matype 0): registered by python/polars_quant/talib/momentum.py:25-30, :136-141 */
+PQ_PLUGIN_DECL(apo) PQ_PLUGIN_DECL(ppo)
 /* mavp(real, periods; minperiod 2, maxperiod 30, matype 0) overlap.rs:407: the period column may be Int64 / Int32 / Float64 */
 PQ_PLUGIN_DECL(mavp)
 

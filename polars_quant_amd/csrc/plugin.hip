@@ -149,12 +149,86 @@ int64_t series_len(const pq_series_export &in) {
     return n;
 }
 
+
+// ---- batched form: `<f>_over(columns..., key, params...)`.  Polars evaluates `<f>(...).over("symbol")` with one plugin call per group
+// (python/polars_quant/talib/momentum.py:13-16, is_elementwise=False): one H2D, one launch and one D2H per ~20 KB group.  The
+// `_over` symbols take the WHOLE columns of a frame in which equal keys are contiguous (sorted by symbol) plus the key column
+// itself, derive the group offsets from it and run every group in one ragged launch (pq_batch.offsets); the result is the
+// concatenation of the per-group results, i.e. exactly what `.over(key)` assembles.  The key may be any integer / float column, a
+// string column (utf8, large_utf8, string view) or a dictionary-encoded one; null keys form their own group.
+struct KeyRef { const uint8_t *p; int64_t len; bool null; };
+static bool key_refs(const pq_series_export &key, int64_t n, std::vector<KeyRef> &out) {
+    if (!key.field || !key.field->format) return false;
+    const char *fm = key.field->format;
+    int width = 0;
+    switch (fm[0]) {
+    case 'c': case 'C': case 'b': width = 1; break;
+    case 's': case 'S': width = 2; break;
+    case 'i': case 'I': case 'f': width = 4; break;
+    case 'l': case 'L': case 'g': width = 8; break;
+    default: break;
+    }
+    const bool small = !strcmp(fm, "u") || !strcmp(fm, "z"), large = !strcmp(fm, "U") || !strcmp(fm, "Z");
+    const bool view = !strcmp(fm, "vu") || !strcmp(fm, "vz");
+    if (fm[0] == 'b' || (fm[1] != 0 && !view)) width = 0; // bit-packed booleans and parametrised types are not keys
+    if (!width && !small && !large && !view) return false;
+    out.clear();
+    out.reserve((size_t)n);
+    for (size_t c = 0; c < key.len; c++) {
+        const ArrowArray *a = key.arrays[c];
+        const uint8_t *vb = a->n_buffers >= 1 ? (const uint8_t *)a->buffers[0] : nullptr;
+        for (int64_t i = 0; i < a->length; i++) {
+            const int64_t r = a->offset + i;
+            KeyRef k{nullptr, 0, false};
+            if (vb && a->null_count != 0 && !((vb[r >> 3] >> (r & 7)) & 1)) k.null = true;
+            else if (width) { if (a->n_buffers < 2 || !a->buffers[1]) return false; k.p = (const uint8_t *)a->buffers[1] + r * width; k.len = width; }
+            else if (small || large) {
+                if (a->n_buffers < 3 || !a->buffers[1]) return false;
+                const int64_t lo = small ? ((const int32_t *)a->buffers[1])[r] : ((const int64_t *)a->buffers[1])[r];
+                const int64_t hi = small ? ((const int32_t *)a->buffers[1])[r + 1] : ((const int64_t *)a->buffers[1])[r + 1];
+                k.p = (const uint8_t *)a->buffers[2] + lo; k.len = hi - lo;
+            } else { // 16-byte views: length, then 12 inline bytes or (prefix, buffer index, offset)
+                if (a->n_buffers < 2 || !a->buffers[1]) return false;
+                const uint8_t *v = (const uint8_t *)a->buffers[1] + r * 16;
+                int32_t len; memcpy(&len, v, 4);
+                k.len = len;
+                if (len <= 12) k.p = v + 4;
+                else {
+                    int32_t bi, bo; memcpy(&bi, v + 8, 4); memcpy(&bo, v + 12, 4);
+                    if (2 + bi >= a->n_buffers || !a->buffers[2 + bi]) return false;
+                    k.p = (const uint8_t *)a->buffers[2 + bi] + bo;
+                }
+            }
+            out.push_back(k);
+        }
+    }
+    return (int64_t)out.size() == n;
+}
+// offsets of the contiguous groups of `key` (host), as a ragged batch on the device; *d_off is pq_free'd by the caller
+static pq_status over_batch(pq_ctx *ctx, const pq_series_export &key, int64_t n, pq_batch *b, void **d_off) {
+    std::vector<KeyRef> k;
+    if (!key_refs(key, n, k)) { pq_set_error("plugin: the key column of an _over call must be an integer, float, string or dictionary column of the frame's length"); return PQ_ERR_ARG; }
+    std::vector<int64_t> off;
+    off.push_back(0);
+    int64_t longest = 0;
+    for (int64_t i = 1; i <= n; i++) {
+        const bool same = i < n && k[(size_t)i].null == k[(size_t)i - 1].null &&
+                          (k[(size_t)i].null || (k[(size_t)i].len == k[(size_t)i - 1].len && !memcmp(k[(size_t)i].p, k[(size_t)i - 1].p, (size_t)k[(size_t)i].len)));
+        if (!same) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
+    }
+    PQ_TRY(pq_malloc(ctx, off.size() * 8, d_off));
+    PQ_TRY(pq_memcpy_h2d(ctx, *d_off, off.data(), off.size() * 8));
+    PQ_TRY(pq_ctx_sync(ctx)); // `off` is a pageable local
+    *b = pq_batch{(int64_t)off.size() - 1, longest, n, (const int64_t *)*d_off};
+    return PQ_OK;
+}
+
 bool read_params(const PParam *params, int nparams, int nin, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
                  size_t kwargs_len, double (&pv)[8]);
-void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret) {
+void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, bool over = false) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
-    if (!inputs || (int)n_inputs < f.nin || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
+    if (!inputs || (int)n_inputs < f.nin + (over ? 1 : 0) || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
     for (int k = 0; k < f.nin; k++) {
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
         const char *fm = inputs[k].field->format;
@@ -162,7 +236,7 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
         if (strcmp(fm, "g") != 0 && !int_ok) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
     }
     double pv[8];
-    if (!read_params(f.params, f.nparams, f.nin, inputs, n_inputs, kwargs, kwargs_len, pv)) return;
+    if (!read_params(f.params, f.nparams, f.nin + (over ? 1 : 0), inputs, n_inputs, kwargs, kwargs_len, pv)) return;
     const int64_t n = series_len(inputs[0]);
     for (int k = 1; k < f.nin; k++)
         if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
@@ -195,7 +269,9 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
                 if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in[k], (const uint8_t *)d_bits, 0, n);
             }
         }
-        const pq_batch b{1, n, n};
+        pq_batch b{1, n, n, nullptr};
+        void *d_off = nullptr;
+        if (st == PQ_OK && over) st = over_batch(ctx, inputs[f.nin], n, &b, &d_off);
         const double *cols[4] = {(const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3]};
         if (st == PQ_OK) st = f.call(ctx, &b, cols, pv, d_out);
         if (f.out_i32) { // Int32 results of this library are never null on non-null input rows beyond the warm-up: PQ_NULL_I32 marks the rest
@@ -209,7 +285,8 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
             if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->validity.data(), d_bits, nb);
             if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count, d_cnt, 8);
         }
-        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_bits, d_cnt}) if (q) (void)pq_free(ctx, q);
+        if (st == PQ_OK) st = pq_ctx_sync(ctx);
+        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_bits, d_cnt, d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail(f.name); return; }
     }
     ArrowArray *arr = new ArrowArray();
@@ -282,16 +359,16 @@ void fill_struct_schema(ArrowSchema *s, const StructFn &f) {
     s->format = "+s"; s->name = sp->name.c_str(); s->flags = 2; s->n_children = f.nout; s->children = sp->kids;
     s->release = release_struct_schema; s->private_data = sp;
 }
-void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret) {
+void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, bool over = false) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
-    if (!inputs || (int)n_inputs < f.nin || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
+    if (!inputs || (int)n_inputs < f.nin + (over ? 1 : 0) || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
     for (int k = 0; k < f.nin; k++) {
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
         if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
     }
     double pv[8];
-    if (!read_params(f.params, f.nparams, f.nin, inputs, n_inputs, kwargs, kwargs_len, pv)) return;
+    if (!read_params(f.params, f.nparams, f.nin + (over ? 1 : 0), inputs, n_inputs, kwargs, kwargs_len, pv)) return;
     const int64_t n = series_len(inputs[0]);
     std::vector<double> host[2];
     std::vector<uint8_t> valid[2];
@@ -326,7 +403,9 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
                 if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in[k], (const uint8_t *)d_bits, 0, n);
             }
         }
-        const pq_batch b{1, n, n};
+        pq_batch b{1, n, n, nullptr};
+        void *d_off = nullptr;
+        if (st == PQ_OK && over) st = over_batch(ctx, inputs[f.nin], n, &b, &d_off);
         const double *cols[2] = {(const double *)d_in[0], (const double *)d_in[1]};
         double *outs[3] = {(double *)d_out[0], (double *)d_out[1], (double *)d_out[2]};
         if (st == PQ_OK) st = f.call(ctx, &b, cols, pv, outs);
@@ -336,7 +415,8 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
             if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op[k]->validity.data(), d_bits, nb);
             if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count[k], d_cnt, 8);
         }
-        for (void *q : {d_in[0], d_in[1], d_out[0], d_out[1], d_out[2], d_bits, d_cnt}) if (q) (void)pq_free(ctx, q);
+        if (st == PQ_OK) st = pq_ctx_sync(ctx);
+        for (void *q : {d_in[0], d_in[1], d_out[0], d_out[1], d_out[2], d_bits, d_cnt, d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { drop(); plugin_fail(f.name); return; }
     }
     StructPriv *sp = new StructPriv();
@@ -364,7 +444,7 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
 
 // the 61 candlestick recognisers: (open, high, low, close[, penetration literal]) -> Int32, never null (pattern.rs:10-2062; inputs go
 // through cont_slice(): a null is an error; penetration = inputs.get(4) as f64, default 0.3, pattern.rs:529-532)
-void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_series_export *ret) {
+void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_series_export *ret, bool over = false) {
     if (ret) memset(ret, 0, sizeof *ret);
     g_plugin_err.clear();
     if (!inputs || n_inputs < 4 || !ret) { plugin_fail("plugin: bad arguments (open, high, low, close expected)"); return; }
@@ -373,9 +453,11 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
         if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
     }
     double pen = 0.3;
-    if (n_inputs >= 5 && inputs[4].len >= 1 && inputs[4].arrays && inputs[4].arrays[0] && inputs[4].arrays[0]->length >= 1 && inputs[4].field &&
-        inputs[4].field->format && !strcmp(inputs[4].field->format, "g") && inputs[4].arrays[0]->n_buffers >= 2 && inputs[4].arrays[0]->buffers[1])
-        pen = ((const double *)inputs[4].arrays[0]->buffers[1])[inputs[4].arrays[0]->offset];
+    const size_t pi = over ? 5 : 4; // the penetration literal follows the key column of an _over call
+    if (over && n_inputs < 5) { plugin_fail("plugin: bad arguments (an _over call takes open, high, low, close, key)"); return; }
+    if (n_inputs > pi && inputs[pi].len >= 1 && inputs[pi].arrays && inputs[pi].arrays[0] && inputs[pi].arrays[0]->length >= 1 && inputs[pi].field &&
+        inputs[pi].field->format && !strcmp(inputs[pi].field->format, "g") && inputs[pi].arrays[0]->n_buffers >= 2 && inputs[pi].arrays[0]->buffers[1])
+        pen = ((const double *)inputs[pi].arrays[0]->buffers[1])[inputs[pi].arrays[0]->offset];
     const int64_t n = series_len(inputs[0]);
     std::vector<double> host[4];
     std::vector<uint8_t> valid;
@@ -396,10 +478,13 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
             st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
             if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
         }
-        const pq_batch b{1, n, n};
+        pq_batch b{1, n, n, nullptr};
+        void *d_off = nullptr;
+        if (st == PQ_OK && over) st = over_batch(ctx, inputs[4], n, &b, &d_off);
         if (st == PQ_OK) st = pq_cdl(ctx, &b, id, (const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3], pen, (int32_t *)d_out);
         if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->ivalues.data(), d_out, (size_t)n * 4);
-        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out}) if (q) (void)pq_free(ctx, q);
+        if (st == PQ_OK) st = pq_ctx_sync(ctx);
+        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail("pq_cdl"); return; }
     }
     ArrowArray *arr = new ArrowArray();
@@ -457,7 +542,13 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_
         static const PlugFn f = {"pq_" #NAME, NIN, HAS_TP, {{"timeperiod", false, (double)DEFAULT}}, NB, false, &plug_call_##NAME}; \
         run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);                                                                \
     }                                                                                                                          \
-    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+    void _polars_plugin_##NAME##_over(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,     \
+                                      pq_series_export *ret, void *) {                                                         \
+        static const PlugFn f = {"pq_" #NAME, NIN, HAS_TP, {{"timeperiod", false, (double)DEFAULT}}, NB, false, &plug_call_##NAME}; \
+        run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret, true);                                                          \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); } \
+    void _polars_plugin_field_##NAME##_over(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
 PQ_PLUGIN_FUNCS(X)
 #undef X
 // functions with other scalar parameters (reference defaults; overlap.rs:146-151 ma, :503-507 t3, :437-443 sar, :457-469 sarext;
@@ -472,7 +563,13 @@ PQ_PLUGIN_FUNCS(X)
         static const PlugFn f = {"pq_" #NAME, NIN, NPARAMS, PARAMS, NB, I32, &plug_call_##NAME};                               \
         run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);                                                                \
     }                                                                                                                          \
-    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { FIELD(fields, n, ret); }
+    void _polars_plugin_##NAME##_over(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,     \
+                                      pq_series_export *ret, void *) {                                                         \
+        static const PlugFn f = {"pq_" #NAME, NIN, NPARAMS, PARAMS, NB, I32, &plug_call_##NAME};                               \
+        run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret, true);                                                          \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { FIELD(fields, n, ret); } \
+    void _polars_plugin_field_##NAME##_over(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { FIELD(fields, n, ret); }
 #define PQ_P(...) {__VA_ARGS__}
 PQ_PLUGIN_DEFINE(ma, 1, 2, PQ_P({"timeperiod", false, 30.0}, {"matype", false, 0.0}), false, false,
                  pq_ma(ctx, b, in[0], (int64_t)pv[0], (int64_t)pv[1], (double *)out), field_f64)
@@ -497,7 +594,12 @@ void _polars_plugin_mavp(pq_series_export *inputs, size_t n_inputs, const uint8_
     static const PlugFn f = {"pq_mavp", 2, 3, {{"minperiod", false, 2.0}, {"maxperiod", false, 30.0}, {"matype", false, 0.0}}, false, false, &plug_call_mavp, 2u};
     run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret);
 }
+void _polars_plugin_mavp_over(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, void *) {
+    static const PlugFn f = {"pq_mavp", 2, 3, {{"minperiod", false, 2.0}, {"maxperiod", false, 30.0}, {"matype", false, 0.0}}, false, false, &plug_call_mavp, 2u};
+    run_cols(f, inputs, n_inputs, kwargs, kwargs_len, ret, true);
+}
 void _polars_plugin_field_mavp(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
+void _polars_plugin_field_mavp_over(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_f64(fields, n, ret); }
 // apo / ppo: registered by the reference's Python (momentum.py:25-30, :136-141: args real, fastperiod, slowperiod, matype) although
 // no Rust function of that name exists; decision D-6 defines them on the reference's own MA family
 PQ_PLUGIN_DEFINE(apo, 1, 3, PQ_P({"fastperiod", false, 12.0}, {"slowperiod", false, 26.0}, {"matype", false, 0.0}), false, false,
@@ -517,7 +619,14 @@ PQ_PLUGIN_DEFINE(ht_trendmode, 1, 0, PQ_P({nullptr, false, 0.0}), true, true, pq
                                pq_series_export *ret, void *) {                                                                \
         run_struct(k_struct_##NAME, inputs, n_inputs, kwargs, kwargs_len, ret);                                                \
     }                                                                                                                          \
+    void _polars_plugin_##NAME##_over(pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len,     \
+                                      pq_series_export *ret, void *) {                                                         \
+        run_struct(k_struct_##NAME, inputs, n_inputs, kwargs, kwargs_len, ret, true);                                          \
+    }                                                                                                                          \
     void _polars_plugin_field_##NAME(ArrowSchema *, size_t, ArrowSchema *ret, const uint8_t *, size_t) {                       \
+        if (ret) fill_struct_schema(ret, k_struct_##NAME);                                                                     \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME##_over(ArrowSchema *, size_t, ArrowSchema *ret, const uint8_t *, size_t) {                \
         if (ret) fill_struct_schema(ret, k_struct_##NAME);                                                                     \
     }
 PQ_PLUGIN_STRUCT(bbands, "bbands", 1, 3, PQ_P({"timeperiod", false, 20.0}, {"nbdevup", true, 2.0}, {"nbdevdn", true, 2.0}), false, 3,
@@ -550,7 +659,11 @@ PQ_PLUGIN_STRUCT(ht_sine, "ht_sine", 1, 0, PQ_P({nullptr, false, 0.0}), true, 2,
     void _polars_plugin_##NAME(pq_series_export *inputs, size_t n_inputs, const uint8_t *, size_t, pq_series_export *ret, void *) { \
         run_pattern(ID, inputs, n_inputs, ret);                                                                                \
     }                                                                                                                          \
-    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_i32(fields, n, ret); }
+    void _polars_plugin_##NAME##_over(pq_series_export *inputs, size_t n_inputs, const uint8_t *, size_t, pq_series_export *ret, void *) { \
+        run_pattern(ID, inputs, n_inputs, ret, true);                                                                          \
+    }                                                                                                                          \
+    void _polars_plugin_field_##NAME(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_i32(fields, n, ret); } \
+    void _polars_plugin_field_##NAME##_over(ArrowSchema *fields, size_t n, ArrowSchema *ret, const uint8_t *, size_t) { field_i32(fields, n, ret); }
 PQ_PLUGIN_PATTERNS(X)
 #undef X
 }

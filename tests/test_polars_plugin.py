@@ -45,6 +45,8 @@ MULTI_FUNCS = {"ma": (["real"], [("timeperiod", 30, 12), ("matype", 0, 1)]),
                                             ("accelerationinitshort", 0.0, 0.03), ("accelerationshort", 0.0, 0.03),
                                             ("accelerationmaxshort", 0.0, 0.3)]),
                "ht_trendmode": (["real"], []),
+               "apo": (["real"], [("fastperiod", 12, 5), ("slowperiod", 26, 13), ("matype", 0, 1)]),
+               "ppo": (["real"], [("fastperiod", 12, 5), ("slowperiod", 26, 13), ("matype", 0, 1)]),
                "mavp": (["real", "periods"], [("minperiod", 2, 3), ("maxperiod", 30, 20), ("matype", 0, 1)])}
 # ... and the Struct-valued ones: name -> (struct name, input columns, [(parameter, reference default, a test value)], field names)
 STRUCT_FUNCS = {"bbands": ("bbands", ["real"], [("timeperiod", 20, 10), ("nbdevup", 2.0, 1.5), ("nbdevdn", 2.0, 2.5)], ["bb_upper", "bb_middle", "bb_lower"]),
@@ -70,10 +72,11 @@ def _lib():
     L._polars_plugin_get_last_error_message.restype = C.c_char_p
     L.pq_plugin_kwargs_i64.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int64)]
     from polars_quant_amd._spec import PATTERN_NAMES
-    for f in ("_polars_plugin_" + n for n in list(TP_FUNCS) + list(PATTERN_NAMES)):
+    both = [n + sfx for n in list(TP_FUNCS) + list(PATTERN_NAMES) for sfx in ("", "_over")]
+    for f in ("_polars_plugin_" + n for n in both):
         getattr(L, f).argtypes = [C.POINTER(SeriesExport), C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(SeriesExport), C.c_void_p]
         getattr(L, f).restype = None
-    for f in ("_polars_plugin_field_" + n for n in list(TP_FUNCS) + list(PATTERN_NAMES)):
+    for f in ("_polars_plugin_field_" + n for n in both):
         getattr(L, f).argtypes = [C.POINTER(ArrowSchema), C.c_size_t, C.POINTER(ArrowSchema), C.c_char_p, C.c_size_t]
         getattr(L, f).restype = None
     return L
@@ -85,10 +88,12 @@ def test_plugin_symbols_and_version():
     declared = set(re.findall(r"\b(_polars_plugin_[a-z0-9_]+|pq_plugin_[a-z0-9_]+)\s*\(", txt))
     for n in re.findall(r"\bPQ_PLUGIN_DECL\((\w+)\)", txt):      # the per-function pairs are declared through a macro
         if n != "NAME":                                           # (the macro's own parameter)
-            declared |= {"_polars_plugin_" + n, "_polars_plugin_field_" + n}
+            declared |= {"_polars_plugin_" + n, "_polars_plugin_field_" + n, "_polars_plugin_" + n + "_over", "_polars_plugin_field_" + n + "_over"}
     declared = {n for n in declared if "##" not in n and not n.endswith("_")}
     from polars_quant_amd._spec import PATTERN_NAMES
-    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n for n in list(TP_FUNCS) + list(PATTERN_NAMES)}
+    assert {n for n in declared if n.startswith("_polars_plugin_field_")} == {"_polars_plugin_field_" + n + sfx for n in list(TP_FUNCS) + list(PATTERN_NAMES)
+                                                                                for sfx in ("", "_over")}
+    assert len(TP_FUNCS) + len(PATTERN_NAMES) == 118, "115 Rust names + aroonosc + apo + ppo"
     declared = sorted(declared)
     assert {"_polars_plugin_get_version", "_polars_plugin_get_last_error_message", "_polars_plugin_ema", "_polars_plugin_field_ema"} <= set(declared)
     L = _lib()
@@ -394,3 +399,106 @@ def test_struct_valued_functions_through_their_plugin_symbols(oracle, name):
     assert out_field.format == b"+s" and out_field.name == sname.encode() and out_field.n_children == len(fields)
     kids = C.cast(out_field.children, C.POINTER(C.POINTER(ArrowSchema)))
     assert [kids[i].contents.name.decode() for i in range(len(fields))] == fields and all(kids[i].contents.format == b"g" for i in range(len(fields)))
+
+
+def _groups(oracle, seed=0x5EED0010):
+    lens = np.array([37, 1, 120, 64, 5, 300, 33, 2], dtype=np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    d = oracle.gen_ohlcv(seed, 1, int(off[-1]), 0)
+    d = {k: np.ascontiguousarray(v[0]) for k, v in d.items()}
+    d["real"] = d["close"]
+    sym = np.repeat(np.arange(len(lens)), lens)
+    return d, off, lens, sym
+
+
+def _key_arrays(sym):
+    """the same grouping as different Arrow layouts of the key column"""
+    names = np.array([f"SYM{i:04d}{'x' * (i * 3)}" for i in range(int(sym.max()) + 1)])   # some longer than 12 bytes: out-of-line views
+    out = {"int64": pa.array(sym.astype(np.int64)), "int32": pa.array(sym.astype(np.int32)), "uint8": pa.array(sym.astype(np.uint8)),
+           "float64": pa.array(sym.astype(np.float64)), "utf8": pa.array(names[sym], type=pa.string()),
+           "large_utf8": pa.array(names[sym], type=pa.large_string())}
+    if hasattr(pa, "string_view"):
+        out["string_view"] = pa.array(names[sym], type=pa.string_view())
+    out["dictionary"] = pa.array(names[sym]).dictionary_encode()
+    return out
+
+
+@pytest.mark.gpu
+def test_batched_over_symbols_equal_one_call_per_group(oracle):
+    """`_polars_plugin_<f>_over(columns..., key, literals...)`: the whole sorted frame in one call == the reference's one call per
+    group under .over("symbol") (momentum.py:13-16), for every key layout, a chunked key / data, null keys, kwargs and literals."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    d, off, lens, sym = _groups(oracle)
+    n = int(off[-1])
+
+    def per_group(name, cols, **prm):
+        outs = None
+        for s in range(len(lens)):
+            lo, hi = off[s], off[s + 1]
+            res = oracle.call(name, *[d[c][lo:hi] for c in cols], **prm)
+            outs = [[] for _ in res] if outs is None else outs
+            for k, r in enumerate(res):
+                outs[k].append(np.asarray(r).reshape(-1))
+        return [np.concatenate(o) for o in outs]
+
+    def run(fn, cols, key, literals=(), kwargs=None, split=None):
+        ses, keep = [], []
+        for c in cols:
+            arr = pa.array(d[c])
+            se, k = _export([arr] if split is None else [arr.slice(0, split), arr.slice(split)], c); ses.append(se); keep.append(k)
+        se, k = _export([key] if split is None else [key.slice(0, split), key.slice(split)], "symbol"); ses.append(se); keep.append(k)
+        for v in literals:
+            se, k = _export([pa.array([v], type=pa.float64() if isinstance(v, float) else pa.int64())], "literal"); ses.append(se); keep.append(k)
+        ins = (SeriesExport * len(ses))(*ses)
+        kw = pickle.dumps(kwargs) if kwargs else None
+        ret = SeriesExport(); fn(ins, len(ses), kw, len(kw) if kw else 0, C.byref(ret), None)
+        assert ret.release, L._polars_plugin_get_last_error_message()
+        return _import(ret)
+
+    def same(got, exp, name):
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert len(got) == n and (np.asarray(got.is_null()) == en).all(), name
+        assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all(), name
+
+    keys = _key_arrays(sym)
+    (exp,) = per_group("ema", ["real"], timeperiod=9)
+    for kind, key in keys.items():
+        same(run(L._polars_plugin_ema_over, ["real"], key, literals=[9]), exp, f"ema_over[{kind}]")
+    same(run(L._polars_plugin_ema_over, ["real"], keys["utf8"], kwargs={"timeperiod": 9}, split=101), exp, "ema_over chunked + kwargs")
+    (exp,) = per_group("ema", ["real"])
+    same(run(L._polars_plugin_ema_over, ["real"], keys["int64"]), exp, "ema_over default period (groups shorter than 30 rows are all-null)")
+    # a null key is a group of its own
+    m = sym == 3
+    same(run(L._polars_plugin_ema_over, ["real"], pa.array(sym.astype(np.int64), mask=m), literals=[9]), per_group("ema", ["real"], timeperiod=9)[0], "null key")
+    # several columns, several parameters, Int32 output, a Struct, a pattern
+    (exp,) = per_group("ultosc", ["high", "low", "close"], timeperiod1=3, timeperiod2=5, timeperiod3=8)
+    same(run(L._polars_plugin_ultosc_over, ["high", "low", "close"], keys["int64"], literals=[3, 5, 8]), exp, "ultosc_over")
+    (exp,) = per_group("apo", ["real"], fastperiod=3, slowperiod=7, matype=1)
+    same(run(L._polars_plugin_apo_over, ["real"], keys["int64"], literals=[3, 7, 1]), exp, "apo_over")
+    st = run(L._polars_plugin_macd_over, ["real"], keys["dictionary"], literals=[3, 7, 4])
+    for fld, exp in zip(("macd", "macd_signal", "macd_hist"), per_group("macd", ["real"], fastperiod=3, slowperiod=7, signalperiod=4)):
+        same(st.field(fld), exp, "macd_over." + fld)
+    tm = run(L._polars_plugin_ht_trendmode_over, ["real"], keys["int64"])
+    (exp,) = per_group("ht_trendmode", ["real"])
+    en = exp == np.int32(-2147483648)
+    assert (np.asarray(tm.is_null()) == en).all() and (tm.to_numpy(zero_copy_only=False)[~en].astype(np.int32) == exp[~en]).all()
+    rich = oracle.gen_ohlcv(0x5EED0011, 1, n, 1)
+    for c in ("open", "high", "low", "close"):
+        d[c] = np.ascontiguousarray(rich[c][0])
+    got = run(L._polars_plugin_cdlengulfing_over, ["open", "high", "low", "close"], keys["int64"]).to_numpy(zero_copy_only=False)
+    exp = np.concatenate([oracle.pattern("cdlengulfing", *[d[c][off[s]:off[s + 1]] for c in ("open", "high", "low", "close")]).reshape(-1)
+                          for s in range(len(lens))])
+    assert (got == exp).all() and (exp != 0).any()
+    # errors: no key column, a key of the wrong length
+    ses, keep = [], []
+    se, k = _export([pa.array(d["real"])], "real"); ses.append(se); keep.append(k)
+    ins = (SeriesExport * 1)(*ses)
+    ret = SeriesExport(); L._polars_plugin_ema_over(ins, 1, None, 0, C.byref(ret), None)
+    assert not ret.release and b"too few" in L._polars_plugin_get_last_error_message()
+    se2, k2 = _export([pa.array(sym[:-3].astype(np.int64))], "symbol")
+    ins = (SeriesExport * 2)(ses[0], se2)
+    ret = SeriesExport(); L._polars_plugin_ema_over(ins, 2, None, 0, C.byref(ret), None)
+    assert not ret.release
