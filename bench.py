@@ -68,24 +68,28 @@ def cpu_baseline(sample_syms: int, T: int):
 def end_to_end(suite, ohlcv, n_local, T, dev):
     """The step from HOST buffers, through the C ABI's own copy entry points: the five OHLCV columns live in page-locked
     (pq_host_register) DENSE host arrays as an Arrow buffer handed over by the caller would; H2D into the pitched device
-    columns (pq_memcpy_h2d_pitched) -> step -> D2H of the [n, 8] summary table.  Second figure: D2H of every output column as
-    well (10.9 GB at full size)."""
+    columns (pq_memcpy_h2d_pitched) -> step -> D2H of the [n, 8] summary table.
+      serial      copies, then the step (round 2's form)
+      overlapped  loader.DeviceFrame.upload on a copy stream, one event per column, and the step split into stages by the columns
+                  a task needs (Suite.record_staged): the consumers of `close` run while `high` is still on the bus
+    Third figure: D2H of every output column as well (10.9 GB at full size)."""
     import ctypes as C
     from polars_quant_amd._lib import check, lib
     from polars_quant_amd.api import ctx
+    from polars_quant_amd.loader import DeviceFrame, HostFrame
     L, h = lib(), ctx(dev.index)
-    host = {k: np.ascontiguousarray(v.cpu().numpy()) for k, v in ohlcv.items()}
-    for a in host.values():
-        check(L.pq_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes))
+    host = HostFrame([str(i) for i in range(n_local)], np.arange(T), {k: np.ascontiguousarray(v.cpu().numpy()) for k, v in ohlcv.items()})
+    frame = DeviceFrame(columns=dict(ohlcv), stride=suite.stride)
+    frame.register(host)
     summ = np.empty((n_local, 8))
     check(L.pq_host_register(summ.ctypes.data_as(C.c_void_p), summ.nbytes))
     outs = [t for ts in suite.out.values() for t in ts] + list(suite.pat.values()) + suite.bt
     big = np.empty(max(t.numel() * t.element_size() for t in outs), dtype=np.uint8)
     check(L.pq_host_register(big.ctypes.data_as(C.c_void_p), big.nbytes))
+    order = list(suite.STAGE_ORDER)
 
-    def once(all_outputs):
-        for k, a in host.items():
-            check(L.pq_memcpy_h2d_pitched(h, C.c_void_p(ohlcv[k].data_ptr()), suite.stride * 8, a.ctypes.data_as(C.c_void_p), T * 8, T * 8, n_local))
+    def serial(all_outputs):
+        frame.upload(host, order=order, copy_stream=torch.cuda.current_stream(dev))
         suite.run(ohlcv)
         check(L.pq_memcpy_d2h(h, summ.ctypes.data_as(C.c_void_p), C.c_void_p(suite.summary.data_ptr()), summ.nbytes))
         if all_outputs:
@@ -94,17 +98,33 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
                 check(L.pq_memcpy_d2h_pitched(h, big.ctypes.data_as(C.c_void_p), T * es, C.c_void_p(t.data_ptr()), suite.stride * es, T * es, n_local))
         torch.cuda.synchronize()
 
+    def overlapped():
+        frame.upload(host, order=order)
+        suite.run_staged(frame.events)
+        check(L.pq_memcpy_d2h(h, summ.ctypes.data_as(C.c_void_p), C.c_void_p(suite.summary.data_ptr()), summ.nbytes))
+        torch.cuda.synchronize()
+
     res = {}
-    for label, allo, reps in (("summary_only", False, 5), ("all_outputs", True, 2)):
-        once(allo)
+    for label, fn, reps in (("summary_only", lambda: serial(False), 5), ("all_outputs", lambda: serial(True), 2)):
+        fn()
         t0 = time.perf_counter()
         for _ in range(reps):
-            once(allo)
+            fn()
         dt = (time.perf_counter() - t0) / reps
         res[label] = {"ms": dt * 1e3, "rows_per_s": n_local * T / dt}
-    res["h2d_bytes"] = sum(a.nbytes for a in host.values())
+    ref_summary = suite.summary.clone()
+    res["stages"] = suite.record_staged(ohlcv)        # (replaces the single recorded suite of this object)
+    overlapped()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        overlapped()
+    dt = (time.perf_counter() - t0) / 5
+    res["summary_only_overlapped"] = {"ms": dt * 1e3, "rows_per_s": n_local * T / dt,
+                                      "same_summary_bits": bool(torch.equal(ref_summary.view(torch.int64), suite.summary.view(torch.int64)))}
+    res["h2d_bytes"] = sum(a.nbytes for a in host.columns.values())
     res["d2h_bytes_all_outputs"] = sum(t.numel() * t.element_size() for t in outs)
-    for a in list(host.values()) + [summ, big]:
+    frame.unregister()
+    for a in (summ, big):
         check(L.pq_host_unregister(a.ctypes.data_as(C.c_void_p)))
     return res
 

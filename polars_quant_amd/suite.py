@@ -165,6 +165,61 @@ class Suite:
             check(L.pq_suite_end(h, C.byref(out)))
         self._suite = out
 
+    # ---- staged form: the step split by the input columns a task needs, so that a stage starts as soon as ITS columns have
+    # arrived from the host (loader.DeviceFrame.upload records one event per column on the copy stream)
+    STAGE_ORDER = ("close", "high", "low", "open", "volume")   # copy order = the order in which the stages become runnable
+
+    def task_inputs(self, name: str) -> set:
+        if name == "cdl_all":
+            return {"open", "high", "low", "close"}
+        if name == "backtest_macd_cross":
+            return {"close"}
+        members = self.FUSED.get(name) or {"dmi_all": ("dx", "plus_di", "minus_di", "adx", "adxr"), "atr_all": ("atr", "natr"),
+                                            "ad_all": ("ad", "adosc"), "macd_pair": ("macd", "macdfix"), "stoch_all": ("stoch", "stochf")}.get(name) or (name,)
+        cols = set()
+        for m in members:
+            cols |= {COLMAP.get(c, c) for c in SPEC[m][0] if c != "periods"}
+        return cols
+
+    def record_staged(self, ohlcv: dict) -> list:
+        """one recorded suite per prefix of STAGE_ORDER that completes some task's inputs -> [(columns needed, n tasks)]"""
+        self.close()
+        L, h = lib(), ctx(self.dev.index)
+        self._ohlcv = ohlcv
+        stages, have, left = [], set(), list(self.tasks(fused=True))
+        for col in self.STAGE_ORDER:
+            have.add(col)
+            ready = [t for t in left if self.task_inputs(t) <= have]
+            left = [t for t in left if t not in ready]
+            if ready:
+                stages.append((col, ready))
+        assert not left, left
+        self._stages = []
+        with torch.cuda.device(self.dev):
+            for col, names in stages:
+                check(L.pq_suite_begin(h, C.byref(self.batch)))
+                try:
+                    for name in names:
+                        self.run_one(name, ohlcv)
+                except Exception:
+                    L.pq_suite_abort(h)
+                    raise
+                out = C.c_void_p()
+                check(L.pq_suite_end(h, C.byref(out)))
+                self._stages.append((col, out, len(names)))
+        return [(col, n) for col, _, n in self._stages]
+
+    def run_staged(self, events: dict | None = None) -> None:
+        """the staged step on the current stream; events[column] (from DeviceFrame.upload): wait for that column's copy first"""
+        cur = torch.cuda.current_stream(self.dev)
+        with torch.cuda.device(self.dev):
+            for col, handle, _n in self._stages:
+                if events is not None:
+                    for c in self.STAGE_ORDER[: self.STAGE_ORDER.index(col) + 1]:
+                        if c in events:
+                            cur.wait_event(events[c])
+                check(lib().pq_suite_run(ctx(self.dev.index), handle))
+
     def info(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         check(lib().pq_suite_info(self._suite, C.byref(a), C.byref(b), C.byref(c)))
@@ -207,6 +262,9 @@ class Suite:
         if getattr(self, "_suite", None) is not None:
             check(lib().pq_suite_destroy(ctx(self.dev.index), self._suite))
             self._suite = None
+        for _col, handle, _n in getattr(self, "_stages", []):
+            check(lib().pq_suite_destroy(ctx(self.dev.index), handle))
+        self._stages = []
 
     def __del__(self):
         try:
