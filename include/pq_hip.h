@@ -317,6 +317,29 @@ pq_status pq_band_signals(pq_ctx *, const pq_batch *, const double *x, double lo
 pq_status pq_channel_signals(pq_ctx *, const pq_batch *, const double *price, const double *lo, const double *hi, int32_t mode,
                              uint8_t *buy, uint8_t *sell);
 
+/* The remaining comparisons of the README's fourteen `Strategy` generators (README.md:942-956; definitions = decision D-11b),
+ * row-parallel and recordable into a suite in front of pq_backtest_vectorized.  A NULL compares false everywhere.
+ *   pq_gate_signals   (buy_in, sell_in) -> (buy, sell), in place allowed; mode 0 zones: buy &= a < k0, sell &= a > k1 (stoch);
+ *                     1 strength: both &= a > k0 (adx); 2: buy &= a > c (ma trend filter); 3: buy &= a[i] > a[i-1] (slope filter);
+ *                     4: buy &= (a - c) > |c| * k0 (distance filter)
+ *   pq_zscore         z = (price - mid) / (upper - mid), NULL where upper is (reversion: then pq_band_signals on z)
+ *   pq_scale_band     lo = base * f_lo, hi = base * f_hi, NULL where base is (grid: then pq_channel_signals mode 0)
+ *   pq_volume_surge_signals  surge = volume > multiplier * avg_volume; buy = surge on an up close, sell = surge on a down close
+ *   pq_gap_signals    buy = open[i] > high[i-1] * f_up, sell = open[i] < low[i-1] * f_dn
+ *   pq_pattern_any_signals   buy = any of <= 16 recogniser columns == +100, sell = any of <= 16 == -100 (host arrays of device pointers)
+ *   pq_ma_stack_signals      buy = first bar where mas[0] > mas[1] > ... holds, sell = first bar of the reverse order (2..16 columns) */
+pq_status pq_gate_signals(pq_ctx *, const pq_batch *, const double *a, const double *c, int32_t mode, double k0, double k1,
+                          const uint8_t *buy_in, const uint8_t *sell_in, uint8_t *buy, uint8_t *sell);
+pq_status pq_zscore(pq_ctx *, const pq_batch *, const double *price, const double *upper, const double *mid, double *z);
+pq_status pq_scale_band(pq_ctx *, const pq_batch *, const double *base, double f_lo, double f_hi, double *lo, double *hi);
+pq_status pq_volume_surge_signals(pq_ctx *, const pq_batch *, const double *volume, const double *avg_volume, const double *close,
+                                  double multiplier, uint8_t *buy, uint8_t *sell);
+pq_status pq_gap_signals(pq_ctx *, const pq_batch *, const double *open, const double *high, const double *low, double f_up, double f_dn,
+                         uint8_t *buy, uint8_t *sell);
+pq_status pq_pattern_any_signals(pq_ctx *, const pq_batch *, const int32_t *const *bullish, int32_t n_bullish,
+                                 const int32_t *const *bearish, int32_t n_bearish, uint8_t *buy, uint8_t *sell);
+pq_status pq_ma_stack_signals(pq_ctx *, const pq_batch *, const double *const *mas, int32_t n, uint8_t *buy, uint8_t *sell);
+
 /* ---- the README's multi-symbol `Backtest` (README.md:346-640; README-only, no source).
  * Semantics = decision D-10 (oracle/backtest.c): independent capital pool per symbol, 100-share lots, leverage
  * with daily compounding interest on the debt, margin call (forced sale), commission with a minimum, proportional

@@ -109,6 +109,20 @@ def lib() -> C.CDLL:
         L.pq_band_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_double, C.c_double, vp, vp]
         L.pq_channel_signals.restype = C.c_int32
         L.pq_channel_signals.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, C.c_int32, vp, vp]
+        L.pq_gate_signals.restype = C.c_int32
+        L.pq_gate_signals.argtypes = [vp, C.POINTER(Batch), vp, vp, C.c_int32, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.pq_zscore.restype = C.c_int32
+        L.pq_zscore.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp]
+        L.pq_scale_band.restype = C.c_int32
+        L.pq_scale_band.argtypes = [vp, C.POINTER(Batch), vp, C.c_double, C.c_double, vp, vp]
+        L.pq_volume_surge_signals.restype = C.c_int32
+        L.pq_volume_surge_signals.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, C.c_double, vp, vp]
+        L.pq_gap_signals.restype = C.c_int32
+        L.pq_gap_signals.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, C.c_double, C.c_double, vp, vp]
+        L.pq_pattern_any_signals.restype = C.c_int32
+        L.pq_pattern_any_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_int32, vp, C.c_int32, vp, vp]
+        L.pq_ma_stack_signals.restype = C.c_int32
+        L.pq_ma_stack_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_int32, vp, vp]
         L.pq_factor_ic.restype = C.c_int32
         L.pq_factor_ic.argtypes = [vp, C.POINTER(Batch), vp, vp, C.c_int32, vp, vp]
         L.pq_rolling_ic.restype = C.c_int32

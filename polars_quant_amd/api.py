@@ -410,6 +410,70 @@ def channel_signals(price, lo, hi, mode: int):
     return _signal_call("pq_channel_signals", [price, lo, hi], int(mode))
 
 
+def _dev2(x, dtype=torch.float64):
+    return _to_device(x, dtype)[0].contiguous()
+
+
+def _rule(fn_name, shape_like, args, outs):
+    """one of the strategy rule kernels (csrc/strategy.hip): args = ctypes values, outs = output tensors (returned)"""
+    n, T = shape_like.shape
+    b = Batch(n, T, T)
+    if n * T:
+        with torch.cuda.device(shape_like.device):
+            check(getattr(lib(), fn_name)(ctx(shape_like.device.index), C.byref(b), *args, *[C.c_void_p(o.data_ptr()) for o in outs]))
+    return outs
+
+
+def gate_signals(buy, sell, a, mode: int, k0: float = 0.0, k1: float = 0.0, c=None):
+    """pq_gate_signals: filter existing signals by a comparison on column `a` (see include/pq_hip.h for the modes)"""
+    a_, bu, se = _dev2(a), _dev2(buy, torch.uint8), _dev2(sell, torch.uint8)
+    c_ = _dev2(c) if c is not None else None
+    outs = [torch.empty_like(bu), torch.empty_like(se)]
+    return tuple(_rule("pq_gate_signals", a_, [C.c_void_p(a_.data_ptr()), C.c_void_p(c_.data_ptr()) if c_ is not None else None, int(mode),
+                                               C.c_double(float(k0)), C.c_double(float(k1)), C.c_void_p(bu.data_ptr()), C.c_void_p(se.data_ptr())], outs))
+
+
+def zscore(price, upper, mid):
+    p, u, m = _dev2(price), _dev2(upper), _dev2(mid)
+    return _rule("pq_zscore", p, [C.c_void_p(t.data_ptr()) for t in (p, u, m)], [torch.empty_like(p)])[0]
+
+
+def scale_band(base, f_lo: float, f_hi: float):
+    b_ = _dev2(base)
+    return tuple(_rule("pq_scale_band", b_, [C.c_void_p(b_.data_ptr()), C.c_double(float(f_lo)), C.c_double(float(f_hi))],
+                       [torch.empty_like(b_), torch.empty_like(b_)]))
+
+
+def _u8_pair(like):
+    return [torch.zeros(like.shape, dtype=torch.uint8, device=like.device), torch.zeros(like.shape, dtype=torch.uint8, device=like.device)]
+
+
+def volume_surge_signals(volume, avg_volume, close, multiplier: float):
+    v, sv, c = _dev2(volume), _dev2(avg_volume), _dev2(close)
+    return tuple(_rule("pq_volume_surge_signals", v, [C.c_void_p(t.data_ptr()) for t in (v, sv, c)] + [C.c_double(float(multiplier))], _u8_pair(v)))
+
+
+def gap_signals(open, high, low, f_up: float, f_dn: float):
+    o, h, l = _dev2(open), _dev2(high), _dev2(low)
+    return tuple(_rule("pq_gap_signals", o, [C.c_void_p(t.data_ptr()) for t in (o, h, l)] + [C.c_double(float(f_up)), C.c_double(float(f_dn))], _u8_pair(o)))
+
+
+def pattern_any_signals(bullish, bearish):
+    """bullish / bearish: lists of int32 recogniser columns (device) -> (buy, sell)"""
+    bu = [_dev2(t, torch.int32) for t in bullish]
+    be = [_dev2(t, torch.int32) for t in bearish]
+    like = (bu + be)[0]
+    pb = (C.c_void_p * max(len(bu), 1))(*[t.data_ptr() for t in bu])
+    ps = (C.c_void_p * max(len(be), 1))(*[t.data_ptr() for t in be])
+    return tuple(_rule("pq_pattern_any_signals", like, [pb, len(bu), ps, len(be)], _u8_pair(like)))
+
+
+def ma_stack_signals(mas):
+    ms = [_dev2(t) for t in mas]
+    ptrs = (C.c_void_p * len(ms))(*[t.data_ptr() for t in ms])
+    return tuple(_rule("pq_ma_stack_signals", ms[0], [ptrs, len(ms)], _u8_pair(ms[0])))
+
+
 def backtest_leveraged(price, buy, sell, benchmark=None, max_trades: int = 64, **kw):
     """README `Backtest` engine (decision D-10): price/buy/sell [N, T], benchmark [T] or None.
     -> dict of device tensors: cash, stock_value, total_value [N,T]; trade_count [N]; trades {field: [N,max_trades]};

@@ -797,7 +797,7 @@ struct RowThunk { // type-erased ROW launch for replay
     int blob_bytes; // sizeof(RowBlob<Op>)
     Dims dims;      // of the batch the call was made on
     unsigned char blob[1200];
-    const void *reads[8];
+    const void *reads[40];
     int n_reads;
     void *writes[64];
     int n_writes;

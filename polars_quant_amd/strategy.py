@@ -5,13 +5,14 @@ Every method takes a dict / DataFrame of [N, T] (or [T]) columns named open/high
 {"buy_signal": uint8 [N, T], "sell_signal": uint8 [N, T]} (device tensors), ready for `VectorizedBacktester`,
 `api.backtest_vectorized` or `Backtest`.  All fourteen README names are here: ma, macd, rsi, bband, stoch, cci, adx, breakout,
 reversion, volume, grid, gap, pattern, trend.  The README documents parameters only for ma / macd / rsi (its `.pyi` has no
-`Strategy` class), so for the others the definitions in the docstrings below are this build's (decision D-11b); every
-indicator value comes from the HIP kernels, the comparisons that turn them into signals are the D-11 rule kernels or plain
-element-wise tensor operations on the device.
+`Strategy` class), so for the others the definitions in the docstrings below are this build's (decision D-11b).  Every
+indicator value comes from the HIP indicator kernels and every comparison that turns them into signals from the rule kernels of the
+C ABI (pq_cross / band / channel_signals, pq_gate_signals, pq_zscore, pq_scale_band, pq_volume_surge_signals, pq_gap_signals,
+pq_pattern_any_signals, pq_ma_stack_signals: csrc/backtest.hip, csrc/strategy.hip) -- this module holds no arithmetic of its own,
+so a non-Python host composes the same strategies from the same calls, and a recorded suite runs them in front of
+pq_backtest_vectorized without the signal columns leaving the device.
 """
 from __future__ import annotations
-
-import torch
 
 from . import api as _api
 
@@ -36,18 +37,11 @@ class Strategy:
         buy, sell = _api.cross_signals(fast, slow)
         if trend_filter and trend_period > 0:
             (trend,) = _api.call(_MA[ma_type], x, timeperiod=trend_period)
-            p = _api._to_device(x)[0]
-            t = _api._to_device(trend)[0]
-            buy = buy & (p > t).to(torch.uint8)      # a null trend value compares False
-        if slope_filter or distance_pct > 0.0:
-            p = _api._to_device(x)[0]
-            sl = _api._to_device(slow)[0]
-            if slope_filter:
-                rising = torch.zeros_like(buy)
-                rising[:, 1:] = (sl[:, 1:] > sl[:, :-1]).to(torch.uint8)
-                buy = buy & rising
-            if distance_pct > 0.0:
-                buy = buy & ((p - sl) > sl.abs() * (distance_pct / 100.0)).to(torch.uint8)
+            buy, sell = _api.gate_signals(buy, sell, x, 2, c=trend)              # buys only while price > MA(trend_period)
+        if slope_filter:
+            buy, sell = _api.gate_signals(buy, sell, slow, 3)                    # buys only while the slow MA rises
+        if distance_pct > 0.0:
+            buy, sell = _api.gate_signals(buy, sell, x, 4, k0=distance_pct / 100.0, c=slow)
         return {"buy_signal": buy, "sell_signal": sell}
 
     def macd(self, df, price_col="close", fast_period=12, slow_period=26, signal_period=9):
@@ -72,9 +66,8 @@ class Strategy:
         """%K crossing %D, buys only in the oversold zone and sells only in the overbought zone"""
         k, d = _api.call("stoch", _col(df, "high"), _col(df, "low"), _col(df, "close"), fastk_period=fastk_period,
                          slowk_period=slowk_period, slowd_period=slowd_period)
-        buy, sell = _api.cross_signals(k, d)
-        kk = _api._to_device(k)[0]
-        return {"buy_signal": buy & (kk < oversold).to(torch.uint8), "sell_signal": sell & (kk > overbought).to(torch.uint8)}
+        buy, sell = _api.gate_signals(*_api.cross_signals(k, d), k, 0, k0=oversold, k1=overbought)
+        return {"buy_signal": buy, "sell_signal": sell}
 
     def cci(self, df, period=14, oversold=-100.0, overbought=100.0):
         (c,) = _api.call("cci", _col(df, "high"), _col(df, "low"), _col(df, "close"), timeperiod=period)
@@ -89,9 +82,8 @@ class Strategy:
         (pdm,) = _api.call("plus_dm", h, l, timeperiod=period)
         (mdm,) = _api.call("minus_dm", h, l, timeperiod=period)
         (adx,) = _api.call("adx", h, l, c, timeperiod=period)
-        buy, sell = _api.cross_signals(pdm, mdm)
-        strong = (_api._to_device(adx)[0] > threshold).to(torch.uint8)      # null ADX compares False
-        return {"buy_signal": buy & strong, "sell_signal": sell & strong}
+        buy, sell = _api.gate_signals(*_api.cross_signals(pdm, mdm), adx, 1, k0=threshold)      # a null ADX compares false
+        return {"buy_signal": buy, "sell_signal": sell}
 
     def breakout(self, df, period=20):
         """Donchian channel: buy when the close exceeds the highest high of the previous `period` bars, sell when it falls
@@ -106,40 +98,28 @@ class Strategy:
         through -threshold, sell when it comes back down through +threshold (rule `band`)"""
         x = _col(df, price_col)
         up, mid, _lo = _api.call("bbands", x, timeperiod=period, nbdevup=1.0, nbdevdn=1.0)
-        p, u, m = (_api._to_device(t)[0] for t in (x, up, mid))
-        z = (p - m) / (u - m)                         # up - mid = 1.0 * sd
-        z = torch.where(u.view(torch.int64) == _NULL_I64, u, z)   # a null band row stays null: the rule is false there
+        z = _api.zscore(x, up, mid)                   # up - mid = 1.0 * sd; a null band row stays null: the rule is false there
         buy, sell = _api.band_signals(z, -threshold, threshold)
         return {"buy_signal": buy, "sell_signal": sell}
 
     def volume(self, df, period=20, multiplier=2.0):
         """volume breakout: volume above multiplier x SMA(volume, period) on an up day buys, on a down day sells"""
-        v, c = _api._to_device(_col(df, "volume"))[0], _api._to_device(_col(df, "close"))[0]
         (sv,) = _api.call("sma", _col(df, "volume"), timeperiod=period)
-        surge = (v > multiplier * _api._to_device(sv)[0])
-        up, dn = torch.zeros_like(surge), torch.zeros_like(surge)
-        up[:, 1:] = c[:, 1:] > c[:, :-1]
-        dn[:, 1:] = c[:, 1:] < c[:, :-1]
-        return {"buy_signal": (surge & up).to(torch.uint8), "sell_signal": (surge & dn).to(torch.uint8)}
+        buy, sell = _api.volume_surge_signals(_col(df, "volume"), sv, _col(df, "close"), multiplier)
+        return {"buy_signal": buy, "sell_signal": sell}
 
     def grid(self, df, price_col="close", base_period=20, grid_pct=5.0):
         """one grid level around a moving base line: buy when the price drops through SMA x (1 - grid_pct %), sell when it rises
         through SMA x (1 + grid_pct %) (rule `channel`, mode 0)"""
         x = _col(df, price_col)
         (base,) = _api.call("sma", x, timeperiod=base_period)
-        b = _api._to_device(base)[0]
-        isn = b.view(torch.int64) == _NULL_I64
-        lo = torch.where(isn, b, b * (1.0 - grid_pct / 100.0))
-        hi = torch.where(isn, b, b * (1.0 + grid_pct / 100.0))
+        lo, hi = _api.scale_band(base, 1.0 - grid_pct / 100.0, 1.0 + grid_pct / 100.0)
         buy, sell = _api.channel_signals(x, lo, hi, 0)
         return {"buy_signal": buy, "sell_signal": sell}
 
     def gap(self, df, gap_pct=2.0):
         """opening gaps: an open above the previous high by gap_pct % buys, below the previous low by gap_pct % sells"""
-        o, h, l = (_api._to_device(_col(df, k))[0] for k in ("open", "high", "low"))
-        buy, sell = torch.zeros(o.shape, dtype=torch.uint8, device=o.device), torch.zeros(o.shape, dtype=torch.uint8, device=o.device)
-        buy[:, 1:] = (o[:, 1:] > h[:, :-1] * (1.0 + gap_pct / 100.0)).to(torch.uint8)
-        sell[:, 1:] = (o[:, 1:] < l[:, :-1] * (1.0 - gap_pct / 100.0)).to(torch.uint8)
+        buy, sell = _api.gap_signals(_col(df, "open"), _col(df, "high"), _col(df, "low"), 1.0 + gap_pct / 100.0, 1.0 - gap_pct / 100.0)
         return {"buy_signal": buy, "sell_signal": sell}
 
     def pattern(self, df, bullish=("cdlhammer", "cdlengulfing", "cdlmorningstar", "cdlpiercing", "cdl3whitesoldiers"),
@@ -147,17 +127,11 @@ class Strategy:
         """candlestick patterns (one fused pass over OHLC): any of `bullish` at +100 buys, any of `bearish` at -100 sells"""
         names = sorted(set(bullish) | set(bearish))
         pats = _api.cdl_all(_col(df, "open"), _col(df, "high"), _col(df, "low"), _col(df, "close"), names=names)
-        any_ = lambda ns, v: torch.stack([(_api._to_device(pats[n], torch.int32)[0] == v) for n in ns]).any(dim=0).to(torch.uint8)
-        return {"buy_signal": any_(bullish, 100), "sell_signal": any_(bearish, -100)}
+        buy, sell = _api.pattern_any_signals([pats[n] for n in bullish], [pats[n] for n in bearish])
+        return {"buy_signal": buy, "sell_signal": sell}
 
     def trend(self, df, price_col="close", periods=(5, 10, 20, 60), ma_type="sma"):
         """multi-MA alignment: buy on the first bar where MA(p1) > MA(p2) > ... holds, sell on the first bar of the reverse order"""
         x = _col(df, price_col)
-        mas = [_api._to_device(_api.call(_MA[ma_type], x, timeperiod=p)[0])[0] for p in periods]
-        bull = torch.stack([a > b for a, b in zip(mas, mas[1:])]).all(dim=0)     # nulls (NaN) compare False
-        bear = torch.stack([a < b for a, b in zip(mas, mas[1:])]).all(dim=0)
-        first = lambda m: torch.cat([torch.zeros_like(m[:, :1]), m[:, 1:] & ~m[:, :-1]], dim=1).to(torch.uint8)
-        return {"buy_signal": first(bull), "sell_signal": first(bear)}
-
-
-_NULL_I64 = 0x7FF80000504E554C
+        buy, sell = _api.ma_stack_signals([_api.call(_MA[ma_type], x, timeperiod=p)[0] for p in periods])   # nulls compare false
+        return {"buy_signal": buy, "sell_signal": sell}
