@@ -306,7 +306,7 @@ def main():
     # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # command; summary committed by scripts/pmc_summary.py).  Only valid for the configuration it was collected on.
     traffic = None
-    pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
+    pmc = ROOT / "profiles" / "r03_pmc_traffic.json"   # (collected by scripts/collect_profiles.sh; says so in the line: roofline.traffic_source)
     if pmc.exists() and n_local == N_SYM and T == T_DAYS:
         kernels = json.loads(pmc.read_text())["kernels"]
         k = kernels.get("seq_jobs_kernel<0>")
@@ -336,6 +336,7 @@ def main():
                        "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "kernel": "seq_jobs_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" if traffic else None,
                          # the whole step against what this chip does for a read/write MIX: its L2-miss bytes (PMC) per second, and
                          # the rate of a streaming copy (2.2 TB/s read + 2.2 TB/s written, scripts/ubench/write_bw.py)
                          "step_traffic": step_traffic,

@@ -90,8 +90,8 @@ struct pq_suite {
 };
 
 // every recordable SEQ op: X(Type).  Kernel variants: the register-hungry Hilbert ops would pin the whole grid to
-// 2 waves/SIMD, so they (and the backtest scan) get their own kernel; everything else is compiled for 3 waves/SIMD
-// (168 VGPRs), which matches the 5-6 two-wave workgroups per CU that LDS admits anyway.
+// 2 waves/SIMD with 255 VGPRs, so they (and the lane-form backtest scan) get their own kernel; everything else needs <= 221
+// VGPRs (no scratch) at the same 2 waves/SIMD.
 #define SEQ_OPS_LIGHT(X)                                                                                             \
     X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
     X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
@@ -108,7 +108,11 @@ struct pq_suite {
 // backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
 template <int V>
 #ifndef PQ_LB0
-#define PQ_LB0 3 // waves per SIMD the light kernel is compiled for (168 VGPRs)
+// waves per SIMD the light kernel is compiled for.  2 (round 3): 221 VGPRs, ScratchSize 0.  At 3 (168 VGPRs) the three widest jobs
+// (EMA x 4, the volume family, the DM system) spilled 359 registers / 272 B of scratch per lane; LDS already holds a CU to four
+// of the LONG grid's workgroups = 2 waves / SIMD, so the third wave was never resident there.  A/B in one session: LONG grid
+// 4.05 -> 3.5 ms, HEAVY 4.25 -> 3.7 ms, step -1.2 % (the ROW chain is then the longest).  Table: profiles/r03_kernel_resources.txt
+#define PQ_LB0 2
 #endif
 __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];

@@ -14,10 +14,20 @@ cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats
 # 2. HBM traffic counters, one pass each
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > /dev/null 2> "$OUT/pmc_write.err"
-( cd "$R" && python scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r02" > "$OUT/pmc_summary.txt" )
+( cd "$R" && python scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r03" > "$OUT/pmc_summary.txt" )
 # 3. workgroup residency of one step (device timestamps)
 ( cd "$R" && PQ_SUITE_DEBUG=2 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/wg.log" 2>&1; python scripts/wg_residency.py "$OUT/wg.log" > "$OUT/wg_residency.txt" )
-# 4. the plain bench line (with the CPU baseline) for reference
+# 4. the plain bench line (with the CPU baseline) for reference, the end-to-end figures, the backtest alone on shards (strong scaling
+#    projection), the phase profile of the wave backtest is a separate build (scripts/prof_backtest.py)
 ( cd "$R" && python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" )
+( cd "$R" && python3 bench.py --e2e --no-cpu-baseline > "$OUT/bench_e2e.json" 2>> "$OUT/bench.err" )
+( cd "$R" && python3 scripts/strong_scaling_1gpu.py > "$OUT/strong_scaling_1gpu.json" 2>> "$OUT/bench.err" )
+( cd "$R" && python3 scripts/bench_backtest.py > "$OUT/bench_backtest.json" 2>> "$OUT/bench.err" )
+( cd "$R" && python3 scripts/bench_strategy.py > "$OUT/bench_strategy.json" 2>> "$OUT/bench.err" )
+( cd "$R" && python3 scripts/measure_tolerance.py > "$OUT/tolerance.json" 2>> "$OUT/bench.err" )
+# 5. rocprofv3 kernel stats of the config-3 backtest alone
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bt" -- python3 $R/scripts/bench_backtest.py > /dev/null 2> "$OUT/trace_bt.err"
+cp "$(find "$OUT/trace_bt" -name '*kernel_stats.csv' | head -1)" "$OUT/backtest_kernel_stats.csv"; rm -rf "$OUT/trace_bt"
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/wg.log"
 ls -la "$OUT"; tail -1 "$OUT/bench.json" | cut -c1-400
