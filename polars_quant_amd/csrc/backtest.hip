@@ -72,6 +72,51 @@ static bool bt_wave(pq_ctx *ctx, const pq_batch *b, bool macd, const BtArgs &g, 
     return true;
 }
 
+struct LevWaveBlob {
+    LevWaveArgs w;
+    pq_batch b;
+    unsigned lds;
+};
+static void lev_wave_launch_blob(const void *blob, hipStream_t stream) {
+    const LevWaveBlob &lb = *reinterpret_cast<const LevWaveBlob *>(blob);
+    static bool big_lds = false;
+    if (lb.lds > 64 * 1024 && !big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lev_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(lev_wave_kernel, dim3((unsigned)lb.b.n_series), dim3(64), lb.lds, stream, lb.w, dims_of(&lb.b));
+}
+// the leveraged engine, one symbol per wavefront (len <= 4096); true: handled
+static bool lev_wave(pq_ctx *ctx, const pq_batch *b, const LevArgs &a, pq_status *st) {
+    if (getenv("PQ_BT_LANE_FORM") || b->len > 64 * BTW_MAX_C || b->n_series > 0x7fffffffLL) return false;
+    LevWaveBlob lb{};
+    BtWaveArgs plan{};
+    size_t lds = 0;
+    btw_plan(b, 0, 0, 0, false, plan, lds, false);
+    lb.w.a = a; lb.w.C = plan.C; lb.w.P = plan.P; lb.w.magic = plan.magic;
+    lb.b = *b;
+    lb.lds = (unsigned)((size_t)64 * plan.P * 8 * ((a.bench && a.summary) ? 2 : 1));
+    *st = PQ_OK;
+    if (ctx->rec) {
+        static_assert(sizeof(LevWaveBlob) <= sizeof(RowThunk::blob), "leveraged wave blob too large");
+        RowThunk t{};
+        t.launch = &lev_wave_launch_blob;
+        t.blob_bytes = (int)sizeof lb;
+        t.dims = dims_of(b);
+        memcpy(t.blob, &lb, sizeof lb);
+        const void *rd[4] = {a.price, a.buy, a.sell, a.bench};
+        for (int k = 0; k < 4; k++) if (rd[k]) t.reads[t.n_reads++] = rd[k];
+        void *wr[] = {a.cash_net, a.stock_value, a.total_value, a.summary, a.trade_count, a.entry_day, a.exit_day, a.reason, a.entry_price,
+                      a.exit_price, a.quantity, a.pnl, a.pnl_pct};
+        for (void *q : wr) if (q) t.writes[t.n_writes++] = q;
+        *st = rec_add_row(ctx, t);
+        return true;
+    }
+    lev_wave_launch_blob(&lb, ctx->stream);
+    if (hipGetLastError() != hipSuccess) { pq_set_error("leveraged wave backtest launch failed"); *st = PQ_ERR_HIP; }
+    return true;
+}
+
 extern "C" {
 
 // [0] symbols run by the wave form since the last reset, [1] speculative chunks that failed the bit test, [2] chunk re-runs
@@ -186,6 +231,8 @@ pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *pr
     a.entry_price = entry_price; a.exit_price = exit_price; a.quantity = quantity; a.pnl = pnl; a.pnl_pct = pnl_pct;
     a.summary = summary; a.prm = *params;
     PQ_REQUIRE(!(b->offsets && benchmark), "pq_backtest_leveraged: a shared benchmark series has no meaning for a ragged batch (pass NULL)");
+    pq_status wst;
+    if (lev_wave(ctx, b, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
     if (!b->offsets && b->stride % 8 == 0 && reinterpret_cast<uintptr_t>(buy) % 8 == 0 && reinterpret_cast<uintptr_t>(sell) % 8 == 0) {
         LevOp op{};                        // tiled path: coalesced column traffic
         op.a = a; op.stride = b->stride;

@@ -95,6 +95,171 @@ __device__ __forceinline__ void btw_bcast_ema(EmaCore &e, int l) { // every lane
     e.sum = btw_readlane(e.sum, l);
 }
 
+// geometry of one symbol's rows in LDS: row i of the series at i + (i / C) * (P - C) (chunk pitch P odd: lane c reads its chunk's
+// rows c * P + b without bank conflicts, and the wave reads 64 consecutive rows without them too)
+struct BtwGeom {
+    int T, C, P;
+    unsigned magic; // ceil(2^20 / C)
+    __device__ __forceinline__ int addr(int i) const { return i + (int)(((unsigned)i * magic) >> 20) * (P - C); }
+};
+// one column of the symbol, coalesced, into LDS (rows >= T: `fill`); returns whether this lane saw a NULL row
+__device__ __forceinline__ bool btw_stage(const BtwGeom &g, int lane, const double *src, double *dst, double fill) {
+    const int T = g.T, C = g.C;
+    bool null_seen = false;
+    auto addr = [&](int i) { return g.addr(i); };
+    {
+        if (((reinterpret_cast<uintptr_t>(src) & 15) == 0)) { // 16 bytes per lane: rows 128 * j + 2 * lane, + 1
+            const int npair = (T + 127) / 128;
+            for (int j0 = 0; j0 < npair; j0 += 8) {
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 128 * (j0 + u) + 2 * lane;
+                    v[u] = make_double2(fill, fill);
+                    if (j0 + u < npair) {
+                        if (i + 1 < T) v[u] = *reinterpret_cast<const double2 *>(src + i);
+                        else if (i < T) v[u].x = src[i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 128 * (j0 + u) + 2 * lane;
+                    if (j0 + u < npair && i < 64 * C) {
+                        dst[addr(i)] = v[u].x;
+                        dst[addr(i + 1)] = v[u].y;
+                        null_seen |= (i < T && pq_isnull(v[u].x)) || (i + 1 < T && pq_isnull(v[u].y));
+                    }
+                }
+            }
+        } else {
+            for (int j0 = 0; j0 < C; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 64 * (j0 + u) + lane;
+                    v[u] = (j0 + u < C && i < T) ? src[i] : fill;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 64 * (j0 + u) + lane;
+                    if (j0 + u < C) {
+                        dst[addr(i)] = v[u];
+                        null_seen |= i < T && pq_isnull(v[u]);
+                    }
+                }
+            }
+        }
+    }
+    return null_seen;
+}
+
+// calculate_summary (metrics.rs:7-152) of the equity row that sits in LDS (`px`; overwritten with the daily returns): lane c owns
+// rows [c*C, (c+1)*C).  The running max is an exact prefix max; max_drawdown / max_profit / win_rate / total_trades are exact; the
+// ordered f64 sums (mean, variance, covariance) are summed per chunk and then across the lanes in a fixed order (<= 1e-12).
+// `bm`: the benchmark rows in LDS (same geometry) or null.
+__device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *px, const double *bm, double initial_capital, int trades, int wins,
+                                            double *sm) {
+    const int T = g.T, C = g.C, P = g.P;
+    auto addr = [&](int i) { return g.addr(i); };
+    struct { double initial_capital; } prm{initial_capital};
+    const bool has_bench = bm != nullptr;
+    // ---- summary (metrics.rs:7-152): lane c owns rows [c*C, (c+1)*C) of the equity row now in LDS
+    const int c = lane, lo = c * C, hi = lo + C < T ? lo + C : T;
+    const int nrow = hi - lo; // <= 0: idle lane
+    double *erow = px + c * P;
+    const double init = prm.initial_capital;
+    const double NEG_INF = __longlong_as_double((long long)0xFFF0000000000000ULL);
+    double lm = NEG_INF;
+    for (int b = 0; b < nrow; b++) { const double e = erow[b]; if (e > lm) lm = e; }
+    double Mx = lm; // inclusive prefix max over the lanes (exact in any order)
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(Mx, off);
+        if (lane >= off && t > Mx) Mx = t;
+    }
+    double max_eq = __shfl_up(Mx, 1);
+    if (lane == 0 || !(max_eq > init)) max_eq = init; // the running max starts at initial_capital (metrics.rs:21)
+    double prev = init;
+    if (c > 0 && nrow > 0) prev = px[addr(lo - 1)];
+    const double last_eq = px[addr(T - 1)];
+    double max_dd = 0.0, rs = 0.0;
+    for (int b0 = 0; b0 < nrow; b0 += 4) { // metrics.rs:26-49, four rows at a time: their eight divisions overlap
+        double e[4], mx[4], pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = b0 + u < nrow ? erow[b0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (b0 + u < nrow && e[u] > max_eq) max_eq = e[u];
+            mx[u] = max_eq;
+            pv[u] = prev;
+            if (b0 + u < nrow) prev = e[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double dd = (mx[u] > 0.0) ? (mx[u] - e[u]) / mx[u] : 0.0;
+            const double rr = (pv[u] > 0.0) ? (e[u] - pv[u]) / pv[u] : 0.0;
+            if (b0 + u < nrow) {
+                if (dd > max_dd) max_dd = dd;
+                rs += rr;
+                erow[b0 + u] = rr;
+            }
+        }
+    }
+    auto wave_sum = [&](double v) { // fixed order, the same value on every lane
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    };
+    for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(max_dd, off); if (t > max_dd) max_dd = t; }
+    const double ret_sum = wave_sum(rs);
+    const double DAYS = 252.0, RF = 0.03;
+    const double total_return = (last_eq - init) / init;
+    const double mean = ret_sum / (double)T;
+    const double dof = fmax((double)T - 1.0, 1.0);
+    double bmean = 0.0;
+    const double *brow = bm + c * P;
+    double pb0 = 0.0;
+    if (has_bench) { // metrics.rs:86-140
+        pb0 = (c == 0 || nrow <= 0) ? bm[0] : bm[addr(lo - 1)];
+        double pb = pb0, bs = 0.0;
+        for (int b = 0; b < nrow; b++) { const double bv = brow[b]; bs += (pb > 0.0) ? (bv - pb) / pb : 0.0; pb = bv; }
+        bmean = wave_sum(bs) / (double)T;
+    }
+    double vs = 0.0, bvs = 0.0, cvs = 0.0;
+    {
+        double pb = pb0;
+        for (int b = 0; b < nrow; b++) {
+            const double dlt = erow[b] - mean;
+            vs += dlt * dlt;
+            if (has_bench) {
+                const double bv = brow[b];
+                const double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
+                const double db = br - bmean;
+                bvs += db * db;
+                cvs += dlt * db;
+                pb = bv;
+            }
+        }
+    }
+    vs = wave_sum(vs);
+    const double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
+    const double var = vs / dof;
+    const double vol = sqrt(var) * sqrt(DAYS);
+    const double sharpe = (vol > 0.0) ? (ann - RF) / vol : 0.0;
+    const double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
+    double alpha = 0.0, beta = 0.0;
+    if (has_bench) {
+        const double bvar = wave_sum(bvs) / dof, cov = wave_sum(cvs) / dof;
+        if (bvar > 0.0) beta = cov / bvar;
+        const double b0 = bm[0], b1 = bm[addr(T - 1)];
+        const double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;
+        const double bann = (btr > -1.0) ? pow(1.0 + btr, DAYS / (double)T) - 1.0 : -1.0;
+        alpha = ann - (RF + beta * (bann - RF));
+    }
+    if (lane == 0) {
+        sm[0] = ann; sm[1] = max_dd; sm[2] = alpha; sm[3] = beta; sm[4] = sharpe;
+        sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
+    }
+}
+
 #ifdef PQ_BTW_PROF // scripts/ab_build.sh only: per-phase device time summed over the waves, stats[4 + k] in 10 ns ticks
 #define BTW_T(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && a.stats) atomicAdd(a.stats + 4 + (k), t__ - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -125,52 +290,10 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
 
     // ---- phase 0: the symbol's rows, coalesced, into LDS; signal masks when the signals are inputs
     unsigned long long bmask = 0, smask = 0; // MACD: bit b of lane c = row c*C + b; else: bit b of lane w = row 64*w + b
-    bool null_seen = false;
-    auto stage = [&](const double *src, double *dst, double fill, bool count_nulls) {
-        if (((reinterpret_cast<uintptr_t>(src + base) & 15) == 0)) { // 16 bytes per lane: rows 128 * j + 2 * lane, + 1
-            const int npair = (T + 127) / 128;
-            for (int j0 = 0; j0 < npair; j0 += 8) {
-                double2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = 128 * (j0 + u) + 2 * lane;
-                    v[u] = make_double2(fill, fill);
-                    if (j0 + u < npair) {
-                        if (i + 1 < T) v[u] = *reinterpret_cast<const double2 *>(src + base + i);
-                        else if (i < T) v[u].x = src[base + i];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = 128 * (j0 + u) + 2 * lane;
-                    if (j0 + u < npair && i < 64 * C) {
-                        dst[addr(i)] = v[u].x;
-                        dst[addr(i + 1)] = v[u].y;
-                        if (count_nulls) null_seen |= (i < T && pq_isnull(v[u].x)) || (i + 1 < T && pq_isnull(v[u].y));
-                    }
-                }
-            }
-        } else {
-            for (int j0 = 0; j0 < C; j0 += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = 64 * (j0 + u) + lane;
-                    v[u] = (j0 + u < C && i < T) ? src[base + i] : fill;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = 64 * (j0 + u) + lane;
-                    if (j0 + u < C) {
-                        dst[addr(i)] = v[u];
-                        if (count_nulls) null_seen |= i < T && pq_isnull(v[u]);
-                    }
-                }
-            }
-        }
-    };
-    stage(a.price, px, pq_null(), true);
-    if (a.bench) stage(a.bench, bm, 0.0, false);
+    bool null_seen;
+    const BtwGeom geo{T, C, P, magic};
+    null_seen = btw_stage(geo, lane, a.price + base, px, pq_null());
+    if (a.bench) (void)btw_stage(geo, lane, a.bench + base, bm, 0.0);
     if (!MACD) {
         btw_lds_fence();
         for (int j0 = 0; j0 < C; j0 += 8) {
@@ -628,103 +751,148 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     BTW_T(2);
     if (!a.summary) return;
 
-    // ---- summary (metrics.rs:7-152): lane c owns rows [c*C, (c+1)*C) of the equity row now in LDS
-    const int c = lane, lo = c * C, hi = lo + C < T ? lo + C : T;
-    const int nrow = hi - lo; // <= 0: idle lane
-    double *erow = px + c * P;
-    const double init = prm.initial_capital;
-    const double NEG_INF = __longlong_as_double((long long)0xFFF0000000000000ULL);
-    double lm = NEG_INF;
-    for (int b = 0; b < nrow; b++) { const double e = erow[b]; if (e > lm) lm = e; }
-    double Mx = lm; // inclusive prefix max over the lanes (exact in any order)
-    for (int off = 1; off < 64; off <<= 1) {
-        const double t = __shfl_up(Mx, off);
-        if (lane >= off && t > Mx) Mx = t;
-    }
-    double max_eq = __shfl_up(Mx, 1);
-    if (lane == 0 || !(max_eq > init)) max_eq = init; // the running max starts at initial_capital (metrics.rs:21)
-    double prev = init;
-    if (c > 0 && nrow > 0) prev = px[addr(lo - 1)];
-    const double last_eq = px[addr(T - 1)];
-    double max_dd = 0.0, rs = 0.0;
-    for (int b0 = 0; b0 < nrow; b0 += 4) { // metrics.rs:26-49, four rows at a time: their eight divisions overlap
-        double e[4], mx[4], pv[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) e[u] = b0 + u < nrow ? erow[b0 + u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (b0 + u < nrow && e[u] > max_eq) max_eq = e[u];
-            mx[u] = max_eq;
-            pv[u] = prev;
-            if (b0 + u < nrow) prev = e[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const double dd = (mx[u] > 0.0) ? (mx[u] - e[u]) / mx[u] : 0.0;
-            const double rr = (pv[u] > 0.0) ? (e[u] - pv[u]) / pv[u] : 0.0;
-            if (b0 + u < nrow) {
-                if (dd > max_dd) max_dd = dd;
-                rs += rr;
-                erow[b0 + u] = rr;
-            }
-        }
-    }
-    auto wave_sum = [&](double v) { // fixed order, the same value on every lane
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        return v;
-    };
-    for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(max_dd, off); if (t > max_dd) max_dd = t; }
-    const double ret_sum = wave_sum(rs);
-    const double DAYS = 252.0, RF = 0.03;
-    const double total_return = (last_eq - init) / init;
-    const double mean = ret_sum / (double)T;
-    const double dof = fmax((double)T - 1.0, 1.0);
-    double bmean = 0.0;
-    const double *brow = bm + c * P;
-    double pb0 = 0.0;
-    if (a.bench) { // metrics.rs:86-140
-        pb0 = (c == 0 || nrow <= 0) ? bm[0] : bm[addr(lo - 1)];
-        double pb = pb0, bs = 0.0;
-        for (int b = 0; b < nrow; b++) { const double bv = brow[b]; bs += (pb > 0.0) ? (bv - pb) / pb : 0.0; pb = bv; }
-        bmean = wave_sum(bs) / (double)T;
-    }
-    double vs = 0.0, bvs = 0.0, cvs = 0.0;
-    {
-        double pb = pb0;
-        for (int b = 0; b < nrow; b++) {
-            const double dlt = erow[b] - mean;
-            vs += dlt * dlt;
-            if (a.bench) {
-                const double bv = brow[b];
-                const double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
-                const double db = br - bmean;
-                bvs += db * db;
-                cvs += dlt * db;
-                pb = bv;
-            }
-        }
-    }
-    vs = wave_sum(vs);
-    const double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
-    const double var = vs / dof;
-    const double vol = sqrt(var) * sqrt(DAYS);
-    const double sharpe = (vol > 0.0) ? (ann - RF) / vol : 0.0;
-    const double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
-    double alpha = 0.0, beta = 0.0;
-    if (a.bench) {
-        const double bvar = wave_sum(bvs) / dof, cov = wave_sum(cvs) / dof;
-        if (bvar > 0.0) beta = cov / bvar;
-        const double b0 = bm[0], b1 = bm[addr(T - 1)];
-        const double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;
-        const double bann = (btr > -1.0) ? pow(1.0 + btr, DAYS / (double)T) - 1.0 : -1.0;
-        alpha = ann - (RF + beta * (bann - RF));
-    }
-    if (lane == 0) {
-        double *sm = a.summary + s * PQ_SUMMARY_COLS;
-        sm[0] = ann; sm[1] = max_dd; sm[2] = alpha; sm[3] = beta; sm[4] = sharpe;
-        sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
-    }
+    btw_summary(geo, lane, px, a.bench ? bm : nullptr, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS);
     BTW_T(3);
+}
+
+// ---- the leveraged engine (SURVEY 8(f) rank 1 / decision D-10, oracle/backtest.c pqo_backtest_leveraged) in the same form: one
+// symbol per wavefront, 64 rows per step.  What is serial here:
+//   * the debt while a leveraged position is open compounds every row (debt += debt * rate / 252, a rounded product and a rounded
+//     sum): a wave-uniform two-operation chain per row, from which every lane keeps the value of its own row;
+//   * the events -- entries on a buy signal while flat, exits on the first row whose margin test fails (evaluated row-parallel
+//     against the lanes' own debt values) or that carries a sell signal -- with the reference's own operations (lot search loop
+//     included), once per event, wave-uniform.
+// Everything else (validity, last valid price, the three daily columns, the summary) is row-parallel.
+struct LevWaveArgs {
+    LevArgs a;
+    int32_t C, P;
+    uint32_t magic;
+};
+__global__ __launch_bounds__(64) void lev_wave_kernel(LevWaveArgs w, Dims d) {
+    extern __shared__ __align__(16) unsigned char btw_lds[];
+    const LevArgs &a = w.a;
+    const int lane = (int)threadIdx.x;
+    const int64_t s = blockIdx.x;
+    const int T = (int)dims_len(d, s);
+    const int64_t base = dims_base(d, s);
+    const BtwGeom geo{T, w.C, w.P, w.magic};
+    double *px = reinterpret_cast<double *>(btw_lds); // the price row; then the total_value row; then its daily returns
+    double *bm = px + 64 * w.P;                       // the shared benchmark row, when there is one
+    const pq_lev_params prm = a.prm;
+    if (a.trade_count && T == 0 && lane == 0) a.trade_count[s] = 0;
+    if (T == 0) {
+        if (a.summary && lane < 8) a.summary[s * PQ_SUMMARY_COLS + lane] = 0.0;
+        return;
+    }
+    (void)btw_stage(geo, lane, a.price + base, px, pq_null());
+    if (a.bench && a.summary) (void)btw_stage(geo, lane, a.bench, bm, 0.0);
+    btw_lds_fence();
+
+    double cash = prm.initial_capital, debt = 0.0, shares = 0.0, last_px = 0.0, e_outlay = 0.0, e_price = 0.0;
+    int e_day = 0, trades = 0, wins = 0;
+    const double rc = prm.interest_rate / 252.0; // D-10 step 1: the daily rate is formed first
+    const int64_t rb = s * (int64_t)a.max_trades;
+    const int nblk = (T + 63) / 64;
+    for (int j0 = 0; j0 < nblk; j0++) {
+        const int j = __builtin_amdgcn_readfirstlane(j0);
+        const int i = 64 * j + lane;
+        const int ai = geo.addr(i);
+        double x = px[ai];
+        if (pq_isnull(x)) x = __longlong_as_double(0x7FF8000000000000LL);
+        const bool in = i < T;
+        const bool valid = in && !(isnan(x) || x <= 0.0);
+        bool bb = false, sb = false;
+        if (in) { bb = a.buy[base + i] != 0; sb = a.sell[base + i] != 0; }
+        const unsigned long long vmask = btw_ballot(valid), bmask = btw_ballot(bb && valid), smask = btw_ballot(sb && valid);
+        // the last valid price at or before my row (stock_value is marked to it)
+        const unsigned long long below = vmask & ((2ULL << lane) - 1ULL);
+        const int src = below ? 63 - __builtin_clzll(below) : lane;
+        const double lpv = __shfl(x, src);
+        const double lp = below ? lpv : last_px;
+        // state after my row
+        double tcash = cash, tdebt = debt, tshares = shares;
+        int cur = 0;
+        const int nrow = T - 64 * j < 64 ? T - 64 * j : 64;
+        while (cur < nrow) {
+            const unsigned long long from = ~0ULL << cur;
+            if (shares == 0.0) { // flat: the next buy signal on a valid price
+                const unsigned long long m = bmask & from;
+                if (!m) break;
+                const int r = __builtin_ctzll(m);
+                const double p = btw_readlane(x, r);
+                const double exec = p * (1.0 + prm.slippage);
+                const double power = cash * prm.position_size * prm.leverage;
+                double lots = floor(power / (exec * 100.0));
+                double cost = 0.0, fee = 0.0;
+                while (lots > 0.0) {
+                    cost = lots * 100.0 * exec;
+                    fee = fmax(cost * prm.commission_rate, prm.min_commission);
+                    if (cost + fee <= cash * prm.leverage) break;
+                    lots -= 1.0;
+                }
+                if (lots > 0.0) {
+                    const double outlay = cost + fee;
+                    debt = fmax(outlay - cash, 0.0);
+                    cash = fmax(cash - outlay, 0.0);
+                    shares = lots * 100.0;
+                    e_outlay = outlay; e_price = exec; e_day = 64 * j + r;
+                    if (lane >= r) { tcash = cash; tdebt = debt; tshares = shares; }
+                }
+                cur = r + 1;
+            } else { // long: the debt compounds row by row; the first failed margin test or sell signal closes the position
+                double dl = tdebt; // my row's debt
+                if (debt > 0.0) {
+                    double dd = debt;
+                    for (int t = cur; t < nrow; t++) {
+                        dd += dd * rc;
+                        if (lane == t) dl = dd;
+                    }
+                }
+                const double eqv = shares * x;
+                const bool mc = valid && lane >= cur && dl > 0.0 && cash + eqv - dl < prm.margin_call_threshold * eqv;
+                const unsigned long long mcm = btw_ballot(mc);
+                const unsigned long long ex = (mcm | smask) & from;
+                if (lane >= cur) tdebt = dl;
+                if (!ex) { // still long at the end of the block
+                    if (debt > 0.0) debt = btw_readlane(dl, nrow - 1);
+                    break;
+                }
+                const int r = __builtin_ctzll(ex);
+                const int why = (mcm >> r) & 1ULL ? 2 : 1;
+                const double p = btw_readlane(x, r);
+                const double dr = btw_readlane(dl, r); // the debt on the exit row (0 if none)
+                const double exec = p * (1.0 - prm.slippage);
+                const double rev = shares * exec;
+                const double fee = fmax(rev * prm.commission_rate, prm.min_commission);
+                const double net = rev - fee;
+                const double gain = net - e_outlay;
+                if (lane == 0 && trades < a.max_trades && a.entry_day) {
+                    const int64_t q = rb + trades;
+                    a.entry_day[q] = e_day; a.exit_day[q] = 64 * j + r;
+                    a.entry_price[q] = e_price; a.exit_price[q] = exec; a.quantity[q] = shares;
+                    a.pnl[q] = gain; a.pnl_pct[q] = gain / e_outlay * 100.0; a.reason[q] = why;
+                }
+                trades += 1;
+                if (gain > 0.0) wins += 1;
+                cash = cash + net - dr;
+                debt = 0.0;
+                shares = 0.0;
+                if (lane >= r) { tcash = cash; tdebt = 0.0; tshares = 0.0; }
+                cur = r + 1;
+            }
+        }
+        if (vmask) last_px = btw_readlane(x, 63 - __builtin_clzll(vmask));
+        const double cn = tcash - tdebt, sv = tshares * lp, tv = cn + sv;
+        if (in) {
+            __builtin_nontemporal_store(cn, &a.cash_net[base + i]);
+            __builtin_nontemporal_store(sv, &a.stock_value[base + i]);
+            __builtin_nontemporal_store(tv, &a.total_value[base + i]);
+        }
+        px[ai] = tv;
+    }
+    btw_lds_fence();
+    if (a.trade_count && lane == 0) a.trade_count[s] = trades;
+    if (a.summary) btw_summary(geo, lane, px, a.bench ? bm : nullptr, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS);
 }
 
 // host side: shape of the wave form for a batch, or false when it does not apply (len > 64 * BTW_MAX_C)
