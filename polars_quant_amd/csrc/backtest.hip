@@ -95,7 +95,7 @@ static bool lev_wave(pq_ctx *ctx, const pq_batch *b, const LevArgs &a, pq_status
     btw_plan(b, 0, 0, 0, false, plan, lds, false);
     lb.w.a = a; lb.w.C = plan.C; lb.w.P = plan.P; lb.w.magic = plan.magic;
     lb.b = *b;
-    lb.lds = (unsigned)((size_t)64 * plan.P * 8 * ((a.bench && a.summary) ? 2 : 1));
+    lb.lds = (unsigned)((size_t)64 * plan.P * 8);
     *st = PQ_OK;
     if (ctx->rec) {
         static_assert(sizeof(LevWaveBlob) <= sizeof(RowThunk::blob), "leveraged wave blob too large");

@@ -156,11 +156,13 @@ __device__ __forceinline__ bool btw_stage(const BtwGeom &g, int lane, const doub
 // calculate_summary (metrics.rs:7-152) of the equity row that sits in LDS (`px`; overwritten with the daily returns): lane c owns
 // rows [c*C, (c+1)*C).  The running max is an exact prefix max; max_drawdown / max_profit / win_rate / total_trades are exact; the
 // ordered f64 sums (mean, variance, covariance) are summed per chunk and then across the lanes in a fixed order (<= 1e-12).
-// `bm`: the benchmark rows in LDS (same geometry) or null.
+// `bm`: the benchmark rows or null -- in LDS with the same geometry, or (bm_linear) a plain series in global memory (the leveraged
+// engine's ONE benchmark shared by all symbols: it stays in L2, so it is not worth a second LDS row per wave).
 __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *px, const double *bm, double initial_capital, int trades, int wins,
-                                            double *sm) {
+                                            double *sm, bool bm_linear = false) {
     const int T = g.T, C = g.C, P = g.P;
     auto addr = [&](int i) { return g.addr(i); };
+    auto baddr = [&](int i) { return bm_linear ? i : g.addr(i); };
     struct { double initial_capital; } prm{initial_capital};
     const bool has_bench = bm != nullptr;
     // ---- summary (metrics.rs:7-152): lane c owns rows [c*C, (c+1)*C) of the equity row now in LDS
@@ -215,10 +217,10 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
     const double mean = ret_sum / (double)T;
     const double dof = fmax((double)T - 1.0, 1.0);
     double bmean = 0.0;
-    const double *brow = bm + c * P;
+    const double *brow = bm + c * (bm_linear ? C : P);
     double pb0 = 0.0;
     if (has_bench) { // metrics.rs:86-140
-        pb0 = (c == 0 || nrow <= 0) ? bm[0] : bm[addr(lo - 1)];
+        pb0 = (c == 0 || nrow <= 0) ? bm[0] : bm[baddr(lo - 1)];
         double pb = pb0, bs = 0.0;
         for (int b = 0; b < nrow; b++) { const double bv = brow[b]; bs += (pb > 0.0) ? (bv - pb) / pb : 0.0; pb = bv; }
         bmean = wave_sum(bs) / (double)T;
@@ -249,7 +251,7 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
     if (has_bench) {
         const double bvar = wave_sum(bvs) / dof, cov = wave_sum(cvs) / dof;
         if (bvar > 0.0) beta = cov / bvar;
-        const double b0 = bm[0], b1 = bm[addr(T - 1)];
+        const double b0 = bm[0], b1 = bm[baddr(T - 1)];
         const double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;
         const double bann = (btr > -1.0) ? pow(1.0 + btr, DAYS / (double)T) - 1.0 : -1.0;
         alpha = ann - (RF + beta * (bann - RF));
@@ -777,7 +779,6 @@ __global__ __launch_bounds__(64) void lev_wave_kernel(LevWaveArgs w, Dims d) {
     const int64_t base = dims_base(d, s);
     const BtwGeom geo{T, w.C, w.P, w.magic};
     double *px = reinterpret_cast<double *>(btw_lds); // the price row; then the total_value row; then its daily returns
-    double *bm = px + 64 * w.P;                       // the shared benchmark row, when there is one
     const pq_lev_params prm = a.prm;
     if (a.trade_count && T == 0 && lane == 0) a.trade_count[s] = 0;
     if (T == 0) {
@@ -785,7 +786,6 @@ __global__ __launch_bounds__(64) void lev_wave_kernel(LevWaveArgs w, Dims d) {
         return;
     }
     (void)btw_stage(geo, lane, a.price + base, px, pq_null());
-    if (a.bench && a.summary) (void)btw_stage(geo, lane, a.bench, bm, 0.0);
     btw_lds_fence();
 
     double cash = prm.initial_capital, debt = 0.0, shares = 0.0, last_px = 0.0, e_outlay = 0.0, e_price = 0.0;
@@ -840,19 +840,22 @@ __global__ __launch_bounds__(64) void lev_wave_kernel(LevWaveArgs w, Dims d) {
                 }
                 cur = r + 1;
             } else { // long: the debt compounds row by row; the first failed margin test or sell signal closes the position
+                // (the position is closed on the first sell signal at the latest: the chain need not run past that row)
+                const unsigned long long sfrom = smask & from;
+                const int last = sfrom ? __builtin_ctzll(sfrom) : nrow - 1;
                 double dl = tdebt; // my row's debt
                 if (debt > 0.0) {
                     double dd = debt;
-                    for (int t = cur; t < nrow; t++) {
+                    for (int t = cur; t <= last; t++) {
                         dd += dd * rc;
                         if (lane == t) dl = dd;
                     }
                 }
                 const double eqv = shares * x;
-                const bool mc = valid && lane >= cur && dl > 0.0 && cash + eqv - dl < prm.margin_call_threshold * eqv;
+                const bool mc = valid && lane >= cur && lane <= last && dl > 0.0 && cash + eqv - dl < prm.margin_call_threshold * eqv;
                 const unsigned long long mcm = btw_ballot(mc);
                 const unsigned long long ex = (mcm | smask) & from;
-                if (lane >= cur) tdebt = dl;
+                if (lane >= cur && lane <= last) tdebt = dl;
                 if (!ex) { // still long at the end of the block
                     if (debt > 0.0) debt = btw_readlane(dl, nrow - 1);
                     break;
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(64) void lev_wave_kernel(LevWaveArgs w, Dims d) {
     }
     btw_lds_fence();
     if (a.trade_count && lane == 0) a.trade_count[s] = trades;
-    if (a.summary) btw_summary(geo, lane, px, a.bench ? bm : nullptr, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS);
+    if (a.summary) btw_summary(geo, lane, px, a.bench, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS, true);
 }
 
 // host side: shape of the wave form for a batch, or false when it does not apply (len > 64 * BTW_MAX_C)

@@ -25,6 +25,22 @@ for _ in range(5):
 e1.record(); e1.synchronize()
 ms_pm = e0.elapsed_time(e1) / 5
 print(f"backtest kernel {ms_bt:.3f} ms (incl. output allocation), portfolio metrics {ms_pm:.3f} ms")
+# the kernel alone: preallocated outputs, the C ABI called directly (what a host that keeps its buffers does)
+import ctypes as C0
+from polars_quant_amd._lib import Batch as B0, LevParams as LP0, check as ck0, lib as lib0
+from polars_quant_amd._spec import LEV_DEFAULTS as LD0
+_o = [torch.empty((N, T), dtype=torch.float64, device="cuda") for _ in range(3)]
+_cnt, _sm = torch.zeros(N, dtype=torch.int32, device="cuda"), torch.empty((N, 8), dtype=torch.float64, device="cuda")
+_prm, _b, _h = LP0(**{**LD0, "leverage": 2.0, "slippage": 0.001}), B0(N, T, T), api.ctx(0)
+_vp = lambda t: C0.c_void_p(t.data_ptr())
+def _k():
+    ck0(lib0().pq_backtest_leveraged(_h, C0.byref(_b), _vp(close), _vp(buy), _vp(sell), _vp(bench), C0.byref(_prm), *[_vp(t) for t in _o], 0, _vp(_cnt),
+                                     *([None] * 8), _vp(_sm)))
+for _ in range(3): _k()
+torch.cuda.synchronize(); e0.record()
+for _ in range(10): _k()
+e1.record(); e1.synchronize()
+print(f"pq_backtest_leveraged alone, preallocated outputs: {e0.elapsed_time(e1) / 10:.3f} ms")
 ms = ms_bt + ms_pm
 alg = (8 + 2 + 24) * N * T + 8 * N * T  # price + 2 signals in, 3 columns out; the portfolio pass re-reads total_value
 print(f"HIP: {ms:.3f} ms/step  {N*T/ms/1e3:.1f} M rows/s  {alg/ms/1e6:.0f} GB/s algorithmic  trades={int(r['trade_count'].sum())}")
