@@ -254,7 +254,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
             const int x = cdl_eval(id, w[CDL_R - 1 - r], w[CDL_R - r], w[CDL_R + 1 - r], w[CDL_R + 2 - r], w[CDL_R + 3 - r], a.pen[id], &lb);
             v[r] = (t0 + r >= lb) ? x : 0;
         }
-#ifdef PQ_EXP_NOSTORE
+#if PQ_EXP_NOSTORE_ON
         if (v[0] == 123456789) a.out[id][base + t0] = v[0];
 #else
         int32_t *dst = &a.out[id][base + t0];

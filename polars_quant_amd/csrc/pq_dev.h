@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../../include/pq_hip.h"
+#include "experiments.h"
 
 struct Recorder; // suite.hip
 
@@ -430,31 +431,13 @@ constexpr size_t SEQ_LDS_LIMIT = 64 * 1024; // above this an op falls back to th
 // Hand-off per tile: wave 0 finishes the out tile in LDS -> barrier A -> wave 1 pulls it into registers -> barrier B ->
 // wave 1 issues the global stores while wave 0 already overwrites LDS with the next input tile.
 constexpr int SEQ_LDS_BLOCK = 128;
-#ifdef PQ_PROFILE_WAVES // experiment: where does the compute wave spend its cycles? [job][load wait+LDS fill, rows, hand-off, tiles]
-static __device__ unsigned long long pq_prof[128][4]; // indexed by Op::SEQ_ID
-template <class Op, class = void> struct ProfId { static constexpr int value = 0; };
-template <class Op> struct ProfId<Op, decltype((void)Op::SEQ_ID)> { static constexpr int value = Op::SEQ_ID & 127; };
-#define PQ_PROF_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define PQ_PROF_ADD(k, dt) do { if (lane == 0) atomicAdd(&pq_prof[ProfId<Op>::value][k], (unsigned long long)(dt)); } while (0)
-#else
-#define PQ_PROF_T(v)
-#define PQ_PROF_ADD(k, dt)
-#endif
 // Output columns are written once and not read again by the same step: a non-temporal store streams them past L2 / MALL
 // instead of allocating there, which keeps the (shared, re-read) input columns cached.  Tile-copy microbenchmark
 // (scripts/ubench/tilecopy2): 2.9 -> 4.3 TB/s of stores.
 typedef double pq_d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
-#ifdef PQ_EXP_NOSTORE // experiment: how much of the step is the output traffic?  (only a never-true store is left)
-    if (v.x == 1.2345e-300) *p = v.y;
-#else
     pq_d2v w = {v.x, v.y};
-#ifdef PQ_EXP_PLAIN_STORES
-    *reinterpret_cast<pq_d2v *>(p) = w;
-#else
-    __builtin_nontemporal_store(w, reinterpret_cast<pq_d2v *>(p));
-#endif
-#endif
+    PQ_HOOK_STORE2(w, reinterpret_cast<pq_d2v *>(p));
 }
 template <class Op>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
@@ -479,9 +462,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
     for (int i = 0; i < NI; i++) co_row[i] = lds + (i * SPI + csym) * ROWB + cchunk * 16;
 
-#ifdef PQ_PROFILE_WAVES
-    if (lane == 0) atomicAdd(&pq_prof[120 + (__builtin_amdgcn_s_getreg(2308) & 3)][wave], 1ULL); // SIMD id histogram per wave role
-#endif
+    PQ_PROF_SIMD(wave);
     // hand-off of a finished out tile to the storer wave.  (Measured alternative: one-wave workgroups in which the compute
     // wave pulls the tile back and issues the stores itself, with the next tile's loads issued before them -- 8.2 vs 5.5 ms
     // per suite step: the wave's own stores hold up its vmcnt waits whatever the order.)
@@ -495,9 +476,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
             // Tunable: the storer can keep ACC consecutive out tiles in registers and issue their stores back to back (ACC * K * 8
             // contiguous bytes per series within a few cycles).  In a pure tile copy 64-byte pieces scattered over 64 series run
             // the write path at ~3.1 TB/s against ~3.7 (pairs) / ~4.3 TB/s (128-byte pieces and up), scripts/ubench/tilecopy3.hip.
-#ifndef PQ_STORER_ACC
-#define PQ_STORER_ACC 1 // 2 / 4: -1 % .. +4 % per suite step (A/B in one session): the microbenchmark's gain does not carry over
-#endif
+            // (PQ_STORER_ACC, experiments.h: 1; 2 / 4 measured -1 % .. +4 % per suite step: the microbenchmark's gain does not carry over)
 #ifndef PQ_STORER_PAIR
 #define PQ_STORER_PAIR 1
 #endif
@@ -615,20 +594,13 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     }
     unsigned char *my_row = lds + lane * ROWB;
     // wave 0 has no stores in flight (except for MASKED ops), so its prefetched loads can be waited for exactly
-#ifndef PQ_PF2_MAX
-#define PQ_PF2_MAX 0
-#endif
     constexpr int PF = (NIN * NI * 4 <= PQ_PF2_MAX) ? 2 : 1; // a second tile of prefetch costs NIN*NI*4 VGPRs
     double2 pre[PF][NIN][NI];
     auto prefetch = [&](double2 (&buf)[NIN][NI], int64_t t0) {
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
-#ifdef PQ_EXP_NOLOAD // experiment (with PQ_EXP_NOCOMPUTE): what do the input reads cost?
-            for (int i = 0; i < NI; i++) buf[k][i] = make_double2((double)t0, (double)i);
-#else
-            for (int i = 0; i < NI; i++) buf[k][i] = *reinterpret_cast<const double2 *>(inp[k] + crow[i] + t0);
-#endif
+            for (int i = 0; i < NI; i++) buf[k][i] = PQ_HOOK_TILE_LOAD(inp[k] + crow[i] + t0, t0, i);
     };
     auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
@@ -650,11 +622,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         PQ_PROF_T(c1);
         if constexpr (HasFast<Op>::value) {
             // steady state on the whole wave and a null-free tile: straight-line rows
-#ifdef PQ_EXP_NOCOMPUTE
-            if (true) {
-#else
-            if (__builtin_amdgcn_ballot_w64(maybe_null || !op.steady(t0)) == 0) {
-#endif
+            if (PQ_HOOK_FAST_OK(__builtin_amdgcn_ballot_w64(maybe_null || !op.steady(t0)) == 0)) {
                 constexpr int FU = FastUnroll<Op>::value < K ? FastUnroll<Op>::value : K;
                 static_assert(K % FU == 0, "FAST_UNROLL must divide the tile height");
 #pragma unroll 1
@@ -664,11 +632,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     for (int u = 0; u < FU; u++)
 #pragma unroll
                         for (int k = 0; k < NIN; k++) xs[u][k] = *reinterpret_cast<const double *>(my_row + k * TB + (j0 + u) * 8);
-#ifdef PQ_EXP_NOCOMPUTE // experiment: the traffic and the hand-off machinery alone (outputs = the first input)
-                    for (int u = 0; u < FU; u++) for (int k = 0; k < NOUT; k++) ys[u][k] = xs[u][0];
-#else
-                    fast_rows<Op, FU>(op, t0 + j0, xs, ys);
-#endif
+                    PQ_HOOK_FAST_ROWS(Op, FU, NOUT, op, t0 + j0, xs, ys);
 #pragma unroll
                     for (int u = 0; u < FU; u++) {
                         if constexpr (MASKED) {
@@ -880,11 +844,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void row_kernel(Op op, InCols<Op::NIN> i
     typename Op::OutT y[Op::NOUT];
     op.eval(r, t, y);
 #pragma unroll
-#ifdef PQ_EXP_NOSTORE
-    for (int k = 0; k < Op::NOUT; k++) if (y[k] == (typename Op::OutT)123456789) out.p[k][sbase + t] = y[k];
-#else
-    for (int k = 0; k < Op::NOUT; k++) __builtin_nontemporal_store(y[k], &out.p[k][sbase + t]); // written once, not re-read
-#endif
+    for (int k = 0; k < Op::NOUT; k++) PQ_HOOK_ROW_STORE(y[k], &out.p[k][sbase + t]); // non-temporal: written once, not re-read
 }
 template <class Op, class = void> struct RowId { static constexpr int value = 0; };
 template <class Op> struct RowId<Op, decltype((void)Op::ROW_ID)> { static constexpr int value = Op::ROW_ID; };

@@ -21,6 +21,7 @@ struct SeqJob { // device-visible
     int kind, nin, nout, cost; // cost: estimated solo duration in microseconds (SeqTraits)
     int heavy, masked;
     int cls;                   // CLS_*: the grid the job runs in (suite_finalize)
+    int prio;                  // s_setprio of the job's waves: by its cost relative to the longest job of the phase (suite_finalize)
     double summary_bytes;
     int alg_cols;                  // f64 column transfers credited (per reference call)
     unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
@@ -55,8 +56,10 @@ struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-
 enum { CLS_LONG = 0, CLS_SHORT = 1, CLS_HEAVY = 2, CLS_GATHER = 3, NCLS = 4, NCHAIN = 4, ROW_CHAIN = 3 };
 static const int k_chain_order[NCHAIN] = {CLS_HEAVY, CLS_LONG, CLS_SHORT, CLS_GATHER}; // enqueue order: hungriest first
 static const int k_variant[NCLS] = {0, 0, 1, 2};                                       // seq_jobs_kernel<V> of each class
-constexpr unsigned THIN_LDS_MAX = 26 * 1024; // six workgroups of this size fit a CU's 160 KB
-constexpr double LONG_FILL = 3.5;            // LONG-grid workgroups per CU placed at t = 0 (4 of <= 40 KB fit)
+// "thin" = six workgroups fit a CU's LDS; the LONG grid places half a workgroup less per CU at t = 0 than LDS admits of its widest
+// job.  Both follow from the device's LDS size and the recorded jobs (at 5 000 x 2 520 on MI355X: 26 KB and 3.5, the values round
+// 2 had tuned as literals).
+static unsigned thin_lds_max(const hipDeviceProp_t &prop) { return (unsigned)(prop.maxSharedMemoryPerMultiProcessor / 6 / 1024 * 1024); }
 struct Phase {
     GridStat gs[NCLS];
     GridStat gs_row;           // the chain of ROW launches (timed as one unit)
@@ -127,9 +130,9 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0
     const int64_t s = s0 + threadIdx.x;
     if (s0 >= d.n) return; // grid.x is padded to a multiple of 8 (see pq_suite_run)
     // long jobs are the critical path of the step: their waves win the issue arbitration against short jobs on the same SIMD
-    if (job.cost >= 1800) __builtin_amdgcn_s_setprio(3);
-    else if (job.cost >= 1300) __builtin_amdgcn_s_setprio(2);
-    else if (job.cost >= 900) __builtin_amdgcn_s_setprio(1);
+    if (job.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (job.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (job.prio == 1) __builtin_amdgcn_s_setprio(1);
 #define X(OP)                                                                                                        \
     case OP::SEQ_ID: {                                                                                               \
         OP op;                                                                                                       \
@@ -358,7 +361,18 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // class of every job (see the comment at CLS_*): heavy / gather by trait, the light tiled jobs by cost and LDS need
         std::stable_sort(p.seq.begin(), p.seq.end(), [](const SeqJob &a, const SeqJob &b) { return a.cost > b.cost; });
         double long_wgs = 0;
-        const double long_budget = LONG_FILL * (double)prop.multiProcessorCount;
+        const unsigned THIN_LDS_MAX = thin_lds_max(prop);
+        unsigned widest = 1;
+        int cmax = 1;
+        for (const SeqJob &j : p.seq) {
+            if (!j.heavy) widest = std::max(widest, j.lds_bytes);
+            cmax = std::max(cmax, j.cost);
+        }
+        const double long_fill = std::max(1.0, (double)(prop.maxSharedMemoryPerMultiProcessor / widest) - 0.5);
+        const double long_budget = long_fill * (double)prop.multiProcessorCount;
+        // the longest jobs are the critical path of a step: their waves win the issue arbitration against shorter jobs on the same
+        // SIMD.  Relative to the longest job of the phase (>= 0.8 / 0.58 / 0.4 of it), not to absolute microseconds.
+        for (SeqJob &j : p.seq) j.prio = j.cost >= 0.8 * cmax ? 3 : j.cost >= 0.58 * cmax ? 2 : j.cost >= 0.4 * cmax ? 1 : 0;
         for (SeqJob &j : p.seq) {
             const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
             if (j.heavy && (j.lds_bytes > 0 || bt)) j.cls = CLS_HEAVY;
@@ -542,7 +556,7 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
                                           q[2] >> 32, q[2] & 0xffffffffULL, p.seq[j].lds_bytes);
                     }
             }
-#ifdef PQ_PROFILE_WAVES
+#if defined(PQ_EXPERIMENTS) && defined(PQ_PROFILE_WAVES)
             {
                 static unsigned long long prof[128][4], zero[128][4];
                 PQ_HIP_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(pq_prof), sizeof(prof)));

@@ -109,11 +109,7 @@ class Suite:
             outs = [o["ht_dcperiod"][0], o["ht_dcphase"][0], o["ht_phasor"][0], o["ht_phasor"][1], o["ht_sine"][0], o["ht_sine"][1]]
             check(L.pq_ht_all(h, C.byref(b), C.c_void_p(ohlcv["close"].data_ptr()), *[C.c_void_p(t.data_ptr()) for t in outs]))
         else:
-            outs = self.out.get(name)
-            if "@" in name:           # experiments: "cci@3" = an independent replica of cci with its own output columns
-                name = name.split("@")[0]
-                if outs is None:
-                    outs = self.out.setdefault(name + "@" + str(len(self.out)), [torch.empty_like(t) for t in self.out[name]])
+            outs = self.out[name]
             cols = SPEC[name][0]
             check(getattr(L, "pq_" + name)(h, C.byref(b), *[C.c_void_p(self._col(ohlcv, c).data_ptr()) for c in cols],
                                            *self._defaults[name], *[C.c_void_p(t.data_ptr()) for t in outs]))
@@ -137,9 +133,6 @@ class Suite:
             fused_map = {k: v for k, v in self.FUSED.items() if k not in skip}
             covered = {n for v in fused_map.values() for n in v}
             return [n for n in names if n not in covered] + list(fused_map) + ["cdl_all", "backtest_macd_cross"]
-        if False:
-            covered = set()
-            names = [n for n in names if n not in covered] + list(self.FUSED)
         return names + ["cdl_all", "backtest_macd_cross"]
 
     def run_eager(self, ohlcv: dict) -> None:

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B variant of the library: scripts/ab_build.sh <name> "<extra -D flags>" [all | <tu>]  -> ab/libpq_<name>.so
+# The experiment switches of csrc/experiments.h need -DPQ_EXPERIMENTS as well (a product build never sets it).
 # Default: only suite.hip (the job-grid kernels bench.py times) is rebuilt with the flags; `all` rebuilds every TU.
 # `ab/` is git-ignored; delete it after use (it travels to the GPU box with every gpurun push).
 set -e
