@@ -35,7 +35,7 @@ struct BtWaveArgs {
     double *position, *cash, *equity, *summary; // each nullable
     pq_bt_params prm;
     int32_t fast, slow, sig;
-    int32_t C, P, nW;          // chunk rows, chunk pitch in LDS (odd: conflict-free per-lane reads), warm-up chunks
+    int32_t C, P, nW, nW2;     // chunk rows, chunk pitch in LDS (odd: conflict-free per-lane reads), warm-up chunks (arbitrary / scanned seeds)
     int32_t kcap;              // capacity of the event lists in LDS (more events: the block form)
     uint32_t magic;            // ceil(2^20 / C): i / C == (i * magic) >> 20 for i < 64 * C
     unsigned long long *stats; // nullable: [0] symbols, [1] speculative chunks that failed the bit test, [2] chunk re-runs
@@ -357,7 +357,13 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
         if (!(st.ef.dead || st.es.dead || st.eg.dead)) { // a dead average => no signal on any row
             const int nlive = (T + C - 1) / C;
             const bool live = c < nlive;
-            const int nk = nlive < a.nW + 1 ? nlive : a.nW + 1; // chunk iterations
+            const int pf = a.fast, ps = a.slow, pg = a.sig;
+            const int R1 = pf > ps ? pf : ps;  // m = fast - slow exists from the R1-th row on
+            const int H = R1 > pg ? R1 : pg;   // after H rows every average is seeded and prev_m / prev_s are values
+            const bool head = !any_null && H <= C;
+            // warm-up chunks: nW from an arbitrary seed; nW2 (much shorter) when the seeds come from the affine prefix scan below
+            const int nWe = head ? a.nW2 : a.nW;
+            const int nk = nlive < nWe + 1 ? nlive : nWe + 1; // chunk iterations
             // Schedule.  Lanes c > nW ("speculative") start nW chunks early and reach their own chunk in the LAST iteration.  The
             // first nW + 1 chunks have no room for a warm-up: lane 0 walks them serially from row 0 (exact) WHILE the speculative
             // lanes warm up, and hands its state after chunk k to lane k + 1; in the last iteration the lanes 1 .. nW run their
@@ -367,11 +373,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             // state from an arbitrary seed (the first price of their warm-up): every iteration of the loop is then straight-line
             // code.  Otherwise (nulls, or a seeding phase longer than a chunk) the speculative lanes start as if the series began
             // at their warm-up row and the loop runs the general per-row state machine while any active lane is not seeded.
-            const bool spec = live && c > a.nW;
-            const int pf = a.fast, ps = a.slow, pg = a.sig;
-            const int R1 = pf > ps ? pf : ps;  // m = fast - slow exists from the R1-th row on
-            const int H = R1 > pg ? R1 : pg;   // after H rows every average is seeded and prev_m / prev_s are values
-            const bool head = !any_null && H <= C;
+            const bool spec = live && c > nWe;
             auto hand_over = [&](int to) { // lane 0's state -> lane `to`: the exact state in front of that lane's chunk
                 BtwMacd h = st;
                 btw_bcast_ema(h.ef, 0); btw_bcast_ema(h.es, 0); btw_bcast_ema(h.eg, 0);
@@ -410,11 +412,48 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     steady_rows_keep(px, H);
                 }
                 hand_over(1);
-                if (spec) {
-                    const double x0 = px[(c - a.nW) * P];
-                    st.ef.ema = st.es.ema = x0; st.eg.ema = 0.0;
-                    st.ef.count = st.es.count = st.eg.count = H;
-                    st.prev_m = st.prev_s = 0.0;
+                // SEEDS.  In exact arithmetic an EMA is the affine map e -> (1-a) e + a x per row; a chunk is the composition of its
+                // rows' maps, and affine maps compose associatively: one Horner pass per lane over its chunk and one wave prefix scan
+                // give every average's value at every chunk boundary to ~1e-15 -- not the bits (each fma of the true recurrence rounds),
+                // but a seed a few ulps from the truth, from which the speculative run merges bitwise within ~1/alpha rows instead of
+                // ~36/alpha.  Lane 0 enters the scan as the constant map onto its exact state after chunk 0.  The signal line needs
+                // the per-row m = fast - slow: a second pass recomputes the rows of the chunk from the approximate boundary values.
+                {
+                    const double af = st.ef.alpha, as = st.es.alpha, ag = st.eg.alpha;
+                    const double qf = 1.0 - af, qs = 1.0 - as, qg = 1.0 - ag;
+                    const double *row = px + (live ? c : 0) * P;
+                    double Af = 1.0, Bf = 0.0, As = 1.0, Bs = 0.0;
+                    for (int b = 0; b < C; b++) {
+                        const double x = row[b];
+                        Bf = fma(qf, Bf, af * x); Bs = fma(qs, Bs, as * x);
+                        Af *= qf; As *= qs;
+                    }
+                    if (lane == 0) { Af = 0.0; Bf = st.ef.ema; As = 0.0; Bs = st.es.ema; }
+                    for (int off = 1; off < 64; off <<= 1) { // inclusive scan: (A, B) of lanes 0 .. c composed in row order
+                        const double pAf = __shfl_up(Af, off), pBf = __shfl_up(Bf, off), pAs = __shfl_up(As, off), pBs = __shfl_up(Bs, off);
+                        if (lane >= off) { Bf = fma(Af, pBf, Bf); Af *= pAf; Bs = fma(As, pBs, Bs); As *= pAs; }
+                    }
+                    // Bf / Bs: fast / slow average after chunk c (approximate; exact on lane 0)
+                    double f = __shfl_up(Bf, 1), sl = __shfl_up(Bs, 1); // ... in front of my chunk
+                    double Ag = 1.0, Bg = 0.0;
+                    for (int b = 0; b < C; b++) {
+                        const double x = row[b];
+                        f = fma(af, x - f, f); sl = fma(as, x - sl, sl);
+                        Bg = fma(qg, Bg, ag * (f - sl));
+                        Ag *= qg;
+                    }
+                    if (lane == 0) { Ag = 0.0; Bg = st.eg.ema; }
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const double pAg = __shfl_up(Ag, off), pBg = __shfl_up(Bg, off);
+                        if (lane >= off) { Bg = fma(Ag, pBg, Bg); Ag *= pAg; }
+                    }
+                    // a speculative lane starts in front of chunk c - nWe: the values after chunk c - nWe - 1
+                    const double sf = __shfl_up(Bf, nWe + 1), ss = __shfl_up(Bs, nWe + 1), sg = __shfl_up(Bg, nWe + 1);
+                    if (spec) {
+                        st.ef.ema = sf; st.es.ema = ss; st.eg.ema = sg;
+                        st.ef.count = st.es.count = st.eg.count = H;
+                        st.prev_m = sf - ss; st.prev_s = sg;
+                    }
                 }
             }
             BTW_T(5);
@@ -424,7 +463,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                 const int k = __builtin_amdgcn_readfirstlane(kk); // (the compiler otherwise keeps the counter in a VGPR and treats
                                                                   // everything derived from it as divergent)
                 const bool last = k == nk - 1;
-                const int q = last ? c : (spec ? c - a.nW + k : (head ? k + 1 : k));
+                const int q = last ? c : (spec ? c - nWe + k : (head ? k + 1 : k));
                 const bool lane0_active = head ? k + 2 < nk : true; // wave-uniform: lane 0 walks a chunk in this iteration
                 const bool lane0 = c == 0 && lane0_active;
                 const bool active = live && (last ? (c > 0 || (nk == 1 && !head)) : (spec || lane0));
@@ -946,6 +985,15 @@ static inline bool btw_plan(const pq_batch *b, int64_t fast, int64_t slow, int64
         if (const char *e = getenv("PQ_BT_WARM_CHUNKS")) nW = atoll(e); // tests: force failing chunks (re-run path)
         if (nW < 1) nW = 1;
         a.nW = (int32_t)(nW > 64 ? 64 : nW);
+        // with seeds from the affine prefix scan (null-free series) only the last ulps have to merge.  Measured at 5 000 x 2 520,
+        // MACD(12, 26, 9): 160 rows of warm-up leave 1.6 % of the 315 000 chunks unmerged, 200 rows none (scripts/bench_backtest.py
+        // with PQ_BT_WARM_CHUNKS2 = 4 / 5)
+        double rows2 = 10.8 / af + 10.8 / ag;
+        if (!(rows2 < 1e9)) rows2 = 1e9;
+        int64_t nW2 = ((int64_t)rows2 + C - 1) / C;
+        if (const char *e = getenv("PQ_BT_WARM_CHUNKS2")) nW2 = atoll(e);
+        if (nW2 < 1) nW2 = 1;
+        a.nW2 = (int32_t)(nW2 > a.nW ? a.nW : nW2);
     }
     a.kcap = 8 * C < T + 1 ? 8 * C : T + 1; // ~12 % of the rows may be events (MACD(12,26,9): 8 %) before the block form takes over
     if (a.kcap > 64 * BTW_NG) a.kcap = 64 * BTW_NG;
