@@ -55,6 +55,28 @@ __device__ __forceinline__ unsigned long long btw_bits(double v) { return (unsig
 // the compiler only has to keep the accesses in order (__syncthreads would also wait for every outstanding global store).
 __device__ __forceinline__ void btw_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
+
+// ---- cross-lane moves by DPP (gfx9: row shifts, row broadcasts and the whole-wave shift) instead of ds_bpermute: a prefix scan over
+// the 64 lanes is six steps -- row_shr 1 / 2 / 4 / 8 inside the rows of 16, then lane 15 of a row into the next row and lane 31 into
+// the upper half -- of ~10 clocks each, against ~250 for a __shfl_up of a double (two bpermutes and a wait per value).  A lane
+// without a source keeps `old`, which every caller sets to its operator's identity.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int btw_dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double btw_dpp(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int BTW_ROW_SHR1 = 0x111, BTW_ROW_SHR2 = 0x112, BTW_ROW_SHR4 = 0x114, BTW_ROW_SHR8 = 0x118, BTW_BCAST15 = 0x142,
+              BTW_BCAST31 = 0x143, BTW_WAVE_SHR1 = 0x138;
+// inclusive prefix scan over the lanes: v <- op(values of the lower lanes (already combined), v); `id` = identity of op
+#define BTW_SCAN_STEPS(STEP)                                                                                 \
+    STEP(BTW_ROW_SHR1, 0xf) STEP(BTW_ROW_SHR2, 0xf) STEP(BTW_ROW_SHR4, 0xf) STEP(BTW_ROW_SHR8, 0xf) STEP(BTW_BCAST15, 0xa) STEP(BTW_BCAST31, 0xc)
+// lane l <- lane l - 1 (lane 0 keeps `old`)
+template <class T>
+__device__ __forceinline__ T btw_prev_lane(T old, T v) { return btw_dpp<BTW_WAVE_SHR1>(old, v); }
+
 // The MACD-cross state machine of one lane (BtMacdOp::step without the trade part)
 struct BtwMacd {
     EmaCore ef, es, eg;
@@ -180,11 +202,10 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
         for (int u = 0; u < 8; u++) if (e[u] > lm) lm = e[u];
     }
     double Mx = lm; // inclusive prefix max over the lanes (exact in any order)
-    for (int off = 1; off < 64; off <<= 1) {
-        const double t = __shfl_up(Mx, off);
-        if (lane >= off && t > Mx) Mx = t;
-    }
-    double max_eq = __shfl_up(Mx, 1);
+#define BTW_MAX(CTRL, RM) { const double t = btw_dpp<CTRL, RM>(NEG_INF, Mx); if (t > Mx) Mx = t; }
+    BTW_SCAN_STEPS(BTW_MAX)
+#undef BTW_MAX
+    double max_eq = btw_prev_lane(NEG_INF, Mx);
     if (lane == 0 || !(max_eq > init)) max_eq = init; // the running max starts at initial_capital (metrics.rs:21)
     double prev = init;
     if (c > 0 && nrow > 0) prev = px[addr(lo - 1)];
@@ -212,12 +233,12 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
             }
         }
     }
-    // butterfly sums in a fixed order, the same value on every lane; several values per step share the cross-lane latency
+    // wave sums in a fixed order (an inclusive DPP scan, the total read from lane 63): the same value on every lane
     auto wave_sum3 = [&](double &v0, double &v1, double &v2) {
-        for (int off = 32; off > 0; off >>= 1) {
-            const double t0 = __shfl_xor(v0, off), t1 = __shfl_xor(v1, off), t2 = __shfl_xor(v2, off);
-            v0 += t0; v1 += t1; v2 += t2;
-        }
+#define BTW_SUM3(CTRL, RM) { v0 += btw_dpp<CTRL, RM>(0.0, v0); v1 += btw_dpp<CTRL, RM>(0.0, v1); v2 += btw_dpp<CTRL, RM>(0.0, v2); }
+        BTW_SCAN_STEPS(BTW_SUM3)
+#undef BTW_SUM3
+        v0 = btw_readlane(v0, 63); v1 = btw_readlane(v1, 63); v2 = btw_readlane(v2, 63);
     };
     double bs = 0.0, pb0 = 0.0;
     const double *brow = bm + c * (bm_linear ? C : P);
@@ -233,11 +254,12 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
         }
     }
     {
-        for (int off = 32; off > 0; off >>= 1) {
-            const double t = __shfl_xor(max_dd, off), t0 = __shfl_xor(rs, off), t1 = __shfl_xor(bs, off);
-            if (t > max_dd) max_dd = t;
-            rs += t0; bs += t1;
-        }
+#define BTW_MAXDD(CTRL, RM) { const double t = btw_dpp<CTRL, RM>(0.0, max_dd); if (t > max_dd) max_dd = t; }
+        BTW_SCAN_STEPS(BTW_MAXDD)
+#undef BTW_MAXDD
+        max_dd = btw_readlane(max_dd, 63);
+        double zero = 0.0;
+        wave_sum3(rs, bs, zero);
     }
     const double ret_sum = rs;
     const double DAYS = 252.0, RF = 0.03;
@@ -397,21 +419,32 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                 bmask = gt & ~pvg & vm;
                 smask = lt & ~pvl & vm;
             };
+            BTW_T(14);
             if (head) {
                 if (lane == 0) { // rows 0 .. H-1: no signal is possible yet (prev_m / prev_s are null until row H - 1)
-                    for (int b = 0; b < H; b++) {
-                        const int cnt = b + 1;
-                        const double x = px[b];
-                        const double f = btw_ema_lock(st.ef, x, cnt, pf), sl = btw_ema_lock(st.es, x, cnt, ps);
-                        if (cnt >= R1) { // before that the signal line sees zeros: its sum and its seed stay +0.0
-                            st.prev_m = f - sl;
-                            st.prev_s = btw_ema_lock(st.eg, st.prev_m, cnt, pg);
+                    for (int b0 = 0; b0 < H; b0 += 8) { // (eight rows leave LDS together: the serial part is the sums, not the reads)
+                        double xr[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) xr[u] = px[b0 + u < H ? b0 + u : H - 1];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int cnt = b0 + u + 1;
+                            if (cnt <= H) {
+                                const double f = btw_ema_lock(st.ef, xr[u], cnt, pf), sl = btw_ema_lock(st.es, xr[u], cnt, ps);
+                                if (cnt >= R1) { // before that the signal line sees zeros: its sum and its seed stay +0.0
+                                    st.prev_m = f - sl;
+                                    st.prev_s = btw_ema_lock(st.eg, st.prev_m, cnt, pg);
+                                }
+                            }
                         }
                     }
                     st.ef.count = st.es.count = st.eg.count = H;
+                    BTW_T(15);
                     steady_rows_keep(px, H);
                 }
+                BTW_T(10);
                 hand_over(1);
+                BTW_T(11);
                 // SEEDS.  In exact arithmetic an EMA is the affine map e -> (1-a) e + a x per row; a chunk is the composition of its
                 // rows' maps, and affine maps compose associatively: one Horner pass per lane over its chunk and one wave prefix scan
                 // give every average's value at every chunk boundary to ~1e-15 -- not the bits (each fma of the true recurrence rounds),
@@ -423,30 +456,56 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     const double qf = 1.0 - af, qs = 1.0 - as, qg = 1.0 - ag;
                     const double *row = px + (live ? c : 0) * P;
                     double Af = 1.0, Bf = 0.0, As = 1.0, Bs = 0.0;
-                    for (int b = 0; b < C; b++) {
-                        const double x = row[b];
-                        Bf = fma(qf, Bf, af * x); Bs = fma(qs, Bs, as * x);
-                        Af *= qf; As *= qs;
+                    int b = 0;
+                    for (; b + 8 <= C; b += 8) { // (eight LDS reads in flight per batch)
+                        double x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) x[u] = row[b + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { Bf = fma(qf, Bf, af * x[u]); Bs = fma(qs, Bs, as * x[u]); Af *= qf; As *= qs; }
                     }
+                    for (; b < C; b++) { const double x = row[b]; Bf = fma(qf, Bf, af * x); Bs = fma(qs, Bs, as * x); Af *= qf; As *= qs; }
                     if (lane == 0) { Af = 0.0; Bf = st.ef.ema; As = 0.0; Bs = st.es.ema; }
-                    for (int off = 1; off < 64; off <<= 1) { // inclusive scan: (A, B) of lanes 0 .. c composed in row order
-                        const double pAf = __shfl_up(Af, off), pBf = __shfl_up(Bf, off), pAs = __shfl_up(As, off), pBs = __shfl_up(Bs, off);
-                        if (lane >= off) { Bf = fma(Af, pBf, Bf); Af *= pAf; Bs = fma(As, pBs, Bs); As *= pAs; }
-                    }
+                    // inclusive scan: (A, B) of lanes 0 .. c composed in row order (identity: A = 1, B = 0)
+#define BTW_AFFINE2(CTRL, RM)                                                                                \
+    {                                                                                                        \
+        const double pAf = btw_dpp<CTRL, RM>(1.0, Af), pBf = btw_dpp<CTRL, RM>(0.0, Bf);                     \
+        const double pAs = btw_dpp<CTRL, RM>(1.0, As), pBs = btw_dpp<CTRL, RM>(0.0, Bs);                     \
+        Bf = fma(Af, pBf, Bf); Af *= pAf; Bs = fma(As, pBs, Bs); As *= pAs;                                  \
+    }
+                    BTW_SCAN_STEPS(BTW_AFFINE2)
+#undef BTW_AFFINE2
+                    BTW_T(12);
                     // Bf / Bs: fast / slow average after chunk c (approximate; exact on lane 0)
-                    double f = __shfl_up(Bf, 1), sl = __shfl_up(Bs, 1); // ... in front of my chunk
+                    double f = btw_prev_lane(Bf, Bf), sl = btw_prev_lane(Bs, Bs); // ... in front of my chunk
                     double Ag = 1.0, Bg = 0.0;
-                    for (int b = 0; b < C; b++) {
+                    b = 0;
+                    for (; b + 8 <= C; b += 8) {
+                        double x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) x[u] = row[b + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            f = fma(af, x[u] - f, f); sl = fma(as, x[u] - sl, sl);
+                            Bg = fma(qg, Bg, ag * (f - sl));
+                            Ag *= qg;
+                        }
+                    }
+                    for (; b < C; b++) {
                         const double x = row[b];
                         f = fma(af, x - f, f); sl = fma(as, x - sl, sl);
                         Bg = fma(qg, Bg, ag * (f - sl));
                         Ag *= qg;
                     }
                     if (lane == 0) { Ag = 0.0; Bg = st.eg.ema; }
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const double pAg = __shfl_up(Ag, off), pBg = __shfl_up(Bg, off);
-                        if (lane >= off) { Bg = fma(Ag, pBg, Bg); Ag *= pAg; }
-                    }
+#define BTW_AFFINE1(CTRL, RM)                                                                                \
+    {                                                                                                        \
+        const double pAg = btw_dpp<CTRL, RM>(1.0, Ag), pBg = btw_dpp<CTRL, RM>(0.0, Bg);                     \
+        Bg = fma(Ag, pBg, Bg); Ag *= pAg;                                                                    \
+    }
+                    BTW_SCAN_STEPS(BTW_AFFINE1)
+#undef BTW_AFFINE1
+                    BTW_T(13);
                     // a speculative lane starts in front of chunk c - nWe: the values after chunk c - nWe - 1
                     const double sf = __shfl_up(Bf, nWe + 1), ss = __shfl_up(Bs, nWe + 1), sg = __shfl_up(Bg, nWe + 1);
                     if (spec) {
@@ -510,10 +569,10 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             }
             // verification: my state at my first row == my predecessor's state after its last row, as raw bits
             auto mismatch = [&]() {
-                const bool p_steady = __shfl_up((int)st.steady(), 1) != 0;
-                const bool same = s_steady && p_steady && btw_bits(s_f) == btw_bits(__shfl_up(st.ef.ema, 1)) &&
-                                  btw_bits(s_s) == btw_bits(__shfl_up(st.es.ema, 1)) && btw_bits(s_g) == btw_bits(__shfl_up(st.eg.ema, 1)) &&
-                                  btw_bits(s_pm) == btw_bits(__shfl_up(st.prev_m, 1)) && btw_bits(s_ps) == btw_bits(__shfl_up(st.prev_s, 1));
+                const bool p_steady = btw_prev_lane(0, (int)st.steady()) != 0;
+                const bool same = s_steady && p_steady && btw_bits(s_f) == btw_bits(btw_prev_lane(0.0, st.ef.ema)) &&
+                                  btw_bits(s_s) == btw_bits(btw_prev_lane(0.0, st.es.ema)) && btw_bits(s_g) == btw_bits(btw_prev_lane(0.0, st.eg.ema)) &&
+                                  btw_bits(s_pm) == btw_bits(btw_prev_lane(0.0, st.prev_m)) && btw_bits(s_ps) == btw_bits(btw_prev_lane(0.0, st.prev_s));
                 return spec && !same;
             };
             unsigned long long mism = btw_ballot(mismatch());
@@ -575,18 +634,21 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             if (st1 ? iss : isb) { st1 ^= 1; ev1 |= 1ULL << b; }
         }
         int f0 = st0, f1 = st1; // inclusive scan of the composition: state after lanes 0..c given the state in front of lane 0
-        for (int off = 1; off < 64; off <<= 1) {
-            const int p0 = __shfl_up(f0, off), p1 = __shfl_up(f1, off);
-            if (lane >= off) { const int n0 = p0 ? f1 : f0, n1 = p1 ? f1 : f0; f0 = n0; f1 = n1; }
-        }
-        const int in = __shfl_up(f0, 1);
+#define BTW_AUTO(CTRL, RM)                                                                                   \
+    {                                                                                                        \
+        const int p0 = btw_dpp<CTRL, RM>(0, f0), p1 = btw_dpp<CTRL, RM>(1, f1); /* identity: 0 -> 0, 1 -> 1 */ \
+        const int n0 = p0 ? f1 : f0, n1 = p1 ? f1 : f0;                                                      \
+        f0 = n0; f1 = n1;                                                                                    \
+    }
+        BTW_SCAN_STEPS(BTW_AUTO)
+#undef BTW_AUTO
+        const int in = btw_prev_lane(0, f0);
         evm = (lane > 0 && in) ? ev1 : ev0;
         int cnt = __popcll(evm);
         const int mine = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(cnt, off);
-            if (lane >= off) cnt += t;
-        }
+#define BTW_ADD(CTRL, RM) cnt += btw_dpp<CTRL, RM>(0, cnt);
+        BTW_SCAN_STEPS(BTW_ADD)
+#undef BTW_ADD
         kexcl = cnt - mine;
         K = __builtin_amdgcn_readlane(cnt, 63);
         if (MACD) { // chunk-mapped bits -> block words, through LDS

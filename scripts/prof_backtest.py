@@ -22,6 +22,7 @@ for n in (5000, 625):
     for _ in range(reps): api.backtest_macd_cross(close)
     check(L.pq_backtest_wave_prof(api.ctx(0), out, 1))
     v = [x / (reps * n) for x in out]   # s_memtime ticks = shader clocks (2.4 GHz, scripts/ubench/f64lat.hip)
+    print(n, "head detail: init %.1f  seeding rows %.1f  lane-0 steady rows %.1f  hand-over %.1f  pass A + scan %.1f  pass B + scan %.1f  seeds %.1f" % tuple(x / 1e3 for x in (v[14], v[15], v[10], v[11], v[12], v[13], v[5])))
     print(n, "kilo-cycles per wave: load %.1f  signals [first chunk %.1f, warm-up chunks %.1f, own chunk %.1f, hand-over + bit test %.1f]  event marking %.1f  "
           "event list + reciprocals %.1f  chain %.1f  fill %.1f  summary %.1f  (sum %.1f = %.1f us)" %
-          (v[0] / 1e3, v[5] / 1e3, v[6] / 1e3, v[7] / 1e3, v[4] / 1e3, v[1] / 1e3, v[8] / 1e3, v[9] / 1e3, v[2] / 1e3, v[3] / 1e3, sum(v[:10]) / 1e3, sum(v[:10]) / 2400.0))
+          (v[0] / 1e3, (v[5] + v[10] + v[11] + v[12] + v[13]) / 1e3, v[6] / 1e3, v[7] / 1e3, v[4] / 1e3, v[1] / 1e3, v[8] / 1e3, v[9] / 1e3, v[2] / 1e3, v[3] / 1e3, sum(v) / 1e3, sum(v) / 2400.0))
