@@ -298,8 +298,8 @@ __device__ __forceinline__ void run_seq(Op &op, const double *const *inp, double
 // [64 series][K rows] per column with coalesced 16-byte accesses (K*8 contiguous bytes per series; K = 16 for
 // 1-in/1-out ops, 8 otherwise.  Measured: K = 32/16 moves ~25 % more bytes/s when the grid is bandwidth-bound, but
 // the doubled LDS footprint costs occupancy and the full suite runs slower, so the smaller tiles are the default),
-// transposes it through LDS (row pitch K*8+8 bytes: conflict-free for the cooperative b128 writes and for
-// the per-lane b64 reads), and each lane then walks ITS OWN row of the tile in the reference's order.
+// transposes it through LDS (row pitch K*8+8 bytes: conflict-free for the per-lane b64 reads, 2-way conflicts on the
+// cooperative 16-byte fills / pulls -- no pitch serves both patterns), and each lane then walks ITS OWN row of the tile in the reference's order.
 // Outputs take the same route back.  The next tile's global loads are in flight (in registers) while
 // the current tile is computed.  Rolling windows live in LDS rings ([slot][lane] layout), which also
 // makes them null-proof: only valid values are pushed.
