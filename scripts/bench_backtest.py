@@ -3,7 +3,7 @@ columns as in bench.py) and prints the wave form's chunk statistics.  PQ_BT_LANE
 import json
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 
 from polars_quant_amd import api

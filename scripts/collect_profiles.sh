@@ -28,6 +28,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 # 5. rocprofv3 kernel stats of the config-3 backtest alone
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bt" -- python3 $R/scripts/bench_backtest.py > /dev/null 2> "$OUT/trace_bt.err"
-cp "$(find "$OUT/trace_bt" -name '*kernel_stats.csv' | head -1)" "$OUT/backtest_kernel_stats.csv"; rm -rf "$OUT/trace_bt"
+f=$(find "$OUT/trace_bt" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/backtest_kernel_stats.csv"; rm -rf "$OUT/trace_bt"
+ls -la "$OUT"
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/wg.log"
 ls -la "$OUT"; tail -1 "$OUT/bench.json" | cut -c1-400
