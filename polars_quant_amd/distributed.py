@@ -102,15 +102,18 @@ class CabiComm:
         self._C, self._check, self._lib = C, check, lib()
         self.device = torch.device(device)
         self.h = api.ctx(self.device.index)
-        idbuf = torch.zeros(128, dtype=torch.uint8)
+        idbuf = torch.zeros(129, dtype=torch.uint8)   # [ok flag, 128 id bytes]: every rank learns whether rank 0 could make the id
         if rank == 0:
             raw = (C.c_ubyte * 128)()
-            check(self._lib.pq_comm_unique_id(raw))
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            if self._lib.pq_comm_unique_id(raw) == 0:
+                idbuf = torch.tensor([1] + list(raw), dtype=torch.uint8)
         if world > 1:
             on = idbuf.to(self.device) if dist.get_backend(group) == "nccl" else idbuf
             dist.broadcast(on, src=0, group=group)
             idbuf = on.cpu()
+        if int(idbuf[0]) != 1:
+            raise RuntimeError("pq_comm_unique_id failed on rank 0 (is RCCL loadable?)")
+        idbuf = idbuf[1:]
         raw = (C.c_ubyte * 128)(*idbuf.tolist())
         with torch.cuda.device(self.device):
             check(self._lib.pq_comm_init(self.h, rank, world, raw))
