@@ -131,3 +131,63 @@ def test_backtests_on_ragged_groups(pq, oracle):
             for k in (1, 5, 6, 7):
                 assert bits(gs[s, k:k + 1])[0] == bits(es2[k:k + 1])[0], (s, k)
             np.testing.assert_allclose(gs[s], es2, rtol=1e-12, atol=1e-13)
+
+
+def test_recorded_suite_on_a_ragged_batch(pq, oracle, groups):
+    """pq_suite_begin / end on a ragged batch: sequential jobs (per-lane body: ragged series start at arbitrary rows), the fused
+    row-parallel grid, the pattern kernel and the wave-per-symbol backtest replay from one recorded plan; every group equals the
+    oracle run on it alone."""
+    import ctypes as C
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import BtParams, check, lib
+    from polars_quant_amd._spec import BT_DEFAULTS
+    d, off, lens = groups
+    dev = torch.device("cuda")
+    g = {k: torch.from_numpy(d[k]).to(dev) for k in ("open", "high", "low", "close", "volume")}
+    b, keep = api.ragged_batch(off, dev)
+    R = int(off[-1])
+    f64 = lambda: torch.full((R,), -7.0, dtype=torch.float64, device=dev)
+    out = {"ema": f64(), "rsi": f64(), "atr": f64(), "mom": f64(), "typprice": f64(), "macd": [f64(), f64(), f64()], "bt": [f64(), f64(), f64()]}
+    pat = torch.full((R,), -7, dtype=torch.int32, device=dev)
+    summ = torch.empty((len(lens), 8), dtype=torch.float64, device=dev)
+    L, h, prm, vp = lib(), api.ctx(0), BtParams(**BT_DEFAULTS), (lambda t: C.c_void_p(t.data_ptr()))
+    check(L.pq_suite_begin(h, C.byref(b)))
+    check(L.pq_ema(h, C.byref(b), vp(g["close"]), 9, vp(out["ema"])))
+    check(L.pq_rsi(h, C.byref(b), vp(g["close"]), 14, vp(out["rsi"])))
+    check(L.pq_atr(h, C.byref(b), vp(g["high"]), vp(g["low"]), vp(g["close"]), 5, vp(out["atr"])))
+    check(L.pq_mom(h, C.byref(b), vp(g["close"]), 10, vp(out["mom"])))
+    check(L.pq_typprice(h, C.byref(b), vp(g["high"]), vp(g["low"]), vp(g["close"]), vp(out["typprice"])))
+    check(L.pq_macd(h, C.byref(b), vp(g["close"]), 12, 26, 9, *[vp(t) for t in out["macd"]]))
+    check(L.pq_cdl(h, C.byref(b), pq.PATTERN_NAMES.index("cdlengulfing"), vp(g["open"]), vp(g["high"]), vp(g["low"]), vp(g["close"]), C.c_double(0.3), vp(pat)))
+    check(L.pq_backtest_macd_cross(h, C.byref(b), vp(g["close"]), 12, 26, 9, C.byref(prm), *[vp(t) for t in out["bt"]], vp(summ)))
+    suite = C.c_void_p()
+    check(L.pq_suite_end(h, C.byref(suite)))
+    try:
+        check(L.pq_suite_run(h, suite))
+        check(L.pq_suite_run(h, suite))
+        torch.cuda.synchronize()
+    finally:
+        check(L.pq_suite_destroy(h, suite))
+    del keep
+    res = {k: ([t.cpu().numpy() for t in v] if isinstance(v, list) else v.cpu().numpy()) for k, v in out.items()}
+    pat, summ = pat.cpu().numpy(), summ.cpu().numpy()
+    for s in range(len(lens)):
+        lo, hi = off[s], off[s + 1]
+        if hi == lo:
+            continue
+        sl = {k: d[k][lo:hi] for k in ("open", "high", "low", "close")}
+        check_ = lambda nm, got, exp: check(f"{nm}{{suite, group {s}}}", got[lo:hi], np.asarray(exp).reshape(-1), True, sl["close"])
+        for nm, exp in (("ema", oracle.call("ema", sl["close"], timeperiod=9)[0]), ("rsi", oracle.call("rsi", sl["close"], timeperiod=14)[0]),
+                        ("atr", oracle.call("atr", sl["high"], sl["low"], sl["close"], timeperiod=5)[0]), ("mom", oracle.call("mom", sl["close"], timeperiod=10)[0]),
+                        ("typprice", oracle.call("typprice", sl["high"], sl["low"], sl["close"])[0])):
+            g_, e_ = res[nm][lo:hi], np.asarray(exp).reshape(-1)
+            assert ((bits(g_) == bits(e_)) | (np.isnan(g_) & np.isnan(e_))).all(), (nm, s)
+        for k, e_ in enumerate(oracle.call("macd", sl["close"])):
+            g_ = res["macd"][k][lo:hi]
+            assert ((bits(g_) == bits(np.asarray(e_).reshape(-1))) | (np.isnan(g_) & np.isnan(np.asarray(e_).reshape(-1)))).all(), ("macd", k, s)
+        assert (pat[lo:hi] == oracle.pattern("cdlengulfing", sl["open"], sl["high"], sl["low"], sl["close"]).reshape(-1)).all(), s
+        eb, es_ = oracle.macd_cross_signals(sl["close"])
+        ep, ec, ee, esum = oracle.backtest(sl["close"], eb, es_)
+        for g_, e_ in zip(res["bt"], (ep, ec, ee)):
+            assert (bits(g_[lo:hi]) == bits(e_)).all(), ("backtest", s)
+        np.testing.assert_allclose(summ[s], esum, rtol=1e-12, atol=1e-13)
