@@ -632,6 +632,120 @@ struct MavpSma16Op {
     }
 };
 
+// MAVP with the SMA core, up to THIRTY-TWO candidate periods [lo, hi] = [minperiod, maxperiod] in ONE job (the default 2 .. 30 is
+// 29): the job covers every period a row can ask for, so its output is an ordinary tile column -- coalesced 128-byte pieces through
+// the storer wave -- instead of the row-masked 8-byte stores two 16-candidate jobs need to share a column, and the inputs are read
+// once.  The candidates run as two halves of sixteen register chains per 8-row batch (same arithmetic and order per candidate as
+// MavpSma16Op: overlap.rs:897-910); the upper half's running sums are parked in LDS between batches ([16][lane] doubles), the lower
+// half's stay in registers.
+struct MavpSma32Op {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0), periods
+    static constexpr int SEQ_ID = 84;
+    static constexpr int COST_NS = 600;
+    int lo, hi, minp, maxp, n;
+    Ring w;
+    double *sb;        // parked sums of the candidates lo+16 .. lo+31, lane-offset: sb[u * 64]
+    const double *tab; // 1/P for P = lo .. lo+31 (shared by the wave)
+    double s[16];
+    // ring: the batched fast path pushes eight rows first and then reads x[t-lo-31 .. t+7-lo] (the oldest was pushed lo + 39 pushes ago)
+    __host__ __device__ int64_t ring_slots() const { return (lo > 0 ? lo : 1) + 39 + 16 + 1; }
+    __device__ void init(const Row<2> &) {}
+    __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
+        n = (int)(r.len < 0x7fffffff ? r.len : 0x7fffffff);
+        w = ra.make((lo > 0 ? lo : 1) + 39);
+        Ring park = ra.make(16);
+        sb = park.base;
+        double *t = ra.make_shared(32);
+        const int k = threadIdx.x & 63;
+        if (k < 32) t[k] = 1.0 / (double)(lo + k);
+        tab = t;
+#pragma unroll
+        for (int u = 0; u < 16; u++) { s[u] = 0.0; sb[u * 64] = 0.0; }
+        lds_fence();
+    }
+    __device__ void step(const Row<2> &, int64_t, const double (&)[2], double (&y)[1]) { y[0] = pq_null(); }
+    __device__ void step_lds(int64_t t64, const double (&x)[2], double (&y)[1]) { // warm-up rows: every gate of the definition
+        const double v = n0(x[0]);
+        const int t = (int)t64;
+        const int64_t p64 = (int64_t)n0(x[1]);
+        const int pi = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
+        const int c = t + 1; // every row is valid after nulls -> 0.0
+        double asel = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            double old[8];
+            w.get8<1>(lo + 8 * g, old); // x[t - P] for the eight periods of this group
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int P = lo + 8 * g + u;
+                double a = (g < 2 ? s[(8 * g + u) & 15] : sb[(8 * (g - 2) + u) * 64]) + v;
+                const double b = a - old[u];
+                a = (c > P) ? b : a; // wave-uniform condition
+                a = (P <= hi && P > 0 && n >= P) ? a : 0.0;
+                if (g < 2) s[(8 * g + u) & 15] = a; else sb[(8 * (g - 2) + u) * 64] = a;
+                asel = (P == pi) ? a : asel;
+            }
+        }
+        w.push(v);
+        const bool ok = pi > 0 && n >= pi && c >= pi && t >= maxp - 1;
+        y[0] = ok ? asel * tab[pi - lo] : pq_null();
+    }
+    static constexpr bool FAST_NULL_OK = true; // N-0: nulls become 0.0 in the row body
+    static constexpr int FAST_UNROLL = 8;
+    // every candidate window is full (c = t+1 > lo+31) and the output gate t >= maxp-1 is open; candidates beyond `hi` or longer
+    // than the series carry garbage here that is never selected (pi is clamped into [minp, maxp] = [lo, hi])
+    static constexpr bool HAS_FAST = true;
+    static constexpr bool FAST_BATCH = true;
+    __device__ bool steady(int64_t t0) const { return t0 >= lo + 32 && t0 >= maxp - 1 && lo > 0; }
+    __device__ void step_fast(int64_t t, const double (&x)[2], double (&y)[1]) { step_lds(t, x, y); }
+    // Eight rows at a time (see MavpSma16Op::steps_fast): half H's candidate P = lo+16H+u subtracts x[t+r-P] at row t+r, i.e. the 23
+    // values X[i] = x[t - lo - 16H - 15 + i], i = r - u + 15.
+    template <int H>
+    __device__ __forceinline__ void half(const double (&v)[8], const int (&pi)[8], double (&sum)[16], double (&asel)[8]) {
+        double X[23];
+        int k = w.pos - (23 + lo + 16 * H); // X[i] was pushed (23 + lo + 16H - i) pushes ago (the newest is v[7])
+        k += (k < 0) ? w.depth : 0;
+#pragma unroll
+        for (int i = 0; i < 23; i++) {
+            X[i] = w.base[k * 64];
+            k = (k + 1 == w.depth) ? 0 : k + 1;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) // row-major: sixteen independent chains advance together
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                sum[u] = (sum[u] + v[r]) - X[r - u + 15];
+                asel[r] = (lo + 16 * H + u == pi[r]) ? sum[u] : asel[r];
+            }
+    }
+    template <int N>
+    __device__ void steps_fast(int64_t, const double (&x)[N][2], double (&y)[N][1]) {
+        static_assert(N == 8, "MavpSma32Op::steps_fast is written for batches of eight rows");
+        double v[8], asel[8];
+        int pi[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            v[r] = n0(x[r][0]);
+            const int64_t p64 = (int64_t)n0(x[r][1]);
+            pi[r] = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
+            asel[r] = 0.0;
+        }
+        w.push_n<8>(v);
+        if (hi >= lo + 16) { // wave-uniform: the upper half exists
+            double sB[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) sB[u] = sb[u * 64];
+            half<1>(v, pi, sB, asel);
+#pragma unroll
+            for (int u = 0; u < 16; u++) sb[u * 64] = sB[u];
+        }
+        half<0>(v, pi, s, asel);
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r][0] = (n >= pi[r]) ? asel[r] * tab[pi[r] - lo] : pq_null();
+    }
+};
+
 // MAVP for the single-core MA types (SMA: matype 0/7/other, EMA: matype 1): a job advances up to EIGHT candidate
 // periods [lo, hi] together from one shared input ring (their running states live in an LDS array [period][lane]) and
 // writes the rows whose clamped period falls in its range.  Same arithmetic per period as MavpSelOp<SmaOp/EmaOp>; the

@@ -123,6 +123,16 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     rec_set_shared_out(ctx, true); // the jobs write disjoint rows of `out`
     pq_status st = PQ_OK;
     bool blocked = false;
+    const bool sma_core = matype != 1 && matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8;
+    if (sma_core && maxp - minp < 32 && maxp < (1 << 30)) { // every candidate in ONE job: an ordinary (unmasked) output column
+        MavpSma32Op op{}; op.lo = (int)minp; op.hi = (int)maxp; op.minp = (int)minp; op.maxp = (int)maxp;
+        InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
+        if (seq_can_lds(b, op, in, o1)) {
+            rec_set_shared_out(ctx, false);
+            PQ_TRY(launch_seq(ctx, b, op, in, o1));
+            return scope.finish();
+        }
+    }
     if (matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8 && maxp < (1 << 30)) {
         // SMA: sixteen candidate periods per job (states in registers); EMA: eight (states in LDS).  Two passes: decide
         // first whether EVERY block fits the tiled body -- nothing may be recorded before that is known, or the rows of `out`

@@ -102,7 +102,7 @@ struct pq_suite {
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op)                                          \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #define SEQ_OPS_HEAVY(X)                                                                                             \

@@ -119,6 +119,11 @@ PARAM_CASES = [
     ("midprice", dict(timeperiod=2)), ("midprice", dict(timeperiod=30)),
     ("mama", dict(fastlimit=0.5, slowlimit=0.05)),
     ("mavp", dict(minperiod=2, maxperiod=12, matype=1)), ("mavp", dict(minperiod=3, maxperiod=9, matype=2)),
+    ("mavp", dict(minperiod=5, maxperiod=20, matype=0)),   # one 32-candidate job, lower half only
+    ("mavp", dict(minperiod=0, maxperiod=31, matype=0)),   # all 32 candidates, candidate 0 (-> null rows)
+    ("mavp", dict(minperiod=7, maxperiod=38, matype=7)),   # 32 candidates from an odd start
+    ("mavp", dict(minperiod=2, maxperiod=45, matype=0)),   # 44 candidates: three masked 16-candidate jobs share the column
+    ("mavp", dict(minperiod=290, maxperiod=310, matype=0)),  # windows longer than the (short) series
     ("sar", dict(acceleration=0.02, maximum=0.2)), ("sar", dict(acceleration=0.3, maximum=0.2)),
     ("sarext", dict(startvalue=0.0, offsetonreverse=0.01, accelerationinitlong=0.02, accelerationlong=0.02,
                     accelerationmaxlong=0.2, accelerationinitshort=0.03, accelerationshort=0.03, accelerationmaxshort=0.3)),
