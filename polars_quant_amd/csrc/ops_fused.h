@@ -8,22 +8,98 @@
 #include "ops_momentum.h"
 #include "ops_overlap.h"
 
-// calc_ma (overlap.rs:857-869) restricted to the types that are a single core: SMA (0, 7, default) and EMA (1)
+// calc_ma (overlap.rs:857-869) restricted to the types that are a single core: SMA (0, 7, default) and EMA (1).  One state for both
+// kinds (the kind is a run-time parameter, so two separate cores would both stay live in registers): `acc` is the SMA's running sum,
+// or the EMA's seed sum and, from the seed row on, the average itself; every operation and its order are SmaCore's / EmaCore's
+// (pq_cores.h; overlap.rs:871-937 / :660-730).
 struct Ma2 {
-    int kind;
-    SmaCore s;
-    EmaCore e;
+    int kind; // 0 SMA, 1 EMA
+    int dead;
+    int64_t p, count;
+    double k;   // SMA: 1/p ; EMA: alpha = 2/(p+1)
+    double acc;
     Ring w;
     __host__ __device__ static bool supports(int64_t matype) { return !(matype >= 2 && matype <= 6) && matype != 8; }
     __host__ __device__ static int64_t slots(int64_t matype, int64_t p) { return matype == 1 ? 0 : (p > 0 ? p : 1); }
-    __device__ void init(int64_t matype, int64_t p, int64_t n, RingAlloc &ra) {
-        kind = matype == 1 ? 1 : 0;
-        if (kind) e.init(p, n);
-        else { s.init(p, n); w = ra.make(p); }
+    __device__ __forceinline__ void init_core(int kind_, int64_t p_, int64_t n) {
+        kind = kind_;
+        p = p_;
+        dead = (p <= 0 || n < p) ? 1 : 0;
+        k = pq_uniform(kind ? 2.0 / ((double)p + 1.0) : 1.0 / (double)p);
+        count = 0;
+        acc = 0.0;
     }
-    __device__ double step(double v) { return kind ? e.step(v) : s.step_ring(w, v); }
-    __device__ bool steady() const { return kind ? e.steady() : s.steady(); }
-    __device__ double fast(double v) { return kind ? e.fast(v) : s.fast_ring(w, v); }
+    __device__ __forceinline__ void init(int64_t matype, int64_t p_, int64_t n, RingAlloc &ra) {
+        init_core(matype == 1 ? 1 : 0, p_, n);
+        if (!kind) w = ra.make(p_);
+    }
+    __device__ __forceinline__ bool steady() const { return !dead && count >= p; } // SMA: full window (count stays at p); EMA: seeded
+    // SMA with the expiring value supplied by the caller (`old` = the valid value pushed p pushes ago)
+    __device__ __forceinline__ double step_old(double v, double old) {
+        if (wave_all(!dead && count >= p && !pq_isnull(v))) { // full window on the whole wave
+            acc += v;
+            acc -= old;
+            return acc * k;
+        }
+        if (dead || pq_isnull(v)) return pq_null();
+        count += 1;
+        acc += v;
+        if (count < p) return pq_null();
+        if (count > p) {
+            acc -= old;
+            count -= 1;
+        }
+        return acc * k;
+    }
+    __device__ __forceinline__ double fast_old(double v, double old) {
+        acc += v;
+        acc -= old;
+        return acc * k;
+    }
+    __device__ __forceinline__ double step(double v) {
+        if (!kind) { // the ring holds the last p valid values: the popped value is ring.swap(v)
+            if (wave_all(!dead && count >= p && !pq_isnull(v))) {
+                acc += v;
+                acc -= w.swap(v);
+                return acc * k;
+            }
+            if (dead || pq_isnull(v)) return pq_null();
+            count += 1;
+            acc += v;
+            const double old = w.swap(v);
+            if (count < p) return pq_null();
+            if (count > p) {
+                acc -= old;
+                count -= 1;
+            }
+            return acc * k;
+        }
+        if (wave_all(!dead && count >= p && !pq_isnull(v))) { // seeded on the whole wave
+            acc = fma(k, v - acc, acc);
+            return acc;
+        }
+        if (dead || pq_isnull(v)) return pq_null();
+        count += 1;
+        if (count < p) {
+            acc += v;
+            return pq_null();
+        } else if (count == p) {
+            acc += v;
+            acc = acc / (double)p;
+            return acc;
+        }
+        acc = fma(k, v - acc, acc);
+        return acc;
+    }
+    __device__ __forceinline__ double fast(double v) {
+        if (!kind) {
+            acc += v;
+            acc -= w.swap(v);
+            return acc * k;
+        }
+        acc = fma(k, v - acc, acc);
+        return acc;
+    }
 };
 
 // Two moving averages of the SAME input: when both are SMAs they share one ring (depth = the longer period; the shorter
@@ -37,31 +113,33 @@ struct Ma2Pair {
         if (mta != 1 && mtb != 1) { int64_t m = pa_ > pb_ ? pa_ : pb_; return m > 0 ? m : 1; }
         return Ma2::slots(mta, pa_) + Ma2::slots(mtb, pb_);
     }
-    __device__ void init(int64_t mta, int64_t pa_, int64_t mtb, int64_t pb_, int64_t n, RingAlloc &ra) {
+    __device__ __forceinline__ void init(int64_t mta, int64_t pa_, int64_t mtb, int64_t pb_, int64_t n, RingAlloc &ra) {
         shared = (mta != 1 && mtb != 1);
         if (shared) {
-            a.kind = b.kind = 0;
-            a.s.init(pa_, n); b.s.init(pb_, n);
+            a.init_core(0, pa_, n); b.init_core(0, pb_, n);
             pa = (int)(pa_ > 0 ? pa_ : 1); pb = (int)(pb_ > 0 ? pb_ : 1);
             w = ra.make(pa_ > pb_ ? pa_ : pb_);
+            // keeps this store where it is: merged with the store of b's own ring below (one store to a run-time offset inside the
+            // op) it would pin the whole op struct to scratch memory instead of registers
+            asm volatile("" ::: "memory");
         } else {
             a.init(mta, pa_, n, ra); b.init(mtb, pb_, n, ra);
         }
     }
-    __device__ void step(double v, double &ya, double &yb) {
+    __device__ __forceinline__ void step(double v, double &ya, double &yb) {
         if (!shared) { ya = a.step(v); yb = b.step(v); return; }
         if (pq_isnull(v)) { ya = yb = pq_null(); return; }
         const double oa = w.get(pa), ob = w.get(pb);
-        ya = a.s.step_old(v, oa);
-        yb = b.s.step_old(v, ob);
+        ya = a.step_old(v, oa);
+        yb = b.step_old(v, ob);
         w.push(v);
     }
-    __device__ bool steady() const { return shared ? (a.s.steady() && b.s.steady()) : (a.steady() && b.steady()); }
-    __device__ void fast(double v, double &ya, double &yb) {
+    __device__ __forceinline__ bool steady() const { return a.steady() && b.steady(); }
+    __device__ __forceinline__ void fast(double v, double &ya, double &yb) {
         if (!shared) { ya = a.fast(v); yb = b.fast(v); return; }
         const double oa = w.get(pa), ob = w.get(pb);
-        ya = a.s.fast_old(v, oa);
-        yb = b.s.fast_old(v, ob);
+        ya = a.fast_old(v, oa);
+        yb = b.fast_old(v, ob);
         w.push(v);
     }
 };
@@ -122,12 +200,12 @@ struct MacdextOp {
     Ma2Pair fs;
     Ma2 g;
     __host__ __device__ int64_t ring_slots() const { return Ma2Pair::slots(fastmt, fast, slowmt, slow) + Ma2::slots(sigmt, sig); }
-    __device__ void init(const Row<1> &) {}
-    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) {
+    __device__ __forceinline__ void init(const Row<1> &) {}
+    __device__ __forceinline__ void init_lds(const Row<1> &r, RingAlloc &ra) {
         fs.init(fastmt, fast, slowmt, slow, r.len, ra); g.init(sigmt, sig, r.len, ra);
     }
-    __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[3]) { y[0] = y[1] = y[2] = pq_null(); }
-    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[3]) {
+    __device__ __forceinline__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[3]) { y[0] = y[1] = y[2] = pq_null(); }
+    __device__ __forceinline__ void step_lds(int64_t, const double (&x)[1], double (&y)[3]) {
         double a, b;
         fs.step(x[0], a, b);
         double m = (pq_isnull(a) || pq_isnull(b)) ? pq_null() : a - b;
@@ -136,8 +214,8 @@ struct MacdextOp {
         y[2] = (pq_isnull(m) || pq_isnull(d)) ? pq_null() : m - d;
     }
     static constexpr bool HAS_FAST = true;
-    __device__ bool steady(int64_t) const { return fs.steady() && g.steady(); }
-    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
+    __device__ __forceinline__ bool steady(int64_t) const { return fs.steady() && g.steady(); }
+    __device__ __forceinline__ void step_fast(int64_t, const double (&x)[1], double (&y)[3]) {
         double a, b;
         fs.fast(x[0], a, b);
         const double m = a - b;
@@ -648,12 +726,12 @@ struct MavpSma32Op {
     double *sb;        // parked sums of the candidates lo+16 .. lo+31, lane-offset: sb[u * 64]
     const double *tab; // 1/P for P = lo .. lo+31 (shared by the wave)
     double s[16];
-    // ring: the batched fast path pushes eight rows first and then reads x[t-lo-31 .. t+7-lo] (the oldest was pushed lo + 39 pushes ago)
-    __host__ __device__ int64_t ring_slots() const { return (lo > 0 ? lo : 1) + 39 + 16 + 1; }
+    // ring: the batched fast path pushes four rows first and then reads x[t-lo-31 .. t+3-lo] (the oldest was pushed lo + 35 pushes ago)
+    __host__ __device__ int64_t ring_slots() const { return (lo > 0 ? lo : 1) + 35 + 16 + 1; }
     __device__ void init(const Row<2> &) {}
     __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
         n = (int)(r.len < 0x7fffffff ? r.len : 0x7fffffff);
-        w = ra.make((lo > 0 ? lo : 1) + 39);
+        w = ra.make((lo > 0 ? lo : 1) + 35);
         Ring park = ra.make(16);
         sb = park.base;
         double *t = ra.make_shared(32);
@@ -681,8 +759,8 @@ struct MavpSma32Op {
                 const int P = lo + 8 * g + u;
                 double a = (g < 2 ? s[(8 * g + u) & 15] : sb[(8 * (g - 2) + u) * 64]) + v;
                 const double b = a - old[u];
-                a = (c > P) ? b : a; // wave-uniform condition
-                a = (P <= hi && P > 0 && n >= P) ? a : 0.0;
+                a = (c > P) ? b : a; // wave-uniform condition.  (A candidate beyond `hi`, of period 0 or longer than the series carries
+                                     // garbage: never selected -- pi is clamped into [lo, hi] and `ok` tests pi > 0 and n >= pi.)
                 if (g < 2) s[(8 * g + u) & 15] = a; else sb[(8 * (g - 2) + u) * 64] = a;
                 asel = (P == pi) ? a : asel;
             }
@@ -692,46 +770,60 @@ struct MavpSma32Op {
         y[0] = ok ? asel * tab[pi - lo] : pq_null();
     }
     static constexpr bool FAST_NULL_OK = true; // N-0: nulls become 0.0 in the row body
-    static constexpr int FAST_UNROLL = 8;
+    static constexpr int FAST_UNROLL = 4;
     // every candidate window is full (c = t+1 > lo+31) and the output gate t >= maxp-1 is open; candidates beyond `hi` or longer
     // than the series carry garbage here that is never selected (pi is clamped into [minp, maxp] = [lo, hi])
     static constexpr bool HAS_FAST = true;
     static constexpr bool FAST_BATCH = true;
     __device__ bool steady(int64_t t0) const { return t0 >= lo + 32 && t0 >= maxp - 1 && lo > 0; }
     __device__ void step_fast(int64_t t, const double (&x)[2], double (&y)[1]) { step_lds(t, x, y); }
-    // Eight rows at a time (see MavpSma16Op::steps_fast): half H's candidate P = lo+16H+u subtracts x[t+r-P] at row t+r, i.e. the 23
-    // values X[i] = x[t - lo - 16H - 15 + i], i = r - u + 15.
+    // Four rows at a time (see MavpSma16Op::steps_fast for the scheme): half H's candidate P = lo+16H+u subtracts x[t+r-P] at row
+    // t+r, i.e. rows r = 0..3 touch the 19 values X[i] = x[t - lo - 16H - 15 + i], i = r - u + 15.  (Four rows instead of eight: 19
+    // window values, 4 selections and 4 staged input rows live instead of 23, 8 and 8 -- the op fits the 192-VGPR job kernel.)
     template <int H>
-    __device__ __forceinline__ void half(const double (&v)[8], const int (&pi)[8], double (&sum)[16], double (&asel)[8]) {
-        double X[23];
-        int k = w.pos - (23 + lo + 16 * H); // X[i] was pushed (23 + lo + 16H - i) pushes ago (the newest is v[7])
+    __device__ __forceinline__ void half(const double (&v)[4], const int (&pi)[4], double (&sum)[16], double (&asel)[4]) {
+        double X[19];
+        int k = w.pos - (19 + lo + 16 * H); // X[i] was pushed (19 + lo + 16H - i) pushes ago (the newest is v[3])
         k += (k < 0) ? w.depth : 0;
 #pragma unroll
-        for (int i = 0; i < 23; i++) {
+        for (int i = 0; i < 19; i++) {
             X[i] = w.base[k * 64];
             k = (k + 1 == w.depth) ? 0 : k + 1;
         }
+        int d[4]; // the row's candidate index within this half (outside 0..15: the other half has it)
 #pragma unroll
-        for (int r = 0; r < 8; r++) // row-major: sixteen independent chains advance together
+        for (int r = 0; r < 4; r++) d[r] = pi[r] - (lo + 16 * H);
+#pragma unroll
+        for (int r = 0; r < 4; r++) // row-major: sixteen independent chains advance together
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 sum[u] = (sum[u] + v[r]) - X[r - u + 15];
-                asel[r] = (lo + 16 * H + u == pi[r]) ? sum[u] : asel[r];
+                sel_eq(asel[r], u, d[r], sum[u]);
             }
+    }
+    // dst = (d == U) ? src : dst with the compare in VCC, consumed at once.  Written as `cond ? a : b` the 64 compares of a batch are
+    // scheduled ahead of their selects and their lane masks (an SGPR pair each) no longer fit the scalar file: 233 of them were
+    // spilled to VGPR lanes and read back one by one.
+    __device__ static __forceinline__ void sel_eq(double &dst, int U, int d, double src) {
+        int dl = __double2loint(dst), dh = __double2hiint(dst);
+        const int sl = __double2loint(src), sh = __double2hiint(src);
+        asm("v_cmp_eq_u32 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc"
+            : "+v"(dl), "+v"(dh) : "n"(U), "v"(d), "v"(sl), "v"(sh) : "vcc");
+        dst = __hiloint2double(dh, dl);
     }
     template <int N>
     __device__ void steps_fast(int64_t, const double (&x)[N][2], double (&y)[N][1]) {
-        static_assert(N == 8, "MavpSma32Op::steps_fast is written for batches of eight rows");
-        double v[8], asel[8];
-        int pi[8];
+        static_assert(N == 4, "MavpSma32Op::steps_fast is written for batches of four rows");
+        double v[4], asel[4];
+        int pi[4];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < 4; r++) {
             v[r] = n0(x[r][0]);
             const int64_t p64 = (int64_t)n0(x[r][1]);
             pi[r] = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
             asel[r] = 0.0;
         }
-        w.push_n<8>(v);
+        w.push_n<4>(v);
         if (hi >= lo + 16) { // wave-uniform: the upper half exists
             double sB[16];
 #pragma unroll
@@ -742,7 +834,7 @@ struct MavpSma32Op {
         }
         half<0>(v, pi, s, asel);
 #pragma unroll
-        for (int r = 0; r < 8; r++) y[r][0] = (n >= pi[r]) ? asel[r] * tab[pi[r] - lo] : pq_null();
+        for (int r = 0; r < 4; r++) y[r][0] = (n >= pi[r]) ? asel[r] * tab[pi[r] - lo] : pq_null();
     }
 };
 

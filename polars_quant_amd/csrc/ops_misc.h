@@ -144,7 +144,7 @@ struct HtOp {
     static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
     static constexpr int SEQ_ID = 45 + MODE;
     static constexpr int COST_NS = 880;
-    static constexpr bool HEAVY = MODE != 2; // ~230 live VGPRs (four 7-deep delay lines); the phasor form fits the light kernel
+    static constexpr bool HEAVY = true; // ~230 live VGPRs (four 7-deep delay lines); the phasor form (212) does not fit the 192 of the light kernel either
     double fastlimit, slowlimit; // MODE 4
     double rl[4];                // real[i], real[i-1], real[i-2], real[i-3]
     double sm[7];                // smooth[i] ... smooth[i-6]

@@ -6,6 +6,12 @@
 // true when the condition holds on every active lane: lets a state machine take its steady-state path without any
 // per-lane branching (the warm-up / null paths below stay the general case)
 __device__ __forceinline__ bool wave_all(bool x) { return __builtin_amdgcn_ballot_w64(x) == __builtin_amdgcn_ballot_w64(true); }
+// A constant derived from a wave-uniform parameter (2/(p+1), 1/p, (double)p ...) is computed by the vector ALU -- there is no scalar
+// f64 unit -- and would occupy a VGPR pair for the whole walk; moved to scalar registers it costs none (same bits in every lane).
+__device__ __forceinline__ double pq_uniform(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 
 // overlap.rs:660-730 calc_ema: null-transparent (N-A), SMA seed at count == p, then
 // alpha.mul_add(x - ema, ema).
@@ -16,7 +22,7 @@ struct EmaCore {
     __device__ void init(int64_t p_, int64_t n) {
         p = p_;
         dead = (p <= 0 || n < p);
-        alpha = 2.0 / ((double)p + 1.0);
+        alpha = pq_uniform(2.0 / ((double)p + 1.0));
         count = 0;
         ema = 0.0;
         sum = 0.0;
@@ -82,7 +88,7 @@ struct SmaCore {
     __device__ void init(int64_t p_, int64_t n) {
         p = p_;
         dead = (p <= 0 || n < p);
-        denom = 1.0 / (double)p;
+        denom = pq_uniform(1.0 / (double)p);
         count = 0;
         sum = 0.0;
         reg.init();
@@ -173,8 +179,8 @@ struct RmaCore {
         dead = (p <= 0 || n < p);
         sum = 0.0;
         r = 0.0;
-        pm1 = (double)p - 1.0;
-        pf = (double)p;
+        pm1 = pq_uniform((double)p - 1.0);
+        pf = pq_uniform((double)p);
     }
     __device__ double step(int64_t i, double x) {
         if (wave_all(!dead && i >= p)) { // steady state on the whole wave

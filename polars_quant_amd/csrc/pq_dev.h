@@ -161,8 +161,11 @@ __device__ __forceinline__ void fast_rows(Op &op, int64_t t, const double (&x)[N
 // keeps a speculatively computed value where it is: without it the compiler turns `cond ? expensive : other` into a branch
 // around the expensive part (a division), which splits the straight-line fast path into basic blocks
 __device__ __forceinline__ double pq_keep(double v) { asm volatile("" : "+v"(v)); return v; }
+#ifndef PQ_FU_DEFAULT
+#define PQ_FU_DEFAULT 2
+#endif
 template <class Op, class = void>
-struct FastUnroll { static constexpr int value = 2; };      // rows per unrolled fast-loop iteration
+struct FastUnroll { static constexpr int value = PQ_FU_DEFAULT; };      // rows per unrolled fast-loop iteration
 template <class Op>
 struct FastUnroll<Op, decltype((void)Op::FAST_UNROLL)> { static constexpr int value = Op::FAST_UNROLL; };
 
@@ -452,15 +455,18 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t T = d.len, nt = T / K;
     const int csym = lane / CPL, cchunk = lane % CPL;
-    int64_t crow[NI]; // global row offsets of the series this lane helps to move
-#pragma unroll
-    for (int i = 0; i < NI; i++) {
-        int64_t cs = tile_s0 + i * SPI + csym;
-        crow[i] = (cs < d.n ? cs : d.n - 1) * d.stride + cchunk * 2;
-    }
-    unsigned char *co_row[NI];
-#pragma unroll
-    for (int i = 0; i < NI; i++) co_row[i] = lds + (i * SPI + csym) * ROWB + cchunk * 16;
+    // global row offset of the i-th series this lane helps to move (dead series of the last tile shadow the last live one).  Computed
+    // at every use from one 32-bit register: four 64-bit offsets held across the row loop were the first values the register
+    // allocator spilled under the job kernel's 192-VGPR cap, and three integer instructions per 16-byte access are noise.
+    const int64_t tile_left = d.n - 1 - tile_s0;                         // wave-uniform: index of the last live series within the tile
+    const unsigned rel_max = tile_left < 63 ? (tile_left > 0 ? (unsigned)tile_left : 0u) : 63u;
+    const int64_t tile_base = tile_s0 * d.stride;                        // wave-uniform
+    auto crow = [&](int i) -> int64_t {
+        const unsigned rel = (unsigned)(csym + i * SPI);
+        return tile_base + (int64_t)(rel < rel_max ? rel : rel_max) * d.stride + cchunk * 2;
+    };
+    unsigned char *const co_base = lds + csym * ROWB + cchunk * 16; // this lane's 16-byte slot of a cooperative tile access; access i adds
+    auto co_row = [&](int i) -> unsigned char * { return co_base + i * (SPI * ROWB); }; // a compile-time offset (the DS offset field)
 
     PQ_PROF_SIMD(wave);
     // hand-off of a finished out tile to the storer wave.  (Measured alternative: one-wave workgroups in which the compute
@@ -517,7 +523,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             for (int k = 0; k < R; k++)
 #pragma unroll
                                 for (int i = 0; i < NI; i++) {
-                                    const double *q = reinterpret_cast<const double *>(co_row[i] + (W + k) * TB);
+                                    const double *q = reinterpret_cast<const double *>(co_row(i) + (W + k) * TB);
                                     v[k][i] = make_double2(q[0], q[1]);
                                 }
                             lds_fence();
@@ -527,7 +533,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             for (int k = 0; k < R; k++)
 #pragma unroll
                                 for (int i = 0; i < NI; i++)
-                                    if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[W + k] + crow[i] + t0, v[k][i]);
+                                    if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[W + k] + crow(i) + t0, v[k][i]);
                         }
                     }
                     const bool mine = it + 1 < nt || half == 0; // an odd tile count leaves the last tile alone
@@ -553,7 +559,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                         for (int k = 0; k < NOUT; k++)
 #pragma unroll
                             for (int i = 0; i < NI; i++) { // two b64 reads: LDS rows are only 8-byte aligned
-                                const double *q = reinterpret_cast<const double *>(co_row[i] + k * TB);
+                                const double *q = reinterpret_cast<const double *>(co_row(i) + k * TB);
                                 v[a][k][i] = make_double2(q[0], q[1]);
                             }
                         lds_fence();
@@ -567,7 +573,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     for (int i = 0; i < NI; i++)
 #pragma unroll
                         for (int a = 0; a < ACC; a++)
-                            if (it + a < nt && tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow[i] + t0 + a * K, v[a][k][i]);
+                            if (it + a < nt && tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow(i) + t0 + a * K, v[a][k][i]);
             }
             }
             if constexpr (HasFinish<Op>::value) { // the epilogue of wave 0 reads what this wave stored
@@ -600,7 +606,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
-            for (int i = 0; i < NI; i++) buf[k][i] = PQ_HOOK_TILE_LOAD(inp[k] + crow[i] + t0, t0, i);
+            for (int i = 0; i < NI; i++) buf[k][i] = PQ_HOOK_TILE_LOAD(inp[k] + crow(i) + t0, t0, i);
     };
     auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
@@ -610,7 +616,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         for (int k = 0; k < NIN; k++)
 #pragma unroll
             for (int i = 0; i < NI; i++) { // two b64 stores: LDS rows are only 8-byte aligned
-                double *q = reinterpret_cast<double *>(co_row[i] + k * TB);
+                double *q = reinterpret_cast<double *>(co_row(i) + k * TB);
                 q[0] = buf[k][i].x;
                 q[1] = buf[k][i].y;
                 if constexpr (HasFast<Op>::value && !FastNullOk<Op>::value)
@@ -692,16 +698,20 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         for (int f = 0; f < PF; f++)
             if (it + f < nt) do_tile(pre[f], it + f);
     }
-    if (live) { // ragged tail: fewer than K rows left
+    // ragged tail: fewer than K rows left.  The series index and its row offset are formed again here (from the lane id as the
+    // hardware counts it, which the compiler cannot tie to the value used above) rather than kept -- or spilled -- across the row loop.
+    const int64_t s_tail = tile_s0 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (s_tail < d.n) {
+        const int64_t row_tail = s_tail * d.stride;
         for (int64_t t = nt * K; t < T; t++) {
             double x[NIN], y[NOUT];
 #pragma unroll
-            for (int k = 0; k < NIN; k++) x[k] = r.in[k][t];
+            for (int k = 0; k < NIN; k++) x[k] = inp[k][row_tail + t];
             if constexpr (HasRings<Op>::value) op.step_lds(t, x, y);
             else op.step(r, t, x, y);
 #pragma unroll
             for (int k = 0; k < NOUT; k++)
-                if (!MASKED || !pq_isskip(y[k])) outp[k][s * d.stride + t] = y[k];
+                if (!MASKED || !pq_isskip(y[k])) outp[k][row_tail + t] = y[k];
         }
     }
     if constexpr (HasFinish<Op>::value) {
@@ -724,6 +734,9 @@ static inline bool seq_cols_aligned(const pq_batch *b, const double *const *in, 
 template <class Op, bool LDS>
 #ifndef PQ_SEQ_MIN_WAVES
 #define PQ_SEQ_MIN_WAVES 1 // analysis builds: 3 = compile every stand-alone op kernel under the light job kernel's register cap
+#endif
+#ifdef PQ_SEQ_NUM_VGPR // analysis builds: the register cap of the light job kernel (the attribute counts pairs: 96 = 192 VGPRs)
+__attribute__((amdgpu_num_vgpr(PQ_SEQ_NUM_VGPR)))
 #endif
 __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK, PQ_SEQ_MIN_WAVES) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
     if constexpr (LDS) {

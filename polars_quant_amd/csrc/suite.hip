@@ -103,13 +103,16 @@ struct pq_suite {
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<1>) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<2>) X(BtMacdOp) X(LevOp)                                     \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
+#ifdef PQ_ANALYZE_LIGHT // analysis builds (never linked): the light job kernel with a subset of its ops, -D'PQ_ANALYZE_LIGHT=X(EmaAllOp)'
+#undef SEQ_OPS_LIGHT
+#define SEQ_OPS_LIGHT(X) PQ_ANALYZE_LIGHT
+#endif
 #define SEQ_OPS_HEAVY(X)                                                                                             \
-    X(HtOp<0>) X(HtOp<1>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
-// V = 0: LDS bodies of the light ops (4 waves/SIMD), 1: LDS bodies of the heavy ops, 2: gather bodies of every op + the
-// backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
-template <int V>
+    X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(StochOp<0>) X(StochAllOp)
+// V = 0: LDS bodies of the light ops (2 waves/SIMD, capped at 192 VGPRs: PQ_NV0 below), 1: LDS bodies of the heavy ops, 2: gather
+// bodies of every op + the backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
 #ifndef PQ_LB0
 // waves per SIMD the light kernel is compiled for.  2 (round 3): 221 VGPRs, ScratchSize 0.  At 3 (168 VGPRs) the three widest jobs
 // (EMA x 4, the volume family, the DM system) spilled 359 registers / 272 B of scratch per lane; LDS already holds a CU to four
@@ -117,7 +120,8 @@ template <int V>
 // 4.05 -> 3.5 ms, HEAVY 4.25 -> 3.7 ms, step -1.2 % (the ROW chain is then the longest).  Table: profiles/r03_kernel_resources.txt
 #define PQ_LB0 2
 #endif
-__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+template <int V>
+__device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];
     const SeqJob &job = jobs[blockIdx.y];
     if (dbg && threadIdx.x == 0) atomicMin(&dbg[2 * blockIdx.y], wall_clock64()); // PQ_SUITE_DEBUG: first start / last end per job
@@ -178,6 +182,23 @@ __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
+template <int V>
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+    seq_jobs_body<V>(jobs, d, dbg, wg);
+}
+// Register cap of the light kernel: 192 VGPRs (`amdgpu_num_vgpr` counts register PAIRS on gfx950: 96).  Two job waves then leave 128
+// of a SIMD's 512 registers free, which is what one wave of the pattern kernel (118) or of the wave-per-symbol backtest (122) needs:
+// at the uncapped 199 (200 allocated) neither fits beside two job waves and the pattern kernel -- the last chain of a step to finish --
+// only advances where a job workgroup has retired.  A/B in one session: 4.60 -> 4.53 ms per step.  PQ_NV0=0: no cap.
+#ifndef PQ_NV0
+#define PQ_NV0 96
+#endif
+#if PQ_NV0 > 0
+template <>
+__global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_LDS_BLOCK, PQ_LB0) void seq_jobs_kernel<0>(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+    seq_jobs_body<0>(jobs, d, dbg, wg);
+}
+#endif
 
 static int phase_for(Recorder &r, const void *const *reads, int nr, void *const *writes, int nw) {
     int ph = 0;
