@@ -269,7 +269,7 @@ struct StochOp {
     static constexpr int NIN = 3, NOUT = 2; // high, low, close
     static constexpr int SEQ_ID = 74 + MODE;
     static constexpr int COST_NS = MODE == 0 ? 637 : 579;
-    static constexpr bool HEAVY = MODE == 0; // three MA cores behind the rolling extrema: > 168 VGPRs
+    static constexpr bool HEAVY = false; // (STOCH's three MA cores behind the rolling extrema fit the light kernel's 192 VGPRs since Ma2 holds one overlaid state)
     int64_t fastk, p1, mt1, p2, mt2; // STOCH: slowk/slowd MA params; STOCHF: (p1, mt1) = fastd, second MA unused
     FastkCore fk;
     Ma2 m1, m2;
