@@ -143,6 +143,10 @@ PARAM_CASES = [
     ("ppo", dict(fastperiod=3, slowperiod=10, matype=1)),
     ("macdext", dict(fastperiod=4, fastmatype=1, slowperiod=9, slowmatype=2, signalperiod=3, signalmatype=0)),
     ("macdext", dict(fastperiod=4, fastmatype=5, slowperiod=9, slowmatype=4, signalperiod=3, signalmatype=1)),
+    # the single-core (SMA / EMA) path in every mix of kinds: shared SMA ring, own rings, EMA seeds
+    *[("macdext", dict(fastperiod=4, fastmatype=a, slowperiod=9, slowmatype=b, signalperiod=3, signalmatype=c))
+      for a, b, c in ((0, 0, 1), (1, 0, 1), (0, 1, 0), (1, 1, 1), (7, 1, 0))],
+    ("macdext", dict(fastperiod=9, fastmatype=0, slowperiod=4, slowmatype=0, signalperiod=1, signalmatype=1)),
     ("stoch", dict(fastk_period=7, slowk_period=4, slowk_matype=1, slowd_period=3, slowd_matype=2)),
     ("stochf", dict(fastk_period=9, fastd_period=5, fastd_matype=1)),
     ("stochrsi", dict(timeperiod=7, fastk_period=6, fastd_period=4, fastd_matype=0)),
@@ -724,6 +728,7 @@ def test_recorded_suite_nulls_and_parameters_on_the_tiled_bodies(pq, oracle):
              ("kama", dict(timeperiod=6)), ("trima", dict(timeperiod=9)), ("trima", dict(timeperiod=20)), ("midpoint", dict(timeperiod=5)),
              ("midprice", dict(timeperiod=9)), ("ma", dict(timeperiod=8, matype=1)), ("apo", dict(fastperiod=4, slowperiod=9, matype=0)),
              ("ppo", dict(fastperiod=4, slowperiod=9, matype=1)), ("macdext", dict(fastperiod=5, fastmatype=0, slowperiod=11, slowmatype=0, signalperiod=8, signalmatype=0)),
+             ("macdext", dict(fastperiod=5, fastmatype=1, slowperiod=11, slowmatype=0, signalperiod=4, signalmatype=1)),
              ("stoch", dict(fastk_period=6, slowk_period=3, slowk_matype=0, slowd_period=4, slowd_matype=1)),
              ("stochf", dict(fastk_period=4, fastd_period=3, fastd_matype=0)), ("atr", dict(timeperiod=6)), ("natr", dict(timeperiod=9)),
              ("ad", {}), ("adosc", dict(fastperiod=2, slowperiod=7)), ("obv", {}), ("sar", dict(acceleration=0.02, maximum=0.2)),
