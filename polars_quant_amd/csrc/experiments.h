@@ -10,6 +10,9 @@
 //   PQ_PROFILE_WAVES     s_memtime accounting of the compute wave per job kind (load wait + LDS fill, rows, hand-off), SIMD histogram
 //   PQ_STORER_ACC=2|4    the storer wave keeps 2 / 4 out tiles and stores them back to back
 //   PQ_PF2_MAX=<n>       a second tile of register prefetch for ops whose inputs need <= n VGPRs
+//   PQ_SEQ_NUM_VGPR=<n>  register cap (in PAIRS: 96 = 192 VGPRs) on every stand-alone op kernel: which ops spill under the job kernel's cap?
+//   PQ_ANALYZE_LIGHT=X(Op)...  (suite.hip) the light job kernel with a subset of its ops: per-op registers / spills INSIDE the job kernel
+//                        (scripts/kernel_resources.sh; such a build is never linked)
 #pragma once
 
 #if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_NOSTORE)
@@ -30,6 +33,7 @@
 #define PQ_PROF_SIMD(wave)
 #define PQ_STORER_ACC 1
 #define PQ_PF2_MAX 0
+#define PQ_HOOK_SEQ_KERNEL_ATTR
 #else
 // ---------------------------------------------------------------- scripts/ab_build.sh only
 #if defined(PQ_EXP_NOSTORE)
@@ -71,5 +75,10 @@ template <class Op> struct ProfId<Op, decltype((void)Op::SEQ_ID)> { static const
 #endif
 #ifndef PQ_PF2_MAX
 #define PQ_PF2_MAX 0
+#endif
+#ifdef PQ_SEQ_NUM_VGPR
+#define PQ_HOOK_SEQ_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(PQ_SEQ_NUM_VGPR)))
+#else
+#define PQ_HOOK_SEQ_KERNEL_ATTR
 #endif
 #endif

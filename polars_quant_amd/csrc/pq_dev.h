@@ -161,11 +161,8 @@ __device__ __forceinline__ void fast_rows(Op &op, int64_t t, const double (&x)[N
 // keeps a speculatively computed value where it is: without it the compiler turns `cond ? expensive : other` into a branch
 // around the expensive part (a division), which splits the straight-line fast path into basic blocks
 __device__ __forceinline__ double pq_keep(double v) { asm volatile("" : "+v"(v)); return v; }
-#ifndef PQ_FU_DEFAULT
-#define PQ_FU_DEFAULT 2
-#endif
 template <class Op, class = void>
-struct FastUnroll { static constexpr int value = PQ_FU_DEFAULT; };      // rows per unrolled fast-loop iteration
+struct FastUnroll { static constexpr int value = 2; };      // rows per unrolled fast-loop iteration
 template <class Op>
 struct FastUnroll<Op, decltype((void)Op::FAST_UNROLL)> { static constexpr int value = Op::FAST_UNROLL; };
 
@@ -735,10 +732,7 @@ template <class Op, bool LDS>
 #ifndef PQ_SEQ_MIN_WAVES
 #define PQ_SEQ_MIN_WAVES 1 // analysis builds: 3 = compile every stand-alone op kernel under the light job kernel's register cap
 #endif
-#ifdef PQ_SEQ_NUM_VGPR // analysis builds: the register cap of the light job kernel (the attribute counts pairs: 96 = 192 VGPRs)
-__attribute__((amdgpu_num_vgpr(PQ_SEQ_NUM_VGPR)))
-#endif
-__global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK, PQ_SEQ_MIN_WAVES) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
+PQ_HOOK_SEQ_KERNEL_ATTR __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK, PQ_SEQ_MIN_WAVES) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
     if constexpr (LDS) {
         extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
         run_seq_lds(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);

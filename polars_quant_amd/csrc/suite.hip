@@ -105,7 +105,7 @@ struct pq_suite {
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
-#ifdef PQ_ANALYZE_LIGHT // analysis builds (never linked): the light job kernel with a subset of its ops, -D'PQ_ANALYZE_LIGHT=X(EmaAllOp)'
+#if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
 #undef SEQ_OPS_LIGHT
 #define SEQ_OPS_LIGHT(X) PQ_ANALYZE_LIGHT
 #endif
