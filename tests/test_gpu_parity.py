@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 # aligned), the even ones the two-wave LDS-tiled body (run_seq_lds / seq_jobs_kernel<0>,<1>) that bench.py times -- with a
 # ragged last tile (304 = 38 x 8 = 19 x 16; 312 = 39 x 8 = 19.5 x 16: a 16-row tail for K = 16 ops) and 1 / 2 full + 1 partial
 # symbol tiles.  Every default / parameter / null case below runs on all three.
-SHAPES = [(70, 301), (70, 304), (130, 312)]
+SHAPES = [(70, 301), (70, 304), (130, 312), (66, 306)]  # odd pitch (gather body); tiled bodies: whole tiles, an 8-row tail of the 16-row tiles, a 2-row tail of every tile
 SEED = 0x5EED0002
 TRANSCENDENTAL = {"ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine", "mama"}
 RTOL = 1e-12                # north_star tolerance for f64 indicators
