@@ -307,7 +307,6 @@ struct StochAllOp {
     static constexpr int ALG_COLS = 5 + 5;  // stoch, stochf
     static constexpr int SEQ_ID = 96;
     static constexpr int COST_NS = 800;
-    static constexpr bool HEAVY = true;
     int64_t fastk, slowk, slowk_mt, slowd, slowd_mt, fastd, fastd_mt;
     FastkCore fk;
     Ma2 mk, md, mf;

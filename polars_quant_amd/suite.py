@@ -118,11 +118,11 @@ class Suite:
              "ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"),
              "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), 
              "dm_pair": ("plus_dm", "minus_dm"), "apo_ppo": ("apo", "ppo"),
-             "sar_pair": ("sar", "sarext"), "volume_all": ("mfi", "ad", "adosc", "obv")}
-    # pq_macd_pair is NOT used here either: six output tiles (27.6 KB) would raise the LDS charge of its whole grid, and on 4-row
-    # tiles it measured +3 % per step.
-    # pq_stoch_all (STOCH + STOCHF, 199 VGPRs -> the register-heavy kernel) is NOT used here: beside the Hilbert job it makes that
-    # chain the critical path (+6 % per step, measured); it pays when STOCH/STOCHF are asked for on their own
+             "sar_pair": ("sar", "sarext"), "volume_all": ("mfi", "ad", "adosc", "obv"),
+             "stoch_all": ("stoch", "stochf"), "macd_pair": ("macd", "macdfix")}
+    # pq_macd_pair (six output tiles, 27.6 KB) and pq_stoch_all (192 VGPRs since the moving-average cores were slimmed: it now runs in
+    # the light job kernel) joined the list in round 3: time-neutral within the noise of a session (4.34 against 4.35 ms per step), two
+    # jobs and four column reads fewer.  PQ_SUITE_UNFUSE=name,... keeps the listed ones as separate calls for A/B runs.
 
     def tasks(self, fused: bool = False):
         """every function of the suite; fused=True replaces the users of a shared core by the multi-output call"""
