@@ -269,7 +269,7 @@ def main():
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------------
     # The step's device time is dominated by seq_jobs_kernel<0>: the tiled bodies of all sequential jobs, two launches per
-    # step (one per LDS class) that run CONCURRENTLY with each other, with seq_jobs_kernel<1> (register-heavy jobs) and with
+    # step (one per LDS class) that run CONCURRENTLY with each other and with
     # the row-parallel kernels.  Each launch was bracketed by HIP events on its own launch stream during the timed steps
     # above (pq_suite_set_timing).  Contract figure: achieved = mean algorithmic bytes per launch / mean launch duration
     # (= what `rocprofv3 --kernel-trace --stats` reports as that kernel's average duration, profiles/).  Because the

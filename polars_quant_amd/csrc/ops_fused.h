@@ -527,22 +527,24 @@ struct HtAllOp {
     static constexpr int ALG_COLS = 2 + 3;  // ht_dcperiod, ht_phasor (ht_dcphase and ht_sine are credited to HtPhaseSineOp's launch)
     static constexpr int SEQ_ID = 79;
     static constexpr int COST_NS = 800;
-    static constexpr bool HEAVY = true;
     HtOp<0> core;
     __device__ void init(const Row<1> &r) { core.init(r); }
+    __host__ __device__ int64_t ring_slots() const { return core.ring_slots(); } // tiled body: the delay lines live in LDS rings (HtOp)
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { core.init_lds(r, ra); }
     static constexpr bool FAST_NULL_OK = true;
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t t0) const { return core.steady(t0); }
-    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[3]) { row<true>(i, x, y); }
-    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[3]) { row<false>(i, x, y); }
-    template <bool FAST>
+    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[3]) { row<true, true>(i, x, y); }
+    __device__ void step_lds(int64_t i, const double (&x)[1], double (&y)[3]) { row<false, true>(i, x, y); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[3]) { row<false, false>(i, x, y); }
+    template <bool FAST, bool RINGS>
     __device__ __forceinline__ void row(int64_t i, const double (&x)[1], double (&y)[3]) {
         double yp[1];
-        core.template row<FAST>(i, x, yp); // advances the pipeline, emits the smoothed period
+        core.template row<FAST, RINGS>(i, x, yp); // advances the pipeline, emits the smoothed period
         y[0] = yp[0];
         y[1] = y[2] = pq_null();
         if (!FAST && (core.dead || i < 31)) return;
-        y[1] = core.i1[0]; y[2] = core.q1[0];
+        y[1] = core.i1_0; y[2] = core.q1_0;
     }
 };
 // dcphase (cycle.rs:130-139), sine and leadsine (cycle.rs:294-300) from the phasor components of the same row.

@@ -144,11 +144,18 @@ struct HtOp {
     static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
     static constexpr int SEQ_ID = 45 + MODE;
     static constexpr int COST_NS = 880;
-    static constexpr bool HEAVY = true; // ~230 live VGPRs (four 7-deep delay lines); the phasor form (212) does not fit the 192 of the light kernel either
     double fastlimit, slowlimit; // MODE 4
     double rl[4];                // real[i], real[i-1], real[i-2], real[i-3]
+    // The delay lines of the pipeline.  Gather body: four 7-deep shift registers (56 VGPRs, 24 register moves per row).  Tiled body:
+    // three LDS rings ([slot][lane], zero-filled) -- smooth (6 deep), detrender (9 deep) and Q1 (6 deep); the I1 line is the
+    // detrender line three rows later (i1[k] = detrend[k + 3]: both are pushed on the same rows, from zeros), so it needs no storage
+    // of its own.  A tap `k rows back after this row's push` is read as `pushed k pushes ago` BEFORE the push, i.e. all thirteen taps
+    // of a row are old values whose LDS reads are issued at the top of the row, off the dependency chain.  Same values, same order
+    // of arithmetic; ~56 VGPRs less, which is what lets the Hilbert jobs run in the 192-VGPR light job kernel.
     double sm[7];                // smooth[i] ... smooth[i-6]
     double detrend[7], q1[7], i1[7];
+    Ring r_sm, r_dt, r_q1;
+    double i1_0, q1_0;           // this row's in-phase / quadrature components (either storage form)
     double i2, q2, re, im, period, smooth_period;
     double mama, fama, prev_phase;
     bool dead;
@@ -157,21 +164,33 @@ struct HtOp {
         for (int k = 6; k >= 1; k--) dq[k] = dq[k - 1];
         dq[0] = v;
     }
-    __device__ void init(const Row<1> &r) {
-        dead = r.len < 32; // cycle.rs:16
-#pragma unroll
-        for (int k = 0; k < 7; k++) sm[k] = detrend[k] = q1[k] = i1[k] = 0.0;
+    __device__ void init_scalars(int64_t len) {
+        dead = len < 32; // cycle.rs:16
 #pragma unroll
         for (int k = 0; k < 4; k++) rl[k] = 0.0;
         i2 = q2 = re = im = period = smooth_period = 0.0;
         mama = fama = prev_phase = 0.0;
+        i1_0 = q1_0 = 0.0;
+    }
+    __device__ void init(const Row<1> &r) {
+        init_scalars(r.len);
+#pragma unroll
+        for (int k = 0; k < 7; k++) sm[k] = detrend[k] = q1[k] = i1[k] = 0.0;
+    }
+    __host__ __device__ int64_t ring_slots() const { return 6 + 9 + 6; }
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) {
+        init_scalars(r.len);
+        r_sm = ra.make(6); r_dt = ra.make(9); r_q1 = ra.make(6);
+#pragma unroll
+        for (int k = 0; k < 9; k++) { if (k < 6) { r_sm.base[k * 64] = 0.0; r_q1.base[k * 64] = 0.0; } r_dt.base[k * 64] = 0.0; }
     }
     static constexpr bool FAST_NULL_OK = true; // N-B (MODE 4: N-0, nulls become 0.0 in the row body itself)
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t t0) const { return !dead && t0 >= 32; } // every warm-up test of the row body is past
-    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<true>(i, x, y); }
-    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<false>(i, x, y); }
-    template <bool FAST> // FAST: i >= 32 and !dead are known
+    __device__ void step_fast(int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<true, true>(i, x, y); }   // tiled body only
+    __device__ void step_lds(int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<false, true>(i, x, y); }
+    __device__ void step(const Row<1> &, int64_t i, const double (&x)[1], double (&y)[NOUT]) { row<false, false>(i, x, y); }
+    template <bool FAST, bool RINGS> // FAST: i >= 32 and !dead are known
     __device__ __forceinline__ void row(int64_t i, const double (&x)[1], double (&y)[NOUT]) {
 #pragma unroll
         for (int k = 0; k < NOUT; k++) y[k] = pq_null();
@@ -180,19 +199,31 @@ struct HtOp {
         rl[3] = rl[2]; rl[2] = rl[1]; rl[1] = rl[0]; rl[0] = v;
         // cycle.rs:462-470 calc_smooth (0 for i < 3)
         double s = (FAST || i >= 3) ? (4.0 * rl[0] + 3.0 * rl[1] + 2.0 * rl[2] + rl[3]) * 0.1 : 0.0;
-        push7(sm, s);
+        double sm2, sm4, sm6;
+        if constexpr (RINGS) { sm2 = r_sm.get(2); sm4 = r_sm.get(4); sm6 = r_sm.get(6); r_sm.push(s); }
+        else { push7(sm, s); sm2 = sm[2]; sm4 = sm[4]; sm6 = sm[6]; }
         if (!FAST && i < 6) return;
+        double d2, d4, d6, i1_2, i1_4, i1_6, q2t, q4t, q6t; // the taps of this row (after its pushes)
+        if constexpr (RINGS) {
+            d2 = r_dt.get(2); i1_0 = r_dt.get(3); d4 = r_dt.get(4); i1_2 = r_dt.get(5); d6 = r_dt.get(6); i1_4 = r_dt.get(7); i1_6 = r_dt.get(9);
+            q2t = r_q1.get(2); q4t = r_q1.get(4); q6t = r_q1.get(6);
+        }
         double prev_period = (FAST || i > 6) ? period : 6.0;
         double adj = 0.075 * prev_period + 0.54;
-        double detrend_curr = (0.0962 * sm[0] + 0.5769 * sm[2] - 0.5769 * sm[4] - 0.0962 * sm[6]) * adj;
-        push7(detrend, detrend_curr);
-        double q1_curr = (0.0962 * detrend[0] + 0.5769 * detrend[2] - 0.5769 * detrend[4] - 0.0962 * detrend[6]) * adj;
-        push7(q1, q1_curr);
-        push7(i1, detrend[3]);
-        double ji = (0.0962 * i1[0] + 0.5769 * i1[2] - 0.5769 * i1[4] - 0.0962 * i1[6]) * adj;
-        double jq = (0.0962 * q1[0] + 0.5769 * q1[2] - 0.5769 * q1[4] - 0.0962 * q1[6]) * adj;
-        double i2_curr = 0.2 * (i1[0] - jq) + 0.8 * i2;
-        double q2_curr = 0.2 * (q1[0] + ji) + 0.8 * q2;
+        double detrend_curr = (0.0962 * s + 0.5769 * sm2 - 0.5769 * sm4 - 0.0962 * sm6) * adj;
+        if constexpr (RINGS) r_dt.push(detrend_curr);
+        else { push7(detrend, detrend_curr); d2 = detrend[2]; d4 = detrend[4]; d6 = detrend[6]; }
+        double q1_curr = (0.0962 * detrend_curr + 0.5769 * d2 - 0.5769 * d4 - 0.0962 * d6) * adj;
+        if constexpr (RINGS) r_q1.push(q1_curr);
+        else {
+            push7(q1, q1_curr); q2t = q1[2]; q4t = q1[4]; q6t = q1[6];
+            push7(i1, detrend[3]); i1_0 = i1[0]; i1_2 = i1[2]; i1_4 = i1[4]; i1_6 = i1[6];
+        }
+        q1_0 = q1_curr;
+        double ji = (0.0962 * i1_0 + 0.5769 * i1_2 - 0.5769 * i1_4 - 0.0962 * i1_6) * adj;
+        double jq = (0.0962 * q1_0 + 0.5769 * q2t - 0.5769 * q4t - 0.0962 * q6t) * adj;
+        double i2_curr = 0.2 * (i1_0 - jq) + 0.8 * i2;
+        double q2_curr = 0.2 * (q1_0 + ji) + 0.8 * q2;
         double re_curr = 0.2 * (i2_curr * i2 + q2_curr * q2) + 0.8 * re;
         double im_curr = 0.2 * (i2_curr * q2 - q2_curr * i2) + 0.8 * im;
         i2 = i2_curr; q2 = q2_curr; re = re_curr; im = im_curr;
@@ -208,22 +239,22 @@ struct HtOp {
             if (FAST || i >= 31) y[0] = smooth_period;
         } else if (MODE == 1) {
             if (FAST || i >= 31) {
-                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * PQ_RAD2DEG : 0.0;
+                double dc_phase = (i1_0 != 0.0) ? atan(q1_0 / i1_0) * PQ_RAD2DEG : 0.0;
                 dc_phase += 90.0;
-                if (i1[0] < 0.0) dc_phase += 180.0;
+                if (i1_0 < 0.0) dc_phase += 180.0;
                 if (dc_phase > 315.0) dc_phase -= 360.0;
                 y[0] = dc_phase;
             }
         } else if (MODE == 2) {
-            if (FAST || i >= 31) { y[0] = i1[0]; y[NOUT - 1] = q1[0]; }
+            if (FAST || i >= 31) { y[0] = i1_0; y[NOUT - 1] = q1_0; }
         } else if (MODE == 3) {
             if (FAST || i >= 31) {
-                double dc_phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * PQ_RAD2DEG : 0.0;
+                double dc_phase = (i1_0 != 0.0) ? atan(q1_0 / i1_0) * PQ_RAD2DEG : 0.0;
                 y[0] = sin(dc_phase * PQ_PI / 180.0);
                 y[NOUT - 1] = sin((dc_phase + 45.0) * PQ_PI / 180.0);
             }
         } else {
-            double phase = (i1[0] != 0.0) ? atan(q1[0] / i1[0]) * PQ_RAD2DEG : 0.0;
+            double phase = (i1_0 != 0.0) ? atan(q1_0 / i1_0) * PQ_RAD2DEG : 0.0;
             double dphase = prev_phase - phase;
             if (dphase < 1.0) dphase = 1.0;
             double alpha = fastlimit / dphase;

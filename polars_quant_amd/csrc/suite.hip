@@ -103,14 +103,13 @@ struct pq_suite {
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(BtMacdOp) X(LevOp)                                     \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
 #undef SEQ_OPS_LIGHT
 #define SEQ_OPS_LIGHT(X) PQ_ANALYZE_LIGHT
 #endif
-#define SEQ_OPS_HEAVY(X)                                                                                             \
-    X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp)
+#define SEQ_OPS_HEAVY(X) // (none since the Hilbert pipeline keeps its delay lines in LDS rings; the class and its kernel remain for ops marked HEAVY)
 // V = 0: LDS bodies of the light ops (2 waves/SIMD, capped at 192 VGPRs: PQ_NV0 below), 1: LDS bodies of the heavy ops, 2: gather
 // bodies of every op + the backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
 #ifndef PQ_LB0

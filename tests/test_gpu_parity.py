@@ -542,7 +542,8 @@ def _check_suite_replay(pq, oracle, data, stride):
     assert (info["seq_jobs"] >= 25 and info["phases"] >= 1) if pitch % 2 == 0 else (info["seq_jobs"] >= 60 and info["phases"] >= 2)
     kernels = {gs["kernel"] for gs in st.grid_stats()}
     # an even row pitch must run the tiled bodies (what bench.py times), an odd one the gather bodies
-    assert ("seq_jobs_kernel<0>" in kernels and "seq_jobs_kernel<1>" in kernels) if pitch % 2 == 0 else ("seq_jobs_kernel<2>" in kernels), kernels
+    # (no job of the suite needs the register-heavy kernel seq_jobs_kernel<1> since the Hilbert pipeline keeps its delay lines in LDS)
+    assert ("seq_jobs_kernel<0>" in kernels and "seq_jobs_kernel<2>" not in kernels) if pitch % 2 == 0 else ("seq_jobs_kernel<2>" in kernels), kernels
     for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
         t.fill_(-7)                      # poison: every row must be produced by the replay
     st.run()
@@ -764,7 +765,7 @@ def test_recorded_suite_nulls_and_parameters_on_the_tiled_bodies(pq, oracle):
             if L.pq_suite_grid_variant(suite, k, C.byref(var)) != 0:
                 break
             kernels.add(var.value); k += 1
-        assert {0, 1} <= kernels and 2 not in kernels, f"expected only the tiled job kernels, got variants {kernels}"
+        assert 0 in kernels and 2 not in kernels, f"expected only the tiled job kernels, got variants {kernels}"
         for name, prm, src, outs in recorded:
             exp = oracle.call(name, *[src[c] for c in pq.SPEC[name][0]], **prm)
             for (oname, _), g, e in zip(pq.SPEC[name][2], outs, exp):
