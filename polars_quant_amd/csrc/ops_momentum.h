@@ -581,7 +581,7 @@ template <bool PLUS> // momentum.rs:414-436 / :359-381
 struct DmRawOp {
     static constexpr int NIN = 2, NOUT = 1; // high, low
     static constexpr int SEQ_ID = 29 + (PLUS ? 0 : 1);
-    static constexpr int COST_NS = 120;
+    static constexpr int COST_NS = 90; // scheduling weight (the plus_dm / minus_dm pair a little later in its grid: -1 % per step, weight search)
     int64_t p;
     RmaCore rr;
     double ph, pl;
