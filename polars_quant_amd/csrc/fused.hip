@@ -108,6 +108,14 @@ pq_status pq_dmi_all(pq_ctx *ctx, const pq_batch *b, const double *h, const doub
 pq_status pq_ht_all(pq_ctx *ctx, const pq_batch *b, const double *real, double *dcperiod, double *dcphase, double *inphase,
                     double *quadrature, double *sine, double *leadsine) {
     CHK("pq_ht_all", real && dcperiod && dcphase && inphase && quadrature && sine && leadsine);
+    {   // tiled body: one job, the derived columns leave through its storer wave
+        HtAll6Op op6{};
+        op6.der[0] = dcphase; op6.der[1] = sine; op6.der[2] = leadsine;
+        InCols<1> in{{real}}; OutCols<3> o3{{dcperiod, inphase, quadrature}};
+        const double *nodep[1] = {real};
+        double *ders[3] = {dcphase, sine, leadsine};
+        if (b->len % SeqTile<HtAll6Op>::K == 0 && seq_can_lds(b, op6, in, o3) && seq_cols_aligned<1, 3>(b, nodep, ders)) return launch_seq(ctx, b, op6, in, o3);
+    }
     PQ_TRY(launch_seq(ctx, b, HtAllOp{}, InCols<1>{{real}}, OutCols<3>{{dcperiod, inphase, quadrature}}));
     // (in a recorded suite the ROW launch reads what the job writes, so it lands in the next phase)
     return launch_row(ctx, b, HtPhaseSineOp{}, InCols<2>{{inphase, quadrature}}, OutColsT<HtPhaseSineOp, double>{{dcphase, sine, leadsine}});

@@ -548,32 +548,43 @@ struct HtAllOp {
     }
 };
 // dcphase (cycle.rs:130-139), sine and leadsine (cycle.rs:294-300) from the phasor components of the same row.
+__device__ __forceinline__ void ht_phase_sine(double i1, double q1, double (&y)[3]) {
+    y[0] = y[1] = y[2] = pq_null();
+    if (pq_isnull(i1)) return; // a row the pipeline does not emit (series shorter than 32 rows, rows 0..30)
+    const double tq = q1 / i1;                                          // the quotient both the phase and the sine take
+    double ph = (i1 != 0.0) ? atan(tq) * PQ_RAD2DEG : 0.0;
+    double dc_phase = ph + 90.0;
+    if (i1 < 0.0) dc_phase += 180.0;
+    if (dc_phase > 315.0) dc_phase -= 360.0;
+    y[0] = dc_phase;
+    // sine / leadsine without a device sin: with phi = atan(t), sin(phi) = t / sqrt(1 + t^2) and cos(phi) = 1 / sqrt(1 + t^2)
+    // (phi in (-pi/2, pi/2): cos >= 0), and sin(phi + pi/4) = (sin + cos) / sqrt(2).  The reference takes sin() of phi after a
+    // degrees round trip (two roundings, ~2e-16 relative on the argument); this form is within a few ulp of the exact value: far
+    // inside the 1e-12 budget of these outputs (the single-output pq_ht_sine keeps the reference's two sin calls).
+    double sn = 0.0, cs = 1.0;
+    if (i1 != 0.0) {
+        const double rr = 1.0 / sqrt(1.0 + tq * tq);
+        sn = tq * rr; cs = rr;
+        if (fabs(tq) >= 1e150) { sn = copysign(1.0, tq); cs = 0.0; }     // t^2 overflows: phi = +-pi/2 (false for a NaN t)
+    }
+    y[1] = sn;
+    y[2] = (sn + cs) * 0.70710678118654752440;
+}
 struct HtPhaseSineOp {
     static constexpr int NIN = 2, NOUT = 3; // inphase, quadrature -> dcphase, sine, leadsine
     typedef double OutT;
-    __device__ void eval(const Row<2> &r, int64_t t, double (&y)[3]) {
-        const double i1 = r.in[0][t], q1 = r.in[1][t];
-        y[0] = y[1] = y[2] = pq_null();
-        if (pq_isnull(i1)) return; // a row the pipeline does not emit (series shorter than 32 rows, rows 0..30)
-        const double tq = q1 / i1;                                          // the quotient both the phase and the sine take
-        double ph = (i1 != 0.0) ? atan(tq) * PQ_RAD2DEG : 0.0;
-        double dc_phase = ph + 90.0;
-        if (i1 < 0.0) dc_phase += 180.0;
-        if (dc_phase > 315.0) dc_phase -= 360.0;
-        y[0] = dc_phase;
-        // sine / leadsine without a device sin: with phi = atan(t), sin(phi) = t / sqrt(1 + t^2) and cos(phi) = 1 / sqrt(1 + t^2)
-        // (phi in (-pi/2, pi/2): cos >= 0), and sin(phi + pi/4) = (sin + cos) / sqrt(2).  The reference takes sin() of phi after a
-        // degrees round trip (two roundings, ~2e-16 relative on the argument); this form is within a few ulp of the exact value: far
-        // inside the 1e-12 budget of these outputs (the single-output pq_ht_sine keeps the reference's two sin calls).
-        double sn = 0.0, cs = 1.0;
-        if (i1 != 0.0) {
-            const double rr = 1.0 / sqrt(1.0 + tq * tq);
-            sn = tq * rr; cs = rr;
-            if (fabs(tq) >= 1e150) { sn = copysign(1.0, tq); cs = 0.0; }     // t^2 overflows: phi = +-pi/2 (false for a NaN t)
-        }
-        y[1] = sn;
-        y[2] = (sn + cs) * 0.70710678118654752440;
-    }
+    __device__ void eval(const Row<2> &r, int64_t t, double (&y)[3]) { ht_phase_sine(r.in[0][t], r.in[1][t], y); }
+};
+// HtAllOp + the three derived columns in ONE job (tiled body): the storer wave computes dcphase / sine / leadsine from the phasor rows
+// it holds (NDer, pq_dev.h) -- the values HtPhaseSineOp would read back from memory, through the same function.  Saves that launch, which
+// could only start when the whole grid of its producer had drained (the last 0.1 ms of a suite step), and 0.2 GB of reads.
+struct HtAll6Op : HtAllOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int SEQ_ID = 85;
+    static constexpr int ALG_COLS = 2 + 3 + 2 + 3; // ht_dcperiod, ht_phasor, ht_dcphase, ht_sine
+    static constexpr int NDER = 3;
+    double *der[3]; // dcphase, sine, leadsine
+    __device__ static void derive(const double (&y)[3], double (&z)[3]) { ht_phase_sine(y[1], y[2], z); }
 };
 
 // MAVP with the SMA core (matype 0 / 7 / other): a job advances SIXTEEN candidate periods [lo, hi] in one walk.  Every

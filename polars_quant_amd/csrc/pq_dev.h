@@ -96,6 +96,16 @@ template <class Op, class = void>
 struct AlgCols { static constexpr int value = Op::NIN + Op::NOUT; };
 template <class Op>
 struct AlgCols<Op, decltype((void)Op::ALG_COLS)> { static constexpr int value = Op::ALG_COLS; };
+// Derived outputs: NDER further columns that are ELEMENT-WISE functions of the job's own output row (e.g. dcphase / sine / leadsine of the
+// Hilbert phasor).  The storer wave -- idle between hand-offs -- computes them from the out tiles it already holds in registers and
+// streams them out with the same 128-byte pieces: no extra LDS, no extra pass over memory, nothing added to the compute wave's
+// dependency chain.  Op contract: static constexpr int NDER;  double *der[NDER] (device pointers, 16-byte aligned, the batch's pitch);
+//   __device__ static void derive(const double (&y)[NOUT], double (&z)[NDER]).   Tiled body, per-tile storer (no pair mode), series of
+// whole tiles (len % K == 0: the host entry falls back to a separate launch otherwise).
+template <class Op, class = void>
+struct NDer { static constexpr int value = 0; };
+template <class Op>
+struct NDer<Op, decltype((void)Op::NDER)> { static constexpr int value = Op::NDER; };
 template <class Op, class = void>
 struct HasFinish { static constexpr bool value = false; }; // void finish(double *const *outp, const Dims &, int64_t s): per-series epilogue
 template <class Op>
@@ -486,7 +496,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #ifndef PQ_PAIR_CAP
 #define PQ_PAIR_CAP 136
 #endif
-            if constexpr (K == 8 && PQ_STORER_PAIR) {
+            if constexpr (K == 8 && PQ_STORER_PAIR && NDer<Op>::value == 0) {
                 // Pair mode: the storer re-maps its lanes to (series of a group of 8, one of the 8 chunks of TWO consecutive tiles):
                 // lanes with chunk < 4 pull their 16 bytes out of the even tile, the others out of the odd tile into the same
                 // registers, and one store instruction then writes 8 series x 128 contiguous bytes instead of 16 x 64 -- with a row
@@ -544,7 +554,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                         }
                 }
             } else {
-            constexpr int ACC = (NOUT * NI * 4 * PQ_STORER_ACC <= 136) ? PQ_STORER_ACC : 1; // registers of the (otherwise idle) storer wave
+            // (an op with derived columns takes this per-tile form: the 64-bit constants of derive() -- ~80 registers for an atan -- leave
+            //  no room for the two held tiles of pair mode under the 192-VGPR cap; its columns go out in 64-byte pieces)
+            constexpr int ACC = (NOUT * NI * 4 * PQ_STORER_ACC <= 136 && NDer<Op>::value == 0) ? PQ_STORER_ACC : 1; // registers of the (otherwise idle) storer wave
             for (int64_t it = 0; it < nt; it += ACC) {
                 double2 v[ACC][NOUT][NI];
 #pragma unroll
@@ -571,6 +583,20 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                         for (int a = 0; a < ACC; a++)
                             if (it + a < nt && tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow(i) + t0 + a * K, v[a][k][i]);
+                if constexpr (NDer<Op>::value > 0) { // derived columns from the two rows per access this lane holds
+                    constexpr int ND = NDer<Op>::value;
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        double ya[NOUT], yb[NOUT], za[ND], zb[ND];
+#pragma unroll
+                        for (int k = 0; k < NOUT; k++) { ya[k] = v[0][k][i].x; yb[k] = v[0][k][i].y; }
+                        Op::derive(ya, za);
+                        Op::derive(yb, zb);
+#pragma unroll
+                        for (int k = 0; k < ND; k++)
+                            if (tile_s0 + i * SPI + csym < d.n) nt_store2(op.der[k] + crow(i) + t0, make_double2(za[k], zb[k]));
+                    }
+                }
             }
             }
             if constexpr (HasFinish<Op>::value) { // the epilogue of wave 0 reads what this wave stored
@@ -709,6 +735,8 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
             for (int k = 0; k < NOUT; k++)
                 if (!MASKED || !pq_isskip(y[k])) outp[k][row_tail + t] = y[k];
+            // (an op with derived columns is only launched on series of whole tiles -- its host entry checks len % K: evaluating
+            // derive() here would add its temporaries to the compute wave's live state for a loop of at most K - 1 rows)
         }
     }
     if constexpr (HasFinish<Op>::value) {
@@ -761,7 +789,7 @@ struct HasExtraReads { static constexpr bool value = false; };
 template <class Op>
 struct HasExtraReads<Op, decltype((void)&Op::extra_reads)> { static constexpr bool value = true; };
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, void *extra_write = nullptr);
+                      int nin, double *const *out, int nout, void *const *extra_writes = nullptr); // extra_writes: 4 pointers or null
 struct RowThunk { // type-erased ROW launch for replay
     void (*launch)(const void *blob, hipStream_t stream);
     int row_id;     // Op::ROW_ID if the suite may run it inside its fused ROW grid (row_jobs_kernel), else 0
@@ -812,8 +840,12 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     if (ctx->rec) {
         if constexpr (HasSeqId<Op>::value) {
             static_assert(sizeof(Op) <= 1024, "SEQ op too large for a job slot");
-            void *extra = nullptr;
-            if constexpr (HasFinish<Op>::value) extra = op.finish_writes();
+            void *extra[4] = {nullptr, nullptr, nullptr, nullptr}; // columns the job writes besides `out` (hazard tracking of the recording)
+            if constexpr (HasFinish<Op>::value) extra[0] = op.finish_writes();
+            if constexpr (NDer<Op>::value > 0) {
+                static_assert(NDer<Op>::value <= 3 && !HasFinish<Op>::value, "at most three derived columns, no epilogue");
+                for (int k = 0; k < NDer<Op>::value; k++) extra[k] = op.der[k];
+            }
             SeqTraits tr{Op::SEQ_ID, (int)((double)OpCost<Op>::get(op) * (double)b->len * 1e-3), IsHeavy<Op>::value, IsMasked<Op>::value,
                          use_lds ? lds : 0, (size_t)SeqTile<Op>::BYTES, AlgCols<Op>::value, HasFinish<Op>::value ? 64.0 : 0.0, {}};
             if constexpr (HasExtraReads<Op>::value) op.extra_reads(tr.extra_reads);

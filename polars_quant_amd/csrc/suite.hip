@@ -103,7 +103,7 @@ struct pq_suite {
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(BtMacdOp) X(LevOp)                                     \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(HtAll6Op) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
 #if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
 #undef SEQ_OPS_LIGHT
@@ -236,7 +236,7 @@ static pq_status same_batch(Recorder &r, const pq_batch *b) {
 }
 
 pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const void *op, size_t op_bytes, const double *const *in,
-                      int nin, double *const *out, int nout, void *extra_write) {
+                      int nin, double *const *out, int nout, void *const *extra_writes) {
     Recorder &r = *ctx->rec;
     PQ_TRY(same_batch(r, b));
     if (nin > 6 || nout > 8) { pq_set_error("internal: SEQ job has too many columns"); return PQ_ERR_UNSUPPORTED; }
@@ -249,14 +249,14 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
     memcpy(j.op, op, op_bytes);
-    void *writes[9];
+    void *writes[12];
     for (int k = 0; k < nout; k++) writes[k] = out[k];
-    writes[nout] = extra_write; // e.g. the backtest's summary table: hazard tracking only
+    for (int k = 0; k < 4; k++) writes[nout + k] = extra_writes ? extra_writes[k] : nullptr; // e.g. a summary table, derived columns: hazard tracking only
     const void *reads[10];
     int nr = 0;
     for (int k = 0; k < nin; k++) reads[nr++] = in[k];
     for (int k = 0; k < 4; k++) if (tr.extra_reads[k]) reads[nr++] = tr.extra_reads[k];
-    int ph = phase_for(r, reads, nr, writes, nout + 1);
+    int ph = phase_for(r, reads, nr, writes, nout + 4);
     r.phases[ph].seq.push_back(j);
     return PQ_OK;
 }
