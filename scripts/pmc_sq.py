@@ -12,5 +12,5 @@ for d in sys.argv[1:]:
         for (k, gy, did, c), v in per.items():
             agg[(k, gy)][c].append(v)
 for (k, gy), cs in sorted(agg.items()):
-    if "seq_jobs" not in k and "cdl" not in k: continue
+    if not any(x in k for x in ("seq_jobs", "cdl", "row_jobs", "bt_wave")): continue
     print(f"{k} y={gy}: " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(cs.items())))
