@@ -462,15 +462,27 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t T = d.len, nt = T / K;
     const int csym = lane / CPL, cchunk = lane % CPL;
-    // global row offset of the i-th series this lane helps to move (dead series of the last tile shadow the last live one).  Computed
-    // at every use from one 32-bit register: four 64-bit offsets held across the row loop were the first values the register
-    // allocator spilled under the job kernel's 192-VGPR cap, and three integer instructions per 16-byte access are noise.
+    // Global addresses of the cooperative tile accesses: a wave-uniform 64-bit base (column + first series of the tile + first row of
+    // the tile: scalar arithmetic) plus a 32-bit BYTE offset per lane -- the global_load / global_store form with a scalar base and a
+    // 32-bit vector offset.  The offset of access i is this lane's part (one register) + a uniform step, with the dead series of the last
+    // tile folded onto the last live one by a compare + select: four full-rate 32-bit instructions per 16-byte access, no 64-bit
+    // multiply.  (Four 64-bit row offsets held across the row loop were the first values the allocator spilled under the 192-VGPR cap.)
+    // The host launches the tiled body only when 64 * stride * 8 < 2^32 (seq_cols_aligned).
     const int64_t tile_left = d.n - 1 - tile_s0;                         // wave-uniform: index of the last live series within the tile
     const unsigned rel_max = tile_left < 63 ? (tile_left > 0 ? (unsigned)tile_left : 0u) : 63u;
     const int64_t tile_base = tile_s0 * d.stride;                        // wave-uniform
-    auto crow = [&](int i) -> int64_t {
-        const unsigned rel = (unsigned)(csym + i * SPI);
-        return tile_base + (int64_t)(rel < rel_max ? rel : rel_max) * d.stride + cchunk * 2;
+    const unsigned stride_b = (unsigned)d.stride * 8u;                   // wave-uniform
+    const unsigned lane_part = (unsigned)csym * stride_b + (unsigned)cchunk * 16u;
+    auto live_i = [&](int i) -> bool { return (unsigned)(csym + i * SPI) <= rel_max; };           // the series of access i exists
+    auto toff = [&](int i) -> unsigned {
+        const unsigned o = lane_part + (unsigned)(i * SPI) * stride_b;
+        return live_i(i) ? o : rel_max * stride_b + (unsigned)cchunk * 16u;
+    };
+    auto at = [&](const double *col, int i, int64_t t0) -> const double * { // col, t0 wave-uniform
+        return reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(col + tile_base + t0) + toff(i));
+    };
+    auto at_w = [&](double *col, int i, int64_t t0) -> double * {
+        return reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(col + tile_base + t0) + toff(i));
     };
     unsigned char *const co_base = lds + csym * ROWB + cchunk * 16; // this lane's 16-byte slot of a cooperative tile access; access i adds
     auto co_row = [&](int i) -> unsigned char * { return co_base + i * (SPI * ROWB); }; // a compile-time offset (the DS offset field)
@@ -540,17 +552,18 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             for (int k = 0; k < R; k++)
 #pragma unroll
                                 for (int i = 0; i < NI; i++)
-                                    if (tile_s0 + i * SPI + csym < d.n) nt_store2(outp[W + k] + crow(i) + t0, v[k][i]);
+                                    if (live_i(i)) nt_store2(at_w(outp[W + k], i, t0), v[k][i]);
                         }
                     }
                     const bool mine = it + 1 < nt || half == 0; // an odd tile count leaves the last tile alone
-                    const int64_t t0 = it * K + (lane & 7) * 2;
+                    const unsigned pair_part = (unsigned)sub * stride_b + (unsigned)(lane & 7) * 16u; // series sub + 8 i, rows 2 (lane & 7) ..
 #pragma unroll
                     for (int k = 0; k < W; k++)
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
-                            const int64_t srs = tile_s0 + i * 8 + sub;
-                            if (mine && srs < d.n) nt_store2(outp[k] + srs * d.stride + t0, w[k][i]);
+                            unsigned char *const pb = reinterpret_cast<unsigned char *>(outp[k] + tile_base + it * K); // wave-uniform
+                            if (mine && (unsigned)(i * 8 + sub) <= rel_max)
+                                nt_store2(reinterpret_cast<double *>(pb + (pair_part + (unsigned)(i * 8) * stride_b)), w[k][i]);
                         }
                 }
             } else {
@@ -582,7 +595,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     for (int i = 0; i < NI; i++)
 #pragma unroll
                         for (int a = 0; a < ACC; a++)
-                            if (it + a < nt && tile_s0 + i * SPI + csym < d.n) nt_store2(outp[k] + crow(i) + t0 + a * K, v[a][k][i]);
+                            if (it + a < nt && live_i(i)) nt_store2(at_w(outp[k], i, t0 + a * K), v[a][k][i]);
                 if constexpr (NDer<Op>::value > 0) { // derived columns from the two rows per access this lane holds
                     constexpr int ND = NDer<Op>::value;
 #pragma unroll
@@ -594,7 +607,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                         Op::derive(yb, zb);
 #pragma unroll
                         for (int k = 0; k < ND; k++)
-                            if (tile_s0 + i * SPI + csym < d.n) nt_store2(op.der[k] + crow(i) + t0, make_double2(za[k], zb[k]));
+                            if (live_i(i)) nt_store2(at_w(op.der[k], i, t0), make_double2(za[k], zb[k]));
                     }
                 }
             }
@@ -629,7 +642,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
         for (int k = 0; k < NIN; k++)
 #pragma unroll
-            for (int i = 0; i < NI; i++) buf[k][i] = PQ_HOOK_TILE_LOAD(inp[k] + crow(i) + t0, t0, i);
+            for (int i = 0; i < NI; i++) buf[k][i] = PQ_HOOK_TILE_LOAD(at(inp[k], i, t0), t0, i);
     };
     auto do_tile = [&](double2 (&buf)[NIN][NI], int64_t it) {
         const int64_t t0 = it * K;
@@ -751,6 +764,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 template <int NIN, int NOUT>
 static inline bool seq_cols_aligned(const pq_batch *b, const double *const *in, double *const *out) {
     if (b->stride % 2 || b->offsets) return false; // (ragged series start at arbitrary rows: the per-lane body runs them)
+    if (b->stride >= (1 << 22)) return false;     // the tiled body addresses a tile's 64 series with 32-bit byte offsets
     for (int k = 0; k < NIN; k++) if (reinterpret_cast<uintptr_t>(in[k]) % 16) return false;
     for (int k = 0; k < NOUT; k++) if (reinterpret_cast<uintptr_t>(out[k]) % 16) return false;
     return true;
