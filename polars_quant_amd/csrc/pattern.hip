@@ -226,7 +226,10 @@ __device__ __forceinline__ Cdl load_candle(const CdlArgs &a, int64_t base, int64
 #define PQ_CDL_R 1
 #endif
 constexpr int CDL_R = PQ_CDL_R;
-__global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, int vec) {
+// ALL: every recogniser has an output column (the usual call): no per-recogniser test of its pointer -- 61 uniform branches per row,
+// each the end of a scheduling region -- and one store form (VEC: the int32 rows are 4R-byte aligned).
+template <bool ALL, bool VEC>
+__global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d) {
     const int64_t s = blockIdx.y;
     const int64_t t0 = ((int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x) * CDL_R;
     const int64_t slen = dims_len(d, s);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
     }
 #pragma unroll
     for (int id = 0; id < PQ_N_PATTERNS; id++) {
-        if (a.out[id] == nullptr) continue; // wave-uniform
+        if (!ALL && a.out[id] == nullptr) continue; // wave-uniform
         int v[CDL_R];
 #pragma unroll
         for (int r = 0; r < CDL_R; r++) { // row t0 + r: current candle w[CDL_R - 1 - r]
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d, i
         if (v[0] == 123456789) a.out[id][base + t0] = v[0];
 #else
         int32_t *dst = &a.out[id][base + t0];
-        if (vec && t0 + CDL_R <= slen) {
+        if (VEC && (CDL_R == 1 || t0 + CDL_R <= slen)) {
             typedef int pq_irv __attribute__((ext_vector_type(CDL_R)));
             pq_irv vv;
 #pragma unroll
@@ -357,7 +360,12 @@ static void cdl_launch_blob(const void *blob, hipStream_t stream) {
                 if (a2.out[i] && reinterpret_cast<uintptr_t>(a2.out[i]) % (4 * CDL_R)) vec = 0;
             const int64_t per_block = (int64_t)ROW_BLOCK * CDL_R;
             dim3 grid2((unsigned)((b->len + per_block - 1) / per_block), (unsigned)ns);
-            hipLaunchKernelGGL(cdl_all_kernel, grid2, dim3(ROW_BLOCK), 0, stream, a2, d, vec);
+            bool all = true;
+            for (int i = 0; i < PQ_N_PATTERNS; i++) all &= a2.out[i] != nullptr;
+            if (all && vec) hipLaunchKernelGGL((cdl_all_kernel<true, true>), grid2, dim3(ROW_BLOCK), 0, stream, a2, d);
+            else if (all) hipLaunchKernelGGL((cdl_all_kernel<true, false>), grid2, dim3(ROW_BLOCK), 0, stream, a2, d);
+            else if (vec) hipLaunchKernelGGL((cdl_all_kernel<false, true>), grid2, dim3(ROW_BLOCK), 0, stream, a2, d);
+            else hipLaunchKernelGGL((cdl_all_kernel<false, false>), grid2, dim3(ROW_BLOCK), 0, stream, a2, d);
         } else hipLaunchKernelGGL(cdl_one_kernel, grid, dim3(ROW_BLOCK), 0, stream, a2, id, d);
     }
 }
