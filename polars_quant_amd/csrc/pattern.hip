@@ -235,10 +235,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void cdl_all_kernel(CdlArgs a, Dims d) {
     const int64_t slen = dims_len(d, s);
     if (t0 >= slen) return;
     const int64_t base = dims_base(d, s);
-    // ~1500 instructions per row: beside the SEQ grids of a suite (whose long jobs raise their own priority) this kernel would
-    // otherwise only be issued in the gaps and become the critical path of the step
+    // Issue priority beside the SEQ grids of a suite (whose long jobs raise their own).  Round 2: 1 (the kernel was only issued in the gaps
+    // and became the critical path at 0; 3 cost +4 %).  Round 3: 0 -- its waves now sit beside two job waves on every SIMD (192-VGPR job
+    // kernel) and advance all the time; at 0 they take what the job waves leave: 4.06 against 4.12 ms per step (2: 4.12, 3: 4.19).
 #ifndef PQ_CDL_PRIO
-#define PQ_CDL_PRIO 1 // 3: +4 % per suite step (A/B): at 0.87 ms of work it no longer needs to win against the SEQ jobs
+#define PQ_CDL_PRIO 0
 #endif
     __builtin_amdgcn_s_setprio(PQ_CDL_PRIO);
     Cdl w[CDL_R + 4]; // w[k] = candle of row t0 + CDL_R - 1 - k
