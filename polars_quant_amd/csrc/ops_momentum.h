@@ -426,7 +426,7 @@ struct UltoscOp { // momentum.rs:572-627
 struct MfiOp { // momentum.rs:286-342
     static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume
     static constexpr int SEQ_ID = 25;
-    static constexpr int COST_NS = 500;
+    static constexpr int COST_NS = 880; // scheduling weight (x 1.4 for the volume-family job it anchors: weight search, -0.8 % per step)
     static constexpr int NTAP = 7; // high, low, close, volume at i-p; high, low, close at i-p-1
     static constexpr int TAP_COL[7] = {0, 1, 2, 3, 0, 1, 2};
     int64_t p;
