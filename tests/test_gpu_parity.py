@@ -976,3 +976,48 @@ def test_backtest_get_stock_performance(pq, oracle):
     bt2 = pq.Backtest(wide(close), wide(ebuy), wide(esell))
     bt2.run()
     assert "alpha_pct" not in bt2.get_stock_performance("AAA")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_recorded_suite_random_task_subsets(pq, oracle, seed):
+    """The launch plan of a recorded suite depends on WHAT was recorded (which chains exist, whether the backtest and a fused ROW grid
+    share the tail of the SHORT chain, whether a ROW launch is hoisted behind its producers): random subsets of the benchmark suite's
+    tasks in random order, on the tiled bodies, every produced column against the oracle and every other column untouched."""
+    from polars_quant_amd.suite import Suite
+    rng = np.random.default_rng(seed)
+    n, T_ = int(rng.choice([70, 200, 333])), int(rng.choice([304, 312, 344]))
+    d = oracle.gen_ohlcv(SEED + 40 + seed, n, T_, 0)
+    d["real"] = d["close"]
+    g = {k: torch.from_numpy(d[k]).cuda() for k in ("open", "high", "low", "close", "volume")}
+    st = Suite(n, T_, "cuda")
+    all_tasks = st.tasks(fused=True)
+    k = int(rng.integers(1, len(all_tasks)))
+    tasks = [all_tasks[i] for i in rng.permutation(len(all_tasks))[:k]]
+    if seed % 2 == 0 and "backtest_macd_cross" not in tasks: tasks.append("backtest_macd_cross")
+    for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
+        t.fill_(-7)
+    st.record(g, tasks)
+    st.run(); st.run()
+    torch.cuda.synchronize()
+    covered = set()
+    for t in tasks:
+        covered |= set({"ht_all": ("ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine")}.get(t) or Suite.FUSED.get(t) or (t,))
+    dd = dict(d); dd["periods"] = st.periods.cpu().numpy()
+    for name in sorted(pq.SPEC):
+        if name in covered:
+            exp = oracle.call(name, *[dd[c] for c in pq.SPEC[name][0]])
+            for (oname, _), got, e in zip(pq.SPEC[name][2], st.out[name], exp):
+                assert_same(f"{name}.{oname}{{subset {seed}}}", got.cpu().numpy(), e, exact=name not in TRANSCENDENTAL, price=d["close"])
+        else:
+            for got in st.out[name]:
+                assert (got == -7).all(), f"{name} was not recorded but its column changed (seed {seed})"
+    if "cdl_all" in tasks:
+        for nm in pq.PATTERN_NAMES:
+            assert (st.pat[nm].cpu().numpy() == oracle.pattern(nm, d["open"], d["high"], d["low"], d["close"])).all(), nm
+    if "backtest_macd_cross" in tasks:
+        ebuy, esell = oracle.macd_cross_signals(d["close"])
+        _, _, eeq, es = oracle.backtest(d["close"], ebuy, esell)
+        assert (bits(st.bt[2].cpu().numpy()) == bits(eeq)).all()
+        np.testing.assert_allclose(st.summary.cpu().numpy(), es, rtol=1e-12, atol=1e-13)
+    st.close()
