@@ -180,7 +180,7 @@ struct FastUnroll<Op, decltype((void)Op::FAST_UNROLL)> { static constexpr int va
 //   static constexpr int COST_NS = ...;        solo cost of one row of the tiled body in ns (measured on MI355X at 5000 x 2520,
 //                                              scripts/exp_solo.py); or, where the cost depends on a parameter,
 //   __host__ int cost_ns() const;              the same from the op's parameters
-//   static constexpr bool HEAVY = true;        needs more than the light job kernel's 168 VGPRs: runs in the 2-waves/SIMD kernel
+//   static constexpr bool HEAVY = true;        needs more than the light job kernel's 192 VGPRs: runs in the 256-VGPR kernel
 template <class Op, class = void>
 struct OpCostStatic { static constexpr int value = 60 + 40 * (Op::NIN + Op::NOUT); };
 template <class Op>

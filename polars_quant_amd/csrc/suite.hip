@@ -92,9 +92,9 @@ struct pq_suite {
     Recorder rec;
 };
 
-// every recordable SEQ op: X(Type).  Kernel variants: the register-hungry Hilbert ops would pin the whole grid to
-// 2 waves/SIMD with 255 VGPRs, so they (and the lane-form backtest scan) get their own kernel; everything else needs <= 221
-// VGPRs (no scratch) at the same 2 waves/SIMD.
+// every recordable SEQ op: X(Type).  Kernel variants: the light job kernel is capped at 192 VGPRs (PQ_NV0 below; every op of the list
+// fits without scratch); an op marked HEAVY (none at present: STOCH and the Hilbert pipeline were slimmed in round 3) and the lane-form
+// backtest scan run in a second kernel with the full 256.
 #define SEQ_OPS_LIGHT(X)                                                                                             \
     X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
     X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
@@ -113,10 +113,9 @@ struct pq_suite {
 // V = 0: LDS bodies of the light ops (2 waves/SIMD, capped at 192 VGPRs: PQ_NV0 below), 1: LDS bodies of the heavy ops, 2: gather
 // bodies of every op + the backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
 #ifndef PQ_LB0
-// waves per SIMD the light kernel is compiled for.  2 (round 3): 221 VGPRs, ScratchSize 0.  At 3 (168 VGPRs) the three widest jobs
-// (EMA x 4, the volume family, the DM system) spilled 359 registers / 272 B of scratch per lane; LDS already holds a CU to four
-// of the LONG grid's workgroups = 2 waves / SIMD, so the third wave was never resident there.  A/B in one session: LONG grid
-// 4.05 -> 3.5 ms, HEAVY 4.25 -> 3.7 ms, step -1.2 % (the ROW chain is then the longest).  Table: profiles/r03_kernel_resources.txt
+// waves per SIMD the light kernel is compiled for: 2.  At 3 (168 VGPRs, round 2) the three widest jobs (EMA x 4, the volume family, the
+// DM system) spilled 359 registers / 272 B of scratch per lane, and LDS holds a CU to four of the LONG grid's workgroups = 2 waves /
+// SIMD anyway.  The actual cap is PQ_NV0 (192).  Table: profiles/r03_kernel_resources.txt, csrc/suite.resources.txt (every build)
 #define PQ_LB0 2
 #endif
 template <int V>
