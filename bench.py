@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_SYM, T_DAYS, SEED = 5000, 2520, 0x5EED0002
-COPY_GBS = 4400.0   # torch copy_ of 4-12 GB on MI355X: 2.2 TB/s read + 2.2 TB/s written (profiles/r02_ubench_write_bw.txt)
+COPY_GBS = 4900.0   # a grid-stride 16-byte copy kernel on MI355X, read + written (scripts/ubench/copybw.hip, profiles/r03_ubench_copybw.txt; torch copy_: 4400)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured here: streaming read 6.1, fill 6.6 TB/s
 
 
@@ -325,7 +325,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" if traffic else None,
                          # the whole step against what this chip does for a read/write MIX: its L2-miss bytes (PMC) per second, and
-                         # the rate of a streaming copy (2.2 TB/s read + 2.2 TB/s written, scripts/ubench/write_bw.py)
+                         # the rate of a streaming copy kernel (read + written, scripts/ubench/copybw.hip)
                          "step_traffic": step_traffic,
                          "step_traffic_GBps": step_traffic / (elapsed / args.steps) / 1e9 if step_traffic and world == 1 else None,
                          "copy_GBps_measured": COPY_GBS,
