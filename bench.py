@@ -7,8 +7,9 @@ recognisers fused) + the fused MACD-cross per-symbol backtest with summary.  N G
 shard of symbols (static split, no data-path collective); the only exchange is one all_gather of the
 [n_local, 8] summary table per step.  rows = symbols x days.
 
-  --scaling weak   (default) every GPU gets --symbols symbols (5000): per-GPU work fixed
-  --scaling strong the --symbols symbols are split over the GPUs (BASELINE config 3: 5000 symbols over 8 GPUs = 625 each)
+  --scaling strong (default for --gpus N > 1: BASELINE.json's metric is 5000 symbols AT 1/2/4/8 GPUs) the --symbols symbols are
+                   split over the GPUs (5000 symbols over 8 GPUs = 625 each); the weak figure is carried as `weak_scaling`
+  --scaling weak   every GPU gets --symbols symbols (5000): per-GPU work fixed (the only meaning at --gpus 1)
   --e2e            additionally times the step END TO END from host Arrow-style buffers: pq_host_register'ed OHLCV columns ->
                    H2D -> step -> D2H of the summary table (and, second figure, of every output); reported in config.e2e,
                    never as `value`
@@ -31,6 +32,20 @@ import torch  # noqa: E402
 N_SYM, T_DAYS, SEED = 5000, 2520, 0x5EED0002
 COPY_GBS = 4900.0   # a grid-stride 16-byte copy kernel on MI355X, read + written (scripts/ubench/copybw.hip, profiles/r03_ubench_copybw.txt; torch copy_: 4400)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured here: streaming read 6.1, fill 6.6 TB/s
+FUSED_FLOOR_BYTES_PER_ROW = 928   # SURVEY 8(d) second denominator: OHLCV read once (40 B) + every output of the step written once
+                                  # (64 + 17 f64 indicator columns, 62 int32 columns, 3 backtest columns = 888 B)
+PMC_FILE = ROOT / "profiles" / "r04_pmc_traffic.json"
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): the PMC traffic file is only quoted for the build it was
+    collected on (scripts/pmc_summary.py writes the same hash into it; .git does not travel to the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list((ROOT / "polars_quant_amd" / "csrc").glob("*.hip")) + list((ROOT / "polars_quant_amd" / "csrc").glob("*.h")) +
+                    list((ROOT / "include").glob("*.h"))):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def make_inputs(n_sym: int, T: int, seed: int, device):
@@ -41,15 +56,21 @@ def make_inputs(n_sym: int, T: int, seed: int, device):
 
 
 def cpu_baseline(sample_syms: int, T: int):
+    """the scalar C restatement, -O3 -march=native (built on this host), OpenMP over symbols on every core
+    this process may use, on the bench's own data set (all 5000 symbols)."""
     from oracle import pq_oracle as oracle   # the ONLY use of oracle/ here: the timed CPU baseline leg
     from polars_quant_amd.synthetic import gen_ohlcv
     d = gen_ohlcv(SEED, sample_syms, T, 0)
-    # the GPU box allots 16 host cores per GPU (and caps worker pools there); use at most that many
-    cores = min(len(os.sched_getaffinity(0)), 16)
-    oracle.suite_bench({k: v[:8] for k, v in d.items()}, cores)  # spin up the OpenMP team
-    t0 = time.perf_counter(); oracle.suite_bench(d, cores); t_all = time.perf_counter() - t0
-    small = {k: v[: max(8, sample_syms // 8)] for k, v in d.items()}
-    t0 = time.perf_counter(); oracle.suite_bench(small, 1); t_one = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0))
+    native = oracle.native_lib() is not None
+    oracle.suite_bench({k: v[:2 * cores] for k, v in d.items()}, cores, native=native)  # spin up the OpenMP team
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.suite_bench(d, cores, native=native)
+    t_all = (time.perf_counter() - t0) / reps
+    small = {k: v[: max(8, sample_syms // 16)] for k, v in d.items()}
+    t0 = time.perf_counter(); oracle.suite_bench(small, 1, native=native); t_one = time.perf_counter() - t0
     rows = sample_syms * T
     cpu = "?"
     try:
@@ -57,10 +78,11 @@ def cpu_baseline(sample_syms: int, T: int):
     except Exception:  # noqa: BLE001
         pass
     import subprocess
-    cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0] if True else "gcc"
+    cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    flags = "-O3 -march=native -ffp-contract=off (built on this host)" if native else "-O3 -ffp-contract=off (the -march=native build failed here: portable build)"
     return {"value": rows / t_all, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_syms} symbols x {T} days, same suite+backtest, oracle (scalar C restatement of the reference; the Rust "
-                      f"reference cannot be built here), {cc}, -O3 -ffp-contract=off (no -march=native: the .so travels between hosts), "
+            "sample": f"{sample_syms} symbols x {T} days (the bench's own data set), same suite+backtest, mean of {reps} passes; oracle = scalar C "
+                      f"restatement of the reference (the Rust reference cannot be built here), {cc}, {flags}, "
                       f"OpenMP over symbols on {cores} threads of '{cpu}'",
             "value_1thread": small["close"].shape[0] * T / t_one}
 
@@ -129,15 +151,36 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
     return res
 
 
+def visible_gpus():
+    """number of GPUs this process would see, WITHOUT touching the HIP / HSA runtime (torch.cuda.device_count() may fall back to
+    hipGetDeviceCount, which initialises it -- and a GPU-initialised parent must not start the ranks): kfd topology nodes with SIMDs,
+    narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None: unknown (then --gpus is trusted and the children fail loudly)."""
+    nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+    if not nodes.is_dir():
+        return 0              # no kfd driver: no AMD GPU on this host
+    try:
+        n = 0
+        for node in sorted(nodes.iterdir()):
+            props = dict(l.split(None, 1) for l in (node / "properties").read_text().splitlines() if " " in l)
+            n += int(props.get("simd_count", "0")) > 0
+    except Exception:  # noqa: BLE001
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: N child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
-    as torch.distributed.run would set them).  The parent has made no HIP call (torch.cuda.device_count() does not initialise
-    the runtime), so the children are ordinary fresh processes; rank 0 prints the JSON line on the inherited stdout."""
+    as torch.distributed.run would set them).  The parent makes no HIP / HSA call at all -- GPUs are counted from the kfd topology
+    in sysfs (visible_gpus) -- so the children are ordinary fresh processes; rank 0 prints the JSON line on the inherited stdout."""
     import socket
     import subprocess
     n = args.gpus
-    have = torch.cuda.device_count()
-    if have < n and not args.dry_run:
+    have = visible_gpus()
+    if have is not None and have < n and not args.dry_run:
         print(f"bench.py: --gpus {n} needs {n} visible GPUs, this host shows {have}; not running a {have}-GPU job under the name "
               f"of an {n}-GPU one", file=sys.stderr)
         return 2
@@ -185,16 +228,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--symbols", type=int, default=N_SYM, help="symbols per GPU (weak scaling) / in total (strong scaling)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--symbols", type=int, default=N_SYM, help="symbols in total (strong scaling) / per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: strong when --gpus > 1 (BASELINE.json: 5000 symbols at 1/2/4/8 GPUs), weak at --gpus 1 (same thing)")
     ap.add_argument("--e2e", action="store_true", help="also time the step end to end from registered host buffers")
     ap.add_argument("--days", type=int, default=T_DAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (dense layout at 1 GPU, weak scaling at N GPUs)")
     ap.add_argument("--stride", type=int, default=0,
                     help="row pitch of the device columns in elements (0 = days rounded up to a multiple of 16 = 128 B; = days: dense)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / shard ranges only (gloo on the CPU, no GPU work): what `--gpus N` would run where")
     args = ap.parse_args()
+    default_scaling = args.scaling is None
+    if default_scaling:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))   # this process never touches the GPU: it starts one fresh process per rank
@@ -212,6 +260,9 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() <= local_rank:
+            print(f"bench.py: rank {rank} needs GPU {local_rank}, this host shows {torch.cuda.device_count()} visible GPUs", file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
@@ -221,117 +272,179 @@ def main():
     from polars_quant_amd.suite import Suite
     from polars_quant_amd.distributed import gather_summaries, shard_range
     T = args.days
-    if args.scaling == "strong":     # one data set of --symbols symbols, split statically over the ranks
-        lo, hi = shard_range(args.symbols, rank, world)
-        n_local, n_total = hi - lo, args.symbols
-        full = make_inputs(args.symbols, T, SEED, torch.device("cpu"))
-        ohlcv = {k: v[lo:hi].contiguous().to(dev) for k, v in full.items()}
-        del full
-    else:
-        n_local, n_total = args.symbols, args.symbols * world
-        ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
-    # Device columns are pitched like a hipMallocPitch allocation: a row pitch that is a multiple of 128 B makes every 64 / 128-byte
-    # tile piece one aligned cache line (dense 2520-element rows start at odd multiples of 64 B): -8 % per step.  `--stride <days>`
-    # measures the dense layout.
     stride = args.stride or (T + 15) // 16 * 16
-    if stride != T:  # re-house the inputs with the padded row pitch
-        for k in list(ohlcv):
-            buf = torch.zeros((n_local, stride), dtype=torch.float64, device=dev)
-            buf[:, :T] = ohlcv[k]
-            ohlcv[k] = buf[:, :T]
-    suite = Suite(n_local, T, dev, stride=stride)
 
-    def step():
-        suite.run(ohlcv)
-        if world > 1:   # the one exchange of the path: per-symbol summary rows to every rank (RCCL over xGMI)
-            gather_summaries(suite.summary, n_total)
+    def build(scaling):
+        """-> (suite, ohlcv, n_local, n_total) for this rank; inputs resident in HBM on the pitched layout"""
+        if scaling == "strong":     # one data set of --symbols symbols, split statically over the ranks
+            lo, hi = shard_range(args.symbols, rank, world)
+            n_local, n_total = hi - lo, args.symbols
+            full = make_inputs(args.symbols, T, SEED, torch.device("cpu"))
+            ohlcv = {k: v[lo:hi].contiguous().to(dev) for k, v in full.items()}
+            del full
+        else:
+            n_local, n_total = args.symbols, args.symbols * world
+            ohlcv = make_inputs(n_local, T, SEED + rank, dev)       # every rank: its own symbols
+        # Device columns are pitched like a hipMallocPitch allocation: a row pitch that is a multiple of 128 B makes every 64 / 128-byte
+        # tile piece one aligned cache line (dense 2520-element rows start at odd multiples of 64 B).  `--stride <days>` measures the
+        # dense layout.
+        if stride != T:  # re-house the inputs with the padded row pitch
+            for k in list(ohlcv):
+                buf = torch.zeros((n_local, stride), dtype=torch.float64, device=dev)
+                buf[:, :T] = ohlcv[k]
+                ohlcv[k] = buf[:, :T]
+        st = Suite(n_local, T, dev, stride=stride)
+        st.record(ohlcv)   # one-time: turn the step's calls into job grids (not part of the timed region)
+        return st, ohlcv, n_local, n_total
 
-    suite.record(ohlcv)   # one-time: turn the step's calls into job grids (not part of the timed region)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    suite.set_timing(True)
+    # ---- the one exchange of the path (world > 1): per-symbol summary rows to every rank, through the PRODUCT's own collective --
+    # pq_comm_init + pq_gather_summaries of the C ABI (csrc/comm.hip: RCCL all-gather over xGMI on the context's stream).  The
+    # communicator is built on a helper thread with a deadline; if it cannot be built, the step falls back to torch.distributed's
+    # all_gather and the line says so (collective.timed).
+    comm, comm_note, th = None, None, None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        import threading
+        box = {}
+
+        def mk_comm():
+            try:
+                torch.cuda.set_device(dev)   # (the current device is per thread)
+                from polars_quant_amd.distributed import CabiComm
+                box["comm"] = CabiComm(dev, rank, world)
+            except Exception as e:  # noqa: BLE001
+                box["err"] = str(e)
+
+        th = threading.Thread(target=mk_comm, daemon=True)
+        th.start()
+        th.join(120.0)
+        ok = torch.tensor([1 if "comm" in box else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks or none
+        if int(ok.item()) == 1:
+            comm = box["comm"]
+        else:
+            comm_note = box.get("err", "no answer within 120 s")
+
+    def time_steps(st, ohlcv, n_total, steps, warmup, timing=False):
+        def step():
+            st.run(ohlcv)
+            if world > 1:
+                if comm is not None:
+                    comm.gather_summaries(st.summary, n_total)
+                else:
+                    gather_summaries(st.summary, n_total)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if timing:
+            st.set_timing(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
+    suite, ohlcv, n_local, n_total = build(args.scaling)
+    elapsed = time_steps(suite, ohlcv, n_total, args.steps, args.warmup, timing=True)
+    gather_check = None
+    if world > 1 and comm is not None:   # cross-check, outside the timed region: the C-ABI gather against torch.distributed's
+        ref = gather_summaries(suite.summary, n_total)
+        got = comm.gather_summaries(suite.summary, n_total)
+        torch.cuda.synchronize()
+        gather_check = bool(torch.equal(got.view(torch.int64), ref.view(torch.int64)))
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------------
-    # The step's device time is dominated by seq_jobs_kernel<0>: the tiled bodies of all sequential jobs, two launches per
-    # step (one per LDS class) that run CONCURRENTLY with each other and with
-    # the row-parallel kernels.  Each launch was bracketed by HIP events on its own launch stream during the timed steps
-    # above (pq_suite_set_timing).  Contract figure: achieved = mean algorithmic bytes per launch / mean launch duration
-    # (= what `rocprofv3 --kernel-trace --stats` reports as that kernel's average duration, profiles/).  Because the
-    # launches overlap, each one sees only its share of the chip; `suite_algorithmic_GBps` in `config` is the rate of the
-    # whole step.
+    # The step's device time is dominated by seq_jobs_kernel<0>: the tiled bodies of all sequential jobs, launched per LDS class, the
+    # launches running CONCURRENTLY with each other and with the row-parallel kernels.  Each launch was bracketed by HIP events on
+    # its own launch stream during the timed steps above (pq_suite_set_timing).  Contract figure: achieved = mean algorithmic bytes
+    # per launch / mean launch duration (= what `rocprofv3 --kernel-trace --stats` reports as that kernel's average duration,
+    # profiles/).  Because the launches overlap, each one sees only its share of the chip; the whole step is reported three ways:
+    # per-call algorithmic bytes (config.suite_algorithmic_GBps), counter bytes (roofline.step_frac_counter_bytes) and the fused
+    # floor (roofline.step_frac_fused_floor) -- SURVEY 8(d): "always state which denominator".
     grids = [g for g in suite.grid_stats() if g["runs"] > 0]
     rows_local = n_local * T
-    dom = [g for g in grids if g["kernel"] == "seq_jobs_kernel<0>"]
+    by_kernel = {}
+    for g in grids:
+        by_kernel.setdefault(g["kernel"], []).append(g)
+    dom_name = max(by_kernel, key=lambda k: sum(g["avg_ms"] * g["runs"] for g in by_kernel[k])) if by_kernel else None
+    dom = by_kernel.get(dom_name, [])
     n_launch = sum(g["runs"] for g in dom)
     if n_launch:
         mean_ms = sum(g["avg_ms"] * g["runs"] for g in dom) / n_launch
         mean_bytes = sum(g["alg_bytes"] * g["runs"] for g in dom) / n_launch
         achieved = mean_bytes / (mean_ms * 1e-3) / 1e9
-    else:   # e.g. an odd --days / --stride: no tiled grid exists, every job ran in the gather kernel
-        mean_ms = mean_bytes = achieved = None
-    span_ms, span_bytes = suite.span_stats(0)   # the two launches as one concurrent set
-    suite_bytes = suite.suite_bytes_per_row() * rows_local
-    suite_gbs = suite_bytes / (elapsed / args.steps) / 1e9
-    # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
-    # command; summary committed by scripts/pmc_summary.py).  Only valid for the configuration it was collected on.
-    traffic = None
-    pmc = ROOT / "profiles" / "r03_pmc_traffic.json"   # (collected by scripts/collect_profiles.sh; says so in the line: roofline.traffic_source)
-    if pmc.exists() and n_local == N_SYM and T == T_DAYS:
-        kernels = json.loads(pmc.read_text())["kernels"]
-        k = kernels.get("seq_jobs_kernel<0>")
-        traffic = k["hbm_bytes_per_launch"] if k else None
-        # every kernel of the step (the PMC file holds means per launch; seq_jobs_kernel<0> is launched twice per step)
-        step_traffic = sum(v["hbm_bytes_per_launch"] * (2 if name == "seq_jobs_kernel<0>" else 1)
-                           for name, v in kernels.items() if not name.startswith(("at::", "__amd")))   # torch's own kernels excluded
     else:
-        step_traffic = None
+        mean_ms = mean_bytes = achieved = None
+    span_ms, span_bytes = suite.span_stats(0)   # the launches of the tiled job kernel as one concurrent set
+    ms_step = elapsed / args.steps * 1e3
+    suite_bytes = suite.suite_bytes_per_row() * rows_local
+    suite_gbs = suite_bytes / (ms_step * 1e-3) / 1e9
+    fused_gbs = FUSED_FLOOR_BYTES_PER_ROW * rows_local / (ms_step * 1e-3) / 1e9
+    # HBM traffic from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command; summary committed by
+    # scripts/pmc_summary.py).  Only quoted for the build (source hash) and the configuration it was collected on.
+    traffic = step_traffic = traffic_note = None
+    if PMC_FILE.exists() and n_local == N_SYM and T == T_DAYS and stride == (T_DAYS + 15) // 16 * 16:
+        pm = json.loads(PMC_FILE.read_text())
+        if pm.get("source_hash") == source_hash():
+            kernels = pm["kernels"]
+            per_step = pm.get("launches_per_step", {})
+            k = kernels.get(dom_name)
+            traffic = k["hbm_bytes_per_launch"] if k else None
+            step_traffic = sum(v["hbm_bytes_per_launch"] * per_step.get(name, 1) for name, v in kernels.items()
+                               if not name.startswith(("at::", "__amd")))   # torch's own kernels excluded
+            traffic_note = f"profiles/{PMC_FILE.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this build, source hash {pm['source_hash']}; not measured in this run)"
+        else:
+            traffic_note = f"profiles/{PMC_FILE.name} was collected on another build (source hash {pm.get('source_hash')} != {source_hash()}): not quoted"
 
+    line = None
     if rank == 0:
         rows_total = n_total * T * args.steps
         line = {
             "metric": "indicator+backtest rows/sec, 5000 sym x 2520 day f64 OHLCV",
             "value": rows_total / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "collective": ({"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
-                            "per_step": "one all_gather of the [n_local, 8] summary rows",
-                            "c_abi_gather": "pq_comm_init + pq_gather_summaries run once AFTER this line and are compared with this result; "
-                                            "outcome on stderr"}
+            "collective": ({"per_step": "one all-gather of the [n_local, 8] summary rows",
+                            "timed": ("pq_gather_summaries (C ABI, csrc/comm.hip: RCCL ncclAllGather on the context's stream)" if comm is not None
+                                      else f"torch.distributed all_gather_into_tensor (the C-ABI communicator could not be built: {comm_note})"),
+                            "torch_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                            "c_abi_equals_torch_gather": gather_check}
                            if world > 1 else None),
             "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
-                                   f"recognisers) + fused MACD-cross backtest with summary, {n_local} symbols x {T} days "
-                                   "f64 OHLCV per GPU, inputs resident in HBM",
+                                   f"recognisers) + fused MACD-cross backtest with summary, {n_total} symbols x {T} days "
+                                   f"f64 OHLCV ({n_local} per GPU), inputs resident in HBM",
                        "symbols_per_gpu": n_local, "symbols_total": n_total, "days": T, "row_pitch_elements": stride,
                        "parallelism": f"symbol-sharded x{world}",
                        "algorithmic_bytes_per_row": suite.suite_bytes_per_row(),
-                       "suite_algorithmic_GBps": suite_gbs, "suite_frac_of_hbm_peak": suite_gbs / HBM_PEAK_GBS},
-            "roofline": {"bound": "hbm", "kernel": "seq_jobs_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "suite_algorithmic_GBps": suite_gbs,
+                       "suite_frac_of_hbm_peak_on_per_call_bytes": suite_gbs / HBM_PEAK_GBS},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" if traffic else None,
-                         # the whole step against what this chip does for a read/write MIX: its L2-miss bytes (PMC) per second, and
-                         # the rate of a streaming copy kernel (read + written, scripts/ubench/copybw.hip)
+                         "traffic_source": traffic_note,
+                         "denominators": "frac: per-call algorithmic bytes (SURVEY 8d B/row of every reference call a job replaces) of ONE launch of "
+                                         "the dominant kernel / its duration; step_frac_counter_bytes: HBM bytes of the whole step from the PMC "
+                                         "counters / step time / peak; step_frac_fused_floor: 928 B/row (inputs once + every output once) / step "
+                                         "time / peak; config.suite_frac_of_hbm_peak_on_per_call_bytes: 1 856 B/row (one call per function, inputs "
+                                         "re-read per call) / step time / peak -- may exceed what moved",
+                         "fused_lower_bound_bytes_per_row": FUSED_FLOOR_BYTES_PER_ROW,
+                         "step_frac_fused_floor": fused_gbs / HBM_PEAK_GBS if world == 1 else None,
                          "step_traffic": step_traffic,
-                         "step_traffic_GBps": step_traffic / (elapsed / args.steps) / 1e9 if step_traffic and world == 1 else None,
+                         "step_traffic_GBps": step_traffic / (ms_step * 1e-3) / 1e9 if step_traffic and world == 1 else None,
+                         "step_frac_counter_bytes": step_traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS if step_traffic and world == 1 else None,
                          "copy_GBps_measured": COPY_GBS,
                          "algorithmic_bytes_per_launch": mean_bytes, "avg_launch_ms": mean_ms,
                          "launches_per_step": len(dom),
-                         "concurrent_set": {"note": "the launches of this kernel overlap inside a step: their summed algorithmic bytes "
+                         "concurrent_set": {"note": "the launches of seq_jobs_kernel<0> overlap inside a step: their summed algorithmic bytes "
                                                     "over the time from the earliest start to the latest end (HIP events)",
                                             "span_ms": span_ms, "algorithmic_bytes": span_bytes,
                                             "achieved": span_bytes / (span_ms * 1e-3) / 1e9 if span_ms else None,
@@ -340,53 +453,40 @@ def main():
         }
         if args.e2e and world == 1:
             line["config"]["e2e"] = end_to_end(suite, ohlcv, n_local, T, dev)
-        if world == 1 and stride != T and args.scaling == "weak" and not args.no_cpu_baseline:
-            # for the record: the same step on the DENSE layout (row pitch = days), outside the timed region above
-            suite.close()
-            dense_in = {k: v.contiguous() for k, v in ohlcv.items()}
-            dense = Suite(n_local, T, dev, stride=T)
-            dense.record(dense_in)
-            for _ in range(args.warmup):
-                dense.run(dense_in)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                dense.run(dense_in)
-            torch.cuda.synchronize()
-            line["config"]["dense_layout"] = {"row_pitch_elements": T, "ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3}
-            dense.close()
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(4096, T)
-        print(json.dumps(line))
-    if world > 1:
-        # The same exchange through the C ABI's own entry points (pq_comm_init + pq_gather_summaries: what a non-Python host calls),
-        # once, after the measurement has been printed, compared bit for bit with the torch.distributed result.  It runs on a
-        # helper thread with a deadline: a second communicator that cannot be built must not be able to hold the job.
-        import threading
-        box = {}
-
-        def cross_check():
-            try:
-                torch.cuda.set_device(dev)   # (the current device is per thread)
-                from polars_quant_amd.distributed import CabiComm
-                ref = gather_summaries(suite.summary, n_total)
-                comm = CabiComm(dev, rank, world)
-                got = comm.gather_summaries(suite.summary, n_total)
-                torch.cuda.synchronize()
-                box["result"] = "ok: identical to the torch.distributed gather" if torch.equal(got.view(torch.int64), ref.view(torch.int64)) else "MISMATCH"
-                comm.close()
-            except Exception as e:  # noqa: BLE001
-                box["result"] = f"failed: {e}"
-
-        th = threading.Thread(target=cross_check, daemon=True)
-        th.start()
-        th.join(90.0)
+    # ---- secondary figures, outside the timed region above
+    if world == 1 and stride != T and not args.no_secondary and not args.no_cpu_baseline:
+        # for the record: the same step on the DENSE layout (row pitch = days)
+        suite.close()
+        dense_in = {k: v.contiguous() for k, v in ohlcv.items()}
+        dense = Suite(n_local, T, dev, stride=T)
+        dense.record(dense_in)
+        el = time_steps(dense, dense_in, n_total, args.steps, args.warmup)
+        line["config"]["dense_layout"] = {"row_pitch_elements": T, "ms_per_step": el / args.steps * 1e3}
+        dense.close()
+    if world > 1 and default_scaling and not args.no_secondary:
+        # the weak-scaling figure (5000 symbols PER GPU) beside the BASELINE configuration (5000 symbols in total)
+        suite.close()
+        del ohlcv
+        wsuite, wohlcv, wn_local, wn_total = build("weak")
+        wsteps = max(5, args.steps // 2)
+        el = time_steps(wsuite, wohlcv, wn_total, wsteps, 2)
         if rank == 0:
-            print(f"[bench] C-ABI gather (pq_comm_init + pq_gather_summaries over {world} ranks): {box.get('result', 'no answer within 90 s')}",
-                  file=sys.stderr, flush=True)
-        if th.is_alive():
+            line["weak_scaling"] = {"symbols_per_gpu": wn_local, "symbols_total": wn_total, "steps": wsteps, "ms_per_step": el / wsteps * 1e3,
+                                    "value": wn_total * T * wsteps / el, "unit": "rows/s"}
+        wsuite.close()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N_SYM, T)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+        elif th is not None and th.is_alive():
             sys.stdout.flush()
-            os._exit(0)   # the measurement is out; do not wait for a collective that will not complete
+            os._exit(0)   # the measurement is out; do not wait for a communicator that will not come up
         dist.destroy_process_group()
 
 

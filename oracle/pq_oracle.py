@@ -346,9 +346,28 @@ def gen_ohlcv(seed: int, n_sym: int, T: int, mode: int = 0):
     return arrs
 
 
-def suite_bench(ohlcv: dict, threads: int = 0) -> float:
+_native = None
+
+
+def native_lib():
+    """the same sources compiled -O3 -march=native on THIS host (bench.py's cpu_baseline leg; the portable build is what the
+    parity tests use) -> CDLL, or None when it cannot be built here"""
+    global _native
+    if _native is None:
+        so = _HERE / "libpq_oracle_native.so"
+        try:
+            subprocess.run(["make", "-C", str(_HERE), "-s", "-B", "native"], check=True, capture_output=True)   # -B: never reuse another host's build
+            _native = C.CDLL(str(so))
+            _native.pqo_suite_bench.restype = C.c_double
+        except Exception:  # noqa: BLE001
+            _native = False
+    return _native or None
+
+
+def suite_bench(ohlcv: dict, threads: int = 0, native: bool = False) -> float:
     N, T = ohlcv["close"].shape
-    return lib().pqo_suite_bench(*[_p(np.ascontiguousarray(ohlcv[k])) for k in ("open", "high", "low", "close", "volume")],
+    L = (native_lib() if native else None) or lib()
+    return L.pqo_suite_bench(*[_p(np.ascontiguousarray(ohlcv[k])) for k in ("open", "high", "low", "close", "volume")],
                                  C.c_int64(N), C.c_int64(T), C.c_int(threads))
 
 

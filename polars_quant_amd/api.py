@@ -142,8 +142,9 @@ def ragged_batch(offsets, device):
     """offsets: n + 1 ascending row indices (series s = rows [offsets[s], offsets[s + 1]) of the long columns, sorted by symbol:
     the groups of `.over("symbol")`) -> (Batch, the device copy it points at)."""
     off = torch.as_tensor(np.asarray(offsets.cpu() if isinstance(offsets, torch.Tensor) else offsets), dtype=torch.int64).reshape(-1)
-    if off.numel() < 1 or (off.numel() > 1 and bool((off[1:] < off[:-1]).any())) or int(off[0]) < 0:
-        raise PqError("offsets must be n + 1 ascending, non-negative row indices")
+    if off.numel() < 1 or (off.numel() > 1 and bool((off[1:] < off[:-1]).any())) or int(off[0]) != 0:
+        raise PqError("offsets must be n + 1 ascending row indices starting at 0 (rows in front of the first group would belong to no "
+                      "group and their outputs would stay unwritten)")
     n = off.numel() - 1
     longest = int((off[1:] - off[:-1]).max()) if n else 0
     total = int(off[-1])
@@ -414,8 +415,12 @@ def _dev2(x, dtype=torch.float64):
     return _to_device(x, dtype)[0].contiguous()
 
 
-def _rule(fn_name, shape_like, args, outs):
-    """one of the strategy rule kernels (csrc/strategy.hip): args = ctypes values, outs = output tensors (returned)"""
+def _rule(fn_name, shape_like, args, outs, same=()):
+    """one of the strategy rule kernels (csrc/strategy.hip): args = ctypes values, outs = output tensors (returned); `same`:
+    the other tensor arguments, which must have shape_like's shape (the kernel indexes all of them with one batch)"""
+    for t in same:
+        if t is not None and tuple(t.shape) != tuple(shape_like.shape):
+            raise PqError(f"{fn_name}: input shapes differ: {tuple(t.shape)} vs {tuple(shape_like.shape)}")
     n, T = shape_like.shape
     b = Batch(n, T, T)
     if n * T:
@@ -430,12 +435,12 @@ def gate_signals(buy, sell, a, mode: int, k0: float = 0.0, k1: float = 0.0, c=No
     c_ = _dev2(c) if c is not None else None
     outs = [torch.empty_like(bu), torch.empty_like(se)]
     return tuple(_rule("pq_gate_signals", a_, [C.c_void_p(a_.data_ptr()), C.c_void_p(c_.data_ptr()) if c_ is not None else None, int(mode),
-                                               C.c_double(float(k0)), C.c_double(float(k1)), C.c_void_p(bu.data_ptr()), C.c_void_p(se.data_ptr())], outs))
+                                               C.c_double(float(k0)), C.c_double(float(k1)), C.c_void_p(bu.data_ptr()), C.c_void_p(se.data_ptr())], outs, same=(bu, se, c_)))
 
 
 def zscore(price, upper, mid):
     p, u, m = _dev2(price), _dev2(upper), _dev2(mid)
-    return _rule("pq_zscore", p, [C.c_void_p(t.data_ptr()) for t in (p, u, m)], [torch.empty_like(p)])[0]
+    return _rule("pq_zscore", p, [C.c_void_p(t.data_ptr()) for t in (p, u, m)], [torch.empty_like(p)], same=(u, m))[0]
 
 
 def scale_band(base, f_lo: float, f_hi: float):
@@ -450,12 +455,12 @@ def _u8_pair(like):
 
 def volume_surge_signals(volume, avg_volume, close, multiplier: float):
     v, sv, c = _dev2(volume), _dev2(avg_volume), _dev2(close)
-    return tuple(_rule("pq_volume_surge_signals", v, [C.c_void_p(t.data_ptr()) for t in (v, sv, c)] + [C.c_double(float(multiplier))], _u8_pair(v)))
+    return tuple(_rule("pq_volume_surge_signals", v, [C.c_void_p(t.data_ptr()) for t in (v, sv, c)] + [C.c_double(float(multiplier))], _u8_pair(v), same=(sv, c)))
 
 
 def gap_signals(open, high, low, f_up: float, f_dn: float):
     o, h, l = _dev2(open), _dev2(high), _dev2(low)
-    return tuple(_rule("pq_gap_signals", o, [C.c_void_p(t.data_ptr()) for t in (o, h, l)] + [C.c_double(float(f_up)), C.c_double(float(f_dn))], _u8_pair(o)))
+    return tuple(_rule("pq_gap_signals", o, [C.c_void_p(t.data_ptr()) for t in (o, h, l)] + [C.c_double(float(f_up)), C.c_double(float(f_dn))], _u8_pair(o), same=(h, l)))
 
 
 def pattern_any_signals(bullish, bearish):
@@ -465,13 +470,13 @@ def pattern_any_signals(bullish, bearish):
     like = (bu + be)[0]
     pb = (C.c_void_p * max(len(bu), 1))(*[t.data_ptr() for t in bu])
     ps = (C.c_void_p * max(len(be), 1))(*[t.data_ptr() for t in be])
-    return tuple(_rule("pq_pattern_any_signals", like, [pb, len(bu), ps, len(be)], _u8_pair(like)))
+    return tuple(_rule("pq_pattern_any_signals", like, [pb, len(bu), ps, len(be)], _u8_pair(like), same=bu + be))
 
 
 def ma_stack_signals(mas):
     ms = [_dev2(t) for t in mas]
     ptrs = (C.c_void_p * len(ms))(*[t.data_ptr() for t in ms])
-    return tuple(_rule("pq_ma_stack_signals", ms[0], [ptrs, len(ms)], _u8_pair(ms[0])))
+    return tuple(_rule("pq_ma_stack_signals", ms[0], [ptrs, len(ms)], _u8_pair(ms[0]), same=ms))
 
 
 def backtest_leveraged(price, buy, sell, benchmark=None, max_trades: int = 64, **kw):

@@ -29,11 +29,12 @@ struct BtWaveBlob {
 };
 static void btw_launch_blob(const void *blob, hipStream_t stream) {
     const BtWaveBlob &w = *reinterpret_cast<const BtWaveBlob *>(blob);
-    static bool big_lds[2] = {false, false}; // above 64 KB of dynamic LDS a kernel has to opt in once
-    if (w.lds > 64 * 1024 && !big_lds[w.macd]) {
-        if (w.macd) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds[w.macd] = true;
+    // above 64 KB of dynamic LDS a kernel has to opt in; the attribute belongs to the CURRENT device's copy of the function, so it
+    // is set on every such launch (a host-side table write) rather than remembered in a process-wide flag
+    if (w.lds > 64 * 1024) {
+        const hipError_t e = w.macd ? hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return; // the launch below would fail with a less specific error; hipGetLastError reports this one
     }
     const dim3 grid((unsigned)w.b.n_series);
     if (w.macd) hipLaunchKernelGGL(bt_wave_kernel<true>, grid, dim3(64), w.lds, stream, w.a, dims_of(&w.b));
@@ -79,11 +80,9 @@ struct LevWaveBlob {
 };
 static void lev_wave_launch_blob(const void *blob, hipStream_t stream) {
     const LevWaveBlob &lb = *reinterpret_cast<const LevWaveBlob *>(blob);
-    static bool big_lds = false;
-    if (lb.lds > 64 * 1024 && !big_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lev_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds = true;
-    }
+    if (lb.lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&lev_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return;
     hipLaunchKernelGGL(lev_wave_kernel, dim3((unsigned)lb.b.n_series), dim3(64), lb.lds, stream, lb.w, dims_of(&lb.b));
 }
 // the leveraged engine, one symbol per wavefront (len <= 4096); true: handled

@@ -118,14 +118,17 @@ pq_status pq_gather_summaries(pq_ctx *ctx, const double *local, int64_t n_symbol
     // ragged shards: every rank's rows are broadcast into their place, as one group (one launch per peer, all links busy at once)
     if (hi > lo) PQ_HIP_TRY(hipMemcpyAsync(all + lo * PQ_SUMMARY_COLS, local, (size_t)(hi - lo) * PQ_SUMMARY_COLS * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     PQ_NCCL_TRY(g_rccl.GroupStart());
-    for (int r = 0; r < G; r++) {
+    ncclResult_t bad = ncclSuccess;   // a failing call inside the group must still be followed by GroupEnd (else the communicator stays mid-group)
+    for (int r = 0; r < G && bad == ncclSuccess; r++) {
         int64_t a, b;
-        PQ_TRY(pq_shard_range(n_symbols, r, G, &a, &b));
+        (void)pq_shard_range(n_symbols, r, G, &a, &b);   // (arguments validated above)
         if (b == a) continue;
         double *dst = all + a * PQ_SUMMARY_COLS;
-        PQ_NCCL_TRY(g_rccl.Broadcast(dst, dst, (size_t)(b - a) * PQ_SUMMARY_COLS, ncclFloat64, r, comm, ctx->stream));
+        bad = g_rccl.Broadcast(dst, dst, (size_t)(b - a) * PQ_SUMMARY_COLS, ncclFloat64, r, comm, ctx->stream);
     }
-    PQ_NCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();
+    PQ_NCCL_TRY(bad);
+    PQ_NCCL_TRY(end);
     return PQ_OK;
 }
 

@@ -131,7 +131,7 @@ __device__ __forceinline__ bool btw_stage(const BtwGeom &g, int lane, const doub
     auto addr = [&](int i) { return g.addr(i); };
     {
         if (((reinterpret_cast<uintptr_t>(src) & 15) == 0)) { // 16 bytes per lane: rows 128 * j + 2 * lane, + 1
-            const int npair = (T + 127) / 128;
+            const int npair = (64 * C + 127) / 128; // every LDS row below 64 * C is written (a ragged batch sizes C for its LONGEST group: rows in [T, 64 * C) get `fill`)
             for (int j0 = 0; j0 < npair; j0 += 8) {
                 double2 v[8];
 #pragma unroll

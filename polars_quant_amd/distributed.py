@@ -102,6 +102,7 @@ class CabiComm:
         self._C, self._check, self._lib = C, check, lib()
         self.device = torch.device(device)
         self.h = api.ctx(self.device.index)
+        self.stream = torch.cuda.current_stream(self.device)   # the communicator lives on this context = this stream
         idbuf = torch.zeros(129, dtype=torch.uint8)   # [ok flag, 128 id bytes]: every rank learns whether rank 0 could make the id
         if rank == 0:
             raw = (C.c_ubyte * 128)()
@@ -121,10 +122,19 @@ class CabiComm:
 
     def gather_summaries(self, local: torch.Tensor, n_symbols: int) -> torch.Tensor:
         C = self._C
+        lo, hi = shard_range(n_symbols, self.rank, self.world)
+        if local.shape[0] != hi - lo:
+            raise ValueError(f"rank {self.rank} of {self.world} owns {hi - lo} of {n_symbols} symbols, got {local.shape[0]} summary rows")
+        cur = torch.cuda.current_stream(self.device)
         out = torch.empty((n_symbols, local.shape[1]), dtype=local.dtype, device=local.device)
         loc = local.contiguous()
+        if cur != self.stream:        # the collective runs on the communicator's stream: order it behind the producer of `local` ...
+            self.stream.wait_stream(cur)
+            out.record_stream(self.stream); loc.record_stream(self.stream)
         with torch.cuda.device(self.device):
             self._check(self._lib.pq_gather_summaries(self.h, C.c_void_p(loc.data_ptr()), n_symbols, C.c_void_p(out.data_ptr())))
+        if cur != self.stream:        # ... and the consumers of `out` behind the collective
+            cur.wait_stream(self.stream)
         return out
 
     def close(self):

@@ -14,7 +14,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
 from oracle import pq_oracle as oracle  # noqa: E402
+from pattern_kats import kat_series  # noqa: E402
 
 N, T = 4, 200
 ALT = {"timeperiod": 7, "timeperiod1": 3, "timeperiod2": 6, "timeperiod3": 11, "fastperiod": 5, "slowperiod": 13, "signalperiod": 4,
@@ -30,6 +32,10 @@ NULL_TOLERANT = {"bbands", "dema", "ema", "kama", "ma", "mama", "mavp", "midpoin
 def datasets():
     clean = oracle.gen_ohlcv(0x601D0001, N, T, 0)
     rich = oracle.gen_ohlcv(0x601D0002, N, T, 1)
+    # symbols 2 and 3 of the pattern-rich set: the hand-built firing sequences of tests/pattern_kats.py (all 60 satisfiable
+    # recognisers fire in the fixture; cdl2crows cannot, pattern.rs:30-33)
+    for sym, start in ((2, 0), (3, 44)):
+        rich["open"][sym], rich["high"][sym], rich["low"][sym], rich["close"][sym] = kat_series(T, start)[:4]
     rng = np.random.default_rng(0x601D)
     holes = {}
     for k, v in clean.items():

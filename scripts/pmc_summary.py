@@ -5,10 +5,14 @@ Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB
 of the bytes of a wide coalesced (16 B/lane) read stream, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores.
 Calibration inside this very profile: cdl_all_kernel writes 61 int32 columns = 3.07 GB algorithmic and WRITE_SIZE reads
 3.08 GB; it reads 4 f64 columns = 403 MB and 2 x FETCH_SIZE reads 430 MB.
-usage: python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01
+usage: python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r04 [steps incl. warm-up of the profiled command]
+The file carries the source hash of the build it was collected on (bench.source_hash): bench.py quotes it only for that build.
 """
 import csv, glob, json, sys
 from collections import defaultdict
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import source_hash  # noqa: E402
 
 def per_kernel(path, counter):
     f = glob.glob(path + "/**/*counter_collection.csv", recursive=True)[0]
@@ -27,7 +31,10 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"launches": max(nf, nw), "fetch_bytes_per_launch": 2.0 * fk * 1024.0, "write_bytes_per_launch": wk * 1024.0,
               "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0,
               "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
-json.dump({"note": "mean per launch; FETCH_SIZE doubled (gfx950 correction), KiB -> bytes", "kernels": out},
+nsteps = int(sys.argv[4]) if len(sys.argv) > 4 else 23
+json.dump({"note": "mean per launch; FETCH_SIZE doubled (gfx950 correction), KiB -> bytes", "source_hash": source_hash(),
+           "launches_per_step": {k: round(v["launches"] / nsteps) for k, v in out.items() if round(v["launches"] / nsteps) >= 1},
+           "kernels": out},
           open(sys.argv[3] + "_pmc_traffic.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:6]:
     print(f"{k[:40]:40s} {v['hbm_bytes_per_launch']/1e9:7.3f} GB/launch  (read {v['fetch_bytes_per_launch']/1e9:.3f} write {v['write_bytes_per_launch']/1e9:.3f})")

@@ -145,22 +145,24 @@ def test_wave_form_equals_lane_form_and_long_series_fall_back(pq, oracle, monkey
 
 
 def test_full_size_config3_wave_backtest(pq, oracle):
-    """BASELINE config 3 (5000 x 2520): sampled symbols against the oracle, size-independent properties on all of them."""
+    """BASELINE config 3 (5000 x 2520) on the bench's layout (row pitch 2528): EVERY symbol against the oracle, plus the
+    size-independent properties."""
     from polars_quant_amd import api
     from polars_quant_amd.synthetic import gen_ohlcv
-    N, T = 5000, 2520
+    N, T, STRIDE = 5000, 2520, 2528
     close = gen_ohlcv(0x5EED0002, N, T, 0)["close"]
+    buf = torch.zeros((N, STRIDE), dtype=torch.float64, device="cuda")
+    buf[:, :T] = torch.from_numpy(close).cuda()
     api.backtest_wave_stats(reset=True)
-    pos, cash, eq, s = api.backtest_macd_cross(torch.from_numpy(close).cuda())
+    pos, cash, eq, s = api.backtest_macd_cross(buf[:, :T])
     st = api.backtest_wave_stats()
     assert st[0] == N
     assert st[1] <= N // 4, f"too many speculative chunks fail at the default warm-up: {st}"
     pos, cash, eq, s = (t.cpu().numpy() for t in (pos, cash, eq, s))
-    sample = np.r_[0:8, 2496:2504, 4992:5000]
-    ebuy, esell = oracle.macd_cross_signals(close[sample])
-    epos, ecash, eeq, es = oracle.backtest(close[sample], ebuy, esell)
-    assert (bits(pos[sample]) == bits(epos)).all() and (bits(cash[sample]) == bits(ecash)).all() and (bits(eq[sample]) == bits(eeq)).all()
-    check_summary(s[sample], es, "config3")
+    ebuy, esell = oracle.macd_cross_signals(close)
+    epos, ecash, eeq, es = oracle.backtest(close, ebuy, esell)
+    assert (bits(pos) == bits(epos)).all() and (bits(cash) == bits(ecash)).all() and (bits(eq) == bits(eeq)).all()
+    check_summary(s, es, "config3")
     # properties over every symbol: equity identity row by row, whole shares, trades counted = position changes / 2 (rounded up)
     assert (bits(eq) == bits(cash + pos * close)).all()
     assert (pos == np.floor(pos)).all() and (pos >= 0).all()

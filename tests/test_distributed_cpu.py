@@ -131,7 +131,9 @@ def test_bench_gpus_flag_launches_one_process_per_rank():
     assert [s["rank"] for s in d["shards"]] == [0, 1] and [s["local_rank"] for s in d["shards"]] == [0, 1]
     p, lines = _run_bench("--gpus", "3", "--dry-run", "--scaling", "strong", "--symbols", "1000")
     assert [s["symbols"] for s in lines[0]["shards"]] == [[0, 333], [333, 666], [666, 1000]]       # ragged: floor(N r / G)
-    p, lines = _run_bench("--gpus", "2", "--dry-run")                                               # weak: 5000 per rank, own seeds
+    p, lines = _run_bench("--gpus", "2", "--dry-run")                    # default at N > 1 = BASELINE's configuration: 5000 in total
+    assert lines[0]["scaling"] == "strong" and [s["symbols"] for s in lines[0]["shards"]] == [[0, 2500], [2500, 5000]]
+    p, lines = _run_bench("--gpus", "2", "--dry-run", "--scaling", "weak")                          # weak: 5000 per rank, own seeds
     assert [s["symbols"] for s in lines[0]["shards"]] == [[0, 5000], [5000, 10000]] and lines[0]["symbols_total"] == 10000
     assert lines[0]["shards"][0]["seed"] != lines[0]["shards"][1]["seed"]
 

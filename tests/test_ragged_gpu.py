@@ -133,6 +133,28 @@ def test_backtests_on_ragged_groups(pq, oracle):
             np.testing.assert_allclose(gs[s], es2, rtol=1e-12, atol=1e-13)
 
 
+def test_backtest_short_aligned_groups_beside_a_long_one(pq, oracle):
+    """A ragged batch sizes the chunk length C for its LONGEST group (3200 rows -> C = 50): a 128- or 130-row group starting on a
+    16-byte boundary then owns LDS rows up to 150 that its own staging must fill (round-3 advisor finding: the aligned staging
+    stopped at row 128 and the last live lane walked stale LDS -- the previous workgroup's equity row -- into spurious signals).
+    Many short groups behind long ones, so that every workgroup inherits poisoned LDS."""
+    from polars_quant_amd import api
+    lens = np.array([3200, 128, 130, 128, 3200, 130, 128, 2, 128, 130, 64, 128, 3200] + [128, 130] * 40, dtype=np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    assert all(o % 2 == 0 for o in off)       # every group starts 16-byte aligned: the double2 staging path
+    close = np.ascontiguousarray(oracle.gen_ohlcv(SEED + 7, 1, int(off[-1]), 0)["close"][0])
+    for rep in range(2):                       # second pass: LDS holds the first pass's equity / returns rows
+        pos, cash, eq, summ = (t.cpu().numpy() for t in api.backtest_macd_cross(torch.from_numpy(close).cuda(), offsets=off))
+        for s in range(len(lens)):
+            lo, hi = off[s], off[s + 1]
+            eb, es_ = oracle.macd_cross_signals(close[lo:hi])
+            ep, ec, ee, es2 = oracle.backtest(close[lo:hi], eb, es_)
+            assert (bits(pos[lo:hi]) == bits(ep)).all() and (bits(cash[lo:hi]) == bits(ec)).all() and (bits(eq[lo:hi]) == bits(ee)).all(), (rep, s)
+            for k in (1, 5, 6, 7):             # max_drawdown, max_profit, win_rate, total_trades
+                assert bits(summ[s, k:k + 1])[0] == bits(es2[k:k + 1])[0], (rep, s, k, summ[s], es2)
+            np.testing.assert_allclose(summ[s], es2, rtol=1e-12, atol=1e-13)
+
+
 def test_recorded_suite_on_a_ragged_batch(pq, oracle, groups):
     """pq_suite_begin / end on a ragged batch: sequential jobs (per-lane body: ragged series start at arbitrary rows), the fused
     row-parallel grid, the pattern kernel and the wave-per-symbol backtest replay from one recorded plan; every group equals the
