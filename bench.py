@@ -61,14 +61,20 @@ def cpu_baseline(sample_syms: int, T: int):
     from oracle import pq_oracle as oracle   # the ONLY use of oracle/ here: the timed CPU baseline leg
     from polars_quant_amd.synthetic import gen_ohlcv
     d = gen_ohlcv(SEED, sample_syms, T, 0)
-    cores = len(os.sched_getaffinity(0))
+    avail = len(os.sched_getaffinity(0))
     native = oracle.native_lib() is not None
-    oracle.suite_bench({k: v[:2 * cores] for k, v in d.items()}, cores, native=native)  # spin up the OpenMP team
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        oracle.suite_bench(d, cores, native=native)
-    t_all = (time.perf_counter() - t0) / reps
+    # "all cores" = every core this process may use; a GPU box gives a job a CPU SHARE smaller than the affinity mask (the first
+    # run on 256 threads was slower than 16): the thread count is swept over {16, 32, 64, all} and the best one reported as `cores`
+    reps, best = 3, None
+    for cores in sorted({min(c, avail) for c in (16, 32, 64, avail)}):
+        oracle.suite_bench({k: v[:2 * cores] for k, v in d.items()}, cores, native=native)  # spin up the OpenMP team
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.suite_bench(d, cores, native=native)
+        t = (time.perf_counter() - t0) / reps
+        if best is None or t < best[0]:
+            best = (t, cores)
+    t_all, cores = best
     small = {k: v[: max(8, sample_syms // 16)] for k, v in d.items()}
     t0 = time.perf_counter(); oracle.suite_bench(small, 1, native=native); t_one = time.perf_counter() - t0
     rows = sample_syms * T
@@ -83,7 +89,7 @@ def cpu_baseline(sample_syms: int, T: int):
     return {"value": rows / t_all, "unit": "rows/s", "cores": cores, "kind": "port",
             "sample": f"{sample_syms} symbols x {T} days (the bench's own data set), same suite+backtest, mean of {reps} passes; oracle = scalar C "
                       f"restatement of the reference (the Rust reference cannot be built here), {cc}, {flags}, "
-                      f"OpenMP over symbols on {cores} threads of '{cpu}'",
+                      f"OpenMP over symbols on {cores} threads (best of 16 / 32 / 64 / all {avail}) of '{cpu}'",
             "value_1thread": small["close"].shape[0] * T / t_one}
 
 

@@ -289,6 +289,15 @@ pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close,
  * its predecessor's state, so results are exact either way).  out3 (host): [0] symbols processed that way since the last
  * reset, [1] chunks that failed the bit test, [2] chunk re-runs.  Synchronises the context's stream. */
 pq_status pq_backtest_wave_stats(pq_ctx *, int64_t *out3, int32_t reset);
+/* The contractive recurrences of the indicator suite -- calc_ema (overlap.rs:660-730) and its cascades DEMA / TEMA / TRIX, MACD
+ * (momentum.rs:250-283), Wilder's calc_rma behind RSI (momentum.rs:507-541), +DM / -DM, DX / DI / ADX / ADXR (momentum.rs:668-727),
+ * ATR / NATR (volatility.rs:18-48) -- and the extrema of MIDPOINT / MIDPRICE run ONE SYMBOL PER WAVEFRONT on regular, aligned
+ * batches with 1 024 <= len <= 4 096 (csrc/wt_dev.h): 64 row chunks per symbol, started from prefix-scanned seeds, whose hand-over
+ * states are compared bit for bit (a chunk that fails is re-run from its predecessor's state: results are the serial walk's either
+ * way).  A symbol with a NULL / NaN input is left to the lane-per-symbol kernel of the same function, launched gated behind.
+ * out4 (host): [0] symbols computed that way since the last reset, [1] chunks that failed the bit test, [2] chunk re-runs,
+ * [3] symbols handed to the gated general path.  Synchronises the context's stream. */
+pq_status pq_wt_stats(pq_ctx *, int64_t *out4, int32_t reset);
 
 /* ---- multi-GPU: symbols are split statically over the ranks -- rank r of G owns [floor(N r / G), floor(N (r + 1) / G)),
  * a contiguous byte range of every symbol-major column -- and every rank runs the calls above on its own shard with no

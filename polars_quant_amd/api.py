@@ -345,6 +345,16 @@ def backtest_wave_stats(reset: bool = False, device=None):
     return tuple(int(v) for v in out)
 
 
+def wt_stats(reset: bool = False, device=None):
+    """(symbols computed by the wave-per-symbol indicator kernels, speculative chunks that failed the bit test, chunk re-runs,
+    symbols handed to the gated lane-per-symbol path) since the last reset -- pq_wt_stats (csrc/wt_dev.h).  Synchronises."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = (C.c_int64 * 4)()
+    with torch.cuda.device(dev):
+        check(lib().pq_wt_stats(ctx(dev.index), out, 1 if reset else 0))
+    return tuple(int(v) for v in out)
+
+
 def factor_ic(factor, fwd_return, method: int = 0):
     """D-12: per-day cross-sectional IC of factor vs forward return, both [N, T] -> (ic [T], n_valid [T]) device tensors.
     method 0 = Pearson IC, 1 = Spearman Rank-IC"""

@@ -2,6 +2,7 @@
 // the chained launches through scratch columns otherwise (very long windows, unaligned columns, MA types that are
 // themselves multi-pass).  Both forms are bit-identical.
 #include "ops_fused.h"
+#include "wt_api.h"
 
 extern "C" {
 pq_status pq_trima_chain(pq_ctx *, const pq_batch *, const double *, int64_t, double *);
@@ -86,6 +87,7 @@ pq_status pq_cci(pq_ctx *ctx, const pq_batch *b, const double *h, const double *
 }
 pq_status pq_adxr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *out) {
     CHK("pq_adxr", h && l && c && out);
+    { pq_status st; if (wt_dmi(ctx, b, h, l, c, p, nullptr, nullptr, nullptr, nullptr, out, &st)) return st; }
     DmAllOp<false> op{}; op.p = p;
     InCols<3> in{{h, l, c}}; OutCols<1> o{{out}};
     if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
@@ -95,6 +97,7 @@ pq_status pq_adxr(pq_ctx *ctx, const pq_batch *b, const double *h, const double 
 pq_status pq_dmi_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                      double *dx, double *plus_di, double *minus_di, double *adx, double *adxr) {
     CHK("pq_dmi_all", h && l && c && dx && plus_di && minus_di && adx && adxr);
+    { pq_status st; if (wt_dmi(ctx, b, h, l, c, p, dx, plus_di, minus_di, adx, adxr, &st)) return st; }
     DmAllOp<true> op{}; op.p = p;
     InCols<3> in{{h, l, c}}; OutCols<5> o{{dx, plus_di, minus_di, adx, adxr}};
     if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
@@ -124,6 +127,7 @@ pq_status pq_ht_all(pq_ctx *ctx, const pq_batch *b, const double *real, double *
 // ---- multi-output forms: several reference functions over the same inputs as ONE job (bit-identical columns) ----
 pq_status pq_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *ema, double *dema, double *tema, double *trix) {
     CHK("pq_ema_all", real && ema && dema && tema && trix);
+    { pq_status st; if (wt_ema_all(ctx, b, real, p, ema, dema, tema, trix, &st)) return st; } // one symbol per wavefront (ops_wt.h)
     EmaAllOp op{};
     op.a.a.p = p; op.a.b.p = p; op.b.a.p = p; op.b.b.p = p;
     InCols<1> in{{real}}; OutCols<4> o{{ema, dema, tema, trix}};
@@ -133,6 +137,7 @@ pq_status pq_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
 }
 pq_status pq_atr_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *atr, double *natr) {
     CHK("pq_atr_all", h && l && c && atr && natr);
+    { pq_status st; if (wt_atr(ctx, b, h, l, c, p, atr, natr, &st)) return st; }
     AtrAllOp op{}; op.a.p = p; op.b.p = p;
     InCols<3> in{{h, l, c}}; OutCols<2> o{{atr, natr}};
     if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
@@ -141,6 +146,7 @@ pq_status pq_atr_all(pq_ctx *ctx, const pq_batch *b, const double *h, const doub
 }
 pq_status pq_dm_pair(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *plus_dm, double *minus_dm) {
     CHK("pq_dm_pair", h && l && plus_dm && minus_dm);
+    { pq_status st; if (wt_dm_pair(ctx, b, h, l, p, plus_dm, minus_dm, &st)) return st; }
     DmPairOp op{}; op.a.p = p; op.b.p = p;
     InCols<2> in{{h, l}}; OutCols<2> o{{plus_dm, minus_dm}};
     if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
@@ -159,6 +165,7 @@ pq_status pq_ad_all(pq_ctx *ctx, const pq_batch *b, const double *h, const doubl
 pq_status pq_macd_pair(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t sig, int64_t fix_sig,
                        double *macd, double *signal, double *hist, double *fmacd, double *fsignal, double *fhist) {
     CHK("pq_macd_pair", real && macd && signal && hist && fmacd && fsignal && fhist);
+    { pq_status st; if (wt_macd(ctx, b, real, fast, slow, sig, fix_sig, macd, signal, hist, fmacd, fsignal, fhist, &st)) return st; }
     MacdPairOp op{};
     op.a.fast = fast; op.a.slow = slow; op.a.sig = sig; op.b.fast = 12; op.b.slow = 26; op.b.sig = fix_sig; // momentum.py:90-92
     InCols<1> in{{real}}; OutCols<6> o{{macd, signal, hist, fmacd, fsignal, fhist}};
@@ -194,6 +201,13 @@ pq_status pq_volume_all(pq_ctx *ctx, const pq_batch *b, const double *h, const d
 pq_status pq_dm_system_all(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *dx,
                            double *plus_di, double *minus_di, double *adx, double *adxr, double *atr, double *natr) {
     CHK("pq_dm_system_all", h && l && c && dx && plus_di && minus_di && adx && adxr && atr && natr);
+    {   // wave-per-symbol form: two jobs (the DI / DX / ADX chains need three LDS columns, ATR / NATR one)
+        pq_status st;
+        if (wt_dmi(ctx, b, h, l, c, p, dx, plus_di, minus_di, adx, adxr, &st)) {
+            PQ_TRY(st);
+            return pq_atr_all(ctx, b, h, l, c, p, atr, natr);
+        }
+    }
     DmiAtrOp op{}; op.a.p = p; op.b.a.p = p; op.b.b.p = p;
     InCols<3> in{{h, l, c}}; OutCols<7> o{{dx, plus_di, minus_di, adx, adxr, atr, natr}};
     if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);
@@ -202,6 +216,10 @@ pq_status pq_dm_system_all(pq_ctx *ctx, const pq_batch *b, const double *h, cons
 }
 pq_status pq_cmo_rsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *cmo, double *rsi) {
     CHK("pq_cmo_rsi", real && cmo && rsi);
+    {   // RSI's Wilder averages contract (wave-per-symbol form); CMO's rolling sums do not: it stays a lane-per-symbol job
+        pq_status st;
+        if (wt_rsi(ctx, b, real, p, rsi, &st)) { PQ_TRY(st); return pq_cmo(ctx, b, real, p, cmo); }
+    }
     CmoRsiOp op{}; op.a.p = p; op.b.p = p;
     InCols<1> in{{real}}; OutCols<2> o{{cmo, rsi}};
     if (seq_can_lds(b, op, in, o)) return launch_seq(ctx, b, op, in, o);

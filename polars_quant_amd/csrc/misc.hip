@@ -1,6 +1,7 @@
 // misc.hip -- kernels + C ABI for volatility / volume / price transforms and the Hilbert-transform
 // cycle indicators (reference: src/talib/{volatility,volume,price,cycle}.rs) plus MAMA (D-4).
 #include "ops_misc.h"
+#include "wt_api.h"
 
 // ---------------------------------------------------------------- C ABI
 #define CHK(name, cond) PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(cond, name ": null pointer")
@@ -30,12 +31,14 @@ pq_status pq_trange(pq_ctx *ctx, const pq_batch *b, const double *h, const doubl
 pq_status pq_atr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                  double *out) {
     CHK("pq_atr", h && l && c && out);
+    { pq_status st; if (wt_atr(ctx, b, h, l, c, p, out, nullptr, &st)) return st; }
     AtrOp<false> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});
 }
 pq_status pq_natr(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p,
                   double *out) {
     CHK("pq_natr", h && l && c && out);
+    { pq_status st; if (wt_atr(ctx, b, h, l, c, p, nullptr, out, &st)) return st; }
     AtrOp<true> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});
 }

@@ -3,6 +3,7 @@
 // momentum.rs functions are N-B (nulls rejected, momentum.rs:12-13): inputs are assumed null-free
 // here; the host layer calls pq_count_nulls first and raises like the reference does.
 #include "ops_momentum.h"
+#include "wt_api.h"
 
 // ---------------------------------------------------------------- C ABI
 #define CHK(name, cond) PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(cond, name ": null pointer")
@@ -81,12 +82,14 @@ pq_status pq_cmo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, 
 }
 pq_status pq_rsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     CHK("pq_rsi", real && out);
+    { pq_status st; if (wt_rsi(ctx, b, real, p, out, &st)) return st; }
     RsiOp op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<1>{{out}});
 }
 pq_status pq_macd(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, int64_t slow, int64_t sig,
                   double *macd, double *signal, double *hist) {
     CHK("pq_macd", real && macd && signal && hist);
+    { pq_status st; if (wt_macd(ctx, b, real, fast, slow, sig, sig, macd, signal, hist, nullptr, nullptr, nullptr, &st)) return st; }
     MacdOp op{}; op.fast = fast; op.slow = slow; op.sig = sig;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<3>{{macd, signal, hist}});
 }
@@ -96,6 +99,7 @@ pq_status pq_macdfix(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
 }
 pq_status pq_trix(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     CHK("pq_trix", real && out);
+    { pq_status st; if (wt_ema_all(ctx, b, real, p, nullptr, nullptr, nullptr, out, &st)) return st; }
     TrixOp op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<1>{{real}}, OutCols<1>{{out}});
 }
@@ -115,6 +119,7 @@ pq_status pq_mfi(pq_ctx *ctx, const pq_batch *b, const double *h, const double *
     pq_status name(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, \
                    double *out) {                                                                              \
         CHK(#name, h && l && c && out);                                                                        \
+        { pq_status st; if (wt_dmi(ctx, b, h, l, c, p, MODE == 0 ? out : nullptr, nullptr, MODE == 1 ? out : nullptr, MODE == 2 ? out : nullptr, nullptr, &st)) return st; } \
         DmOp<MODE> op{}; op.p = p;                                                                               \
         return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});                                \
     }
@@ -133,11 +138,13 @@ pq_status pq_adxr_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const d
 }
 pq_status pq_plus_dm(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *out) {
     CHK("pq_plus_dm", h && l && out);
+    { pq_status st; if (wt_dm_pair(ctx, b, h, l, p, out, nullptr, &st)) return st; }
     DmRawOp<true> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<2>{{h, l}}, OutCols<1>{{out}});
 }
 pq_status pq_minus_dm(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *out) {
     CHK("pq_minus_dm", h && l && out);
+    { pq_status st; if (wt_dm_pair(ctx, b, h, l, p, nullptr, out, &st)) return st; }
     DmRawOp<false> op{}; op.p = p;
     return launch_seq(ctx, b, op, InCols<2>{{h, l}}, OutCols<1>{{out}});
 }

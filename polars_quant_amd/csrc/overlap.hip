@@ -1,6 +1,7 @@
 // overlap.hip -- SEQ kernels + C ABI for the overlap studies (reference: src/talib/overlap.rs).
 // One series per lane, reference operation order, null-transparent streaming (N-A).
 #include "ops_fused.h"
+#include "wt_api.h"
 
 // ---------------------------------------------------------------- C ABI
 #define IN1(a) InCols<1>{{a}}
@@ -26,6 +27,7 @@ pq_status pq_sma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, 
 }
 pq_status pq_ema(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_ema: null pointer");
+    { pq_status st; if (wt_ema_all(ctx, b, real, p, out, nullptr, nullptr, nullptr, &st)) return st; }
     EmaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
@@ -37,11 +39,13 @@ pq_status pq_bbands(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t 
 }
 pq_status pq_dema(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_dema: null pointer");
+    { pq_status st; if (wt_ema_all(ctx, b, real, p, nullptr, out, nullptr, nullptr, &st)) return st; }
     DemaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_tema(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_tema: null pointer");
+    { pq_status st; if (wt_ema_all(ctx, b, real, p, nullptr, nullptr, out, nullptr, &st)) return st; }
     TemaOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
@@ -85,11 +89,13 @@ pq_status pq_ma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, i
 }
 pq_status pq_midpoint(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && out, "pq_midpoint: null pointer");
+    { pq_status st; if (wt_midpoint(ctx, b, real, p, out, &st)) return st; }
     MidpointOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN1(real), OUT1(out));
 }
 pq_status pq_midprice(pq_ctx *ctx, const pq_batch *b, const double *high, const double *low, int64_t p, double *out) {
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(high && low && out, "pq_midprice: null pointer");
+    { pq_status st; if (wt_midprice(ctx, b, high, low, p, out, &st)) return st; }
     MidpriceOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN2(high, low), OUT1(out));
 }

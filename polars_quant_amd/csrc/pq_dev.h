@@ -31,6 +31,8 @@ struct pq_ctx {
     Recorder *rec;   // non-null while a suite is being recorded
     void *comm;      // ncclComm_t of pq_comm_init (comm.hip), or null
     int comm_rank, comm_world;
+    unsigned *wt_gate = nullptr; // [wt_gate_tiles] flags of the wave-per-symbol kernels' direct launches (ops_wt.h): tiles the gated general path redoes
+    size_t wt_gate_tiles = 0;
 };
 
 void pq_set_error(const char *fmt, ...);
@@ -774,7 +776,16 @@ template <class Op, bool LDS>
 #ifndef PQ_SEQ_MIN_WAVES
 #define PQ_SEQ_MIN_WAVES 1 // analysis builds: 3 = compile every stand-alone op kernel under the light job kernel's register cap
 #endif
-PQ_HOOK_SEQ_KERNEL_ATTR __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK, PQ_SEQ_MIN_WAVES) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d) {
+PQ_HOOK_SEQ_KERNEL_ATTR __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_BLOCK, PQ_SEQ_MIN_WAVES) void seq_kernel(Op op, InCols<Op::NIN> in, OutCols<Op::NOUT> out, Dims d,
+                                                                                                                          unsigned *gate) {
+    // gate (nullable): this launch stands behind a wave-per-symbol launch of the same function (ops_wt.h) and redoes only the
+    // 64-symbol tiles that one has flagged (a symbol with a NULL / NaN input); it clears the flag it consumed
+    if (gate) {
+        const unsigned g = gate[blockIdx.x];
+        if (!g) return;
+        __syncthreads();
+        if (threadIdx.x == 0) gate[blockIdx.x] = 0;
+    }
     if constexpr (LDS) {
         extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
         run_seq_lds(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
@@ -814,6 +825,8 @@ struct RowThunk { // type-erased ROW launch for replay
     int n_reads;
     void *writes[64];
     int n_writes;
+    int wt_cols = 0;     // > 0: a wave-per-symbol job (ops_wt.h) that moves this many f64 columns; the suite schedules it as sequential work
+    int wt_alg_cols = 0; // f64 column transfers credited (per reference call)
 };
 pq_status rec_add_row(pq_ctx *ctx, const RowThunk &t);
 void rec_set_shared_out(pq_ctx *ctx, bool on); // jobs recorded while on may write disjoint rows of one column
@@ -870,8 +883,8 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
         }
     }
     dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
-    if (use_lds) hipLaunchKernelGGL((seq_kernel<Op, true>), grid, dim3(SEQ_LDS_BLOCK), lds, ctx->stream, op, in, out, dims_of(b));
-    else hipLaunchKernelGGL((seq_kernel<Op, false>), grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b));
+    if (use_lds) hipLaunchKernelGGL((seq_kernel<Op, true>), grid, dim3(SEQ_LDS_BLOCK), lds, ctx->stream, op, in, out, dims_of(b), (unsigned *)nullptr);
+    else hipLaunchKernelGGL((seq_kernel<Op, false>), grid, dim3(SEQ_BLOCK), 0, ctx->stream, op, in, out, dims_of(b), (unsigned *)nullptr);
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }

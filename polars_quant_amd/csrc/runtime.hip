@@ -104,8 +104,8 @@ pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out) {
     c->comm_world = 0;
     c->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
     c->own_stream = false;
-    hipError_t e = hipMalloc((void **)&c->d_flag, 32 * sizeof(int64_t)); // [0] reduction scalar, [4..6] wave-backtest statistics (+ [8..23] profiling builds)
-    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 32 * sizeof(int64_t));
+    hipError_t e = hipMalloc((void **)&c->d_flag, 64 * sizeof(int64_t)); // [0] reduction scalar, [4..6] wave-backtest statistics (+ [8..23] profiling builds), [24..27] wave-per-symbol indicators (+ [32..63] profiling builds)
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 64 * sizeof(int64_t));
     if (e != hipSuccess) { if (c->own_stream) (void)hipStreamDestroy(c->stream); delete c; pq_set_error("hipMalloc: %s", hipGetErrorString(e)); return PQ_ERR_NOMEM; }
     *out = c;
     return PQ_OK;
@@ -117,6 +117,7 @@ pq_status pq_ctx_destroy(pq_ctx *ctx) {
     if (ctx->comm) (void)pq_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    if (ctx->wt_gate) (void)hipFree(ctx->wt_gate);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PQ_OK;

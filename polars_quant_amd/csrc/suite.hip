@@ -387,7 +387,8 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             if (!j.heavy) widest = std::max(widest, j.lds_bytes);
             cmax = std::max(cmax, j.cost);
         }
-        const double long_fill = std::max(1.0, (double)(prop.maxSharedMemoryPerMultiProcessor / widest) - 0.5);
+        double long_fill = std::max(1.0, (double)(prop.maxSharedMemoryPerMultiProcessor / widest) - 0.5);
+        if (const char *e = getenv("PQ_LONG_FILL")) long_fill = atof(e); // A/B runs: workgroups per CU placed in the LONG grid (large: one grid for every light job)
         const double long_budget = long_fill * (double)prop.multiProcessorCount;
         // the longest jobs are the critical path of a step: their waves win the issue arbitration against shorter jobs on the same
         // SIMD.  Relative to the longest job of the phase (>= 0.8 / 0.58 / 0.4 of it), not to absolute microseconds.
@@ -634,6 +635,13 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
     r.scratch.clear();
 }
 
+void *rec_alloc_zero(pq_ctx *ctx, size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes ? bytes : 4) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    ctx->rec->scratch.push_back(p);
+    return p;
+}
 double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k) {
     size_t col = batch_rows(b);
     if (ctx->rec) { // fresh column per request, owned by the suite
