@@ -524,6 +524,29 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
     }
 };
 
+// MIDPRICE as a ROW op: its value is a pure function of the last p VALID highs / lows up to the row (the front of the reference's
+// monotonic deques, overlap.rs:325-345 / :378-398, holds exactly their extremum; extrema are exact in any order), so it needs no
+// serial walk: thread per row, the window from L1 -- one more job of the suite's fused ROW grid instead of a lane-per-symbol job
+// with 39 KB of LDS rings (1.04 ms alone at 5 000 x 2 520, the most expensive one-column job of a step).
+struct MidpriceRowOp {
+    static constexpr int NIN = 2, NOUT = 1;
+    static constexpr int ROW_ID = 18;
+    typedef double OutT;
+    int64_t p;
+    __device__ void eval(const Row<2> &r, int64_t t, double (&y)[1]) {
+        y[0] = pq_null();
+        if (p <= 0) return;                                   // decision D-7b
+        const double h0 = r.in[0][t], l0 = r.in[1][t];
+        if (pq_isnull(h0) || pq_isnull(l0)) return;          // a null in either input -> null row (D-7)
+        double mx = h0, mn = l0;
+        int64_t cnt = 1;
+        for (int64_t j = t - 1; j >= 0 && cnt < p; j--) { const double v = r.in[0][j]; if (!pq_isnull(v)) { mx = fmax(mx, v); cnt++; } }
+        cnt = 1;
+        for (int64_t j = t - 1; j >= 0 && cnt < p; j--) { const double v = r.in[1][j]; if (!pq_isnull(v)) { mn = fmin(mn, v); cnt++; } }
+        y[0] = (mx + mn) / 2.0;                               // overlap.rs:401
+    }
+};
+
 // SAR / SAREXT (decision D-4: TA-Lib algorithm; nulls -> 0.0 as overlap.rs:445-450)
 __device__ __forceinline__ double n0(double x) { return pq_isnull(x) ? 0.0 : x; }
 

@@ -295,7 +295,7 @@ constexpr int ROW_FUSE_BLOB = 176;
 struct RowJobDev { int kind; int pad; unsigned char blob[ROW_FUSE_BLOB]; };
 #define ROW_OPS(X)                                                                                                             \
     X(PriceOp<0>) X(PriceOp<1>) X(PriceOp<2>) X(PriceOp<3>) X(TrangeOp) X(TrendlineOp) X(TrendmodeOp) X(LagOp<0>) X(LagOp<1>) \
-    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(AroonOp<2>) X(WillrOp)
+    X(LagOp<2>) X(LagOp<3>) X(LagOp<4>) X(BopOp) X(AroonOp<0>) X(AroonOp<1>) X(AroonOp<2>) X(WillrOp) X(MidpriceRowOp)
 __global__ __launch_bounds__(ROW_BLOCK) void row_jobs_kernel(const RowJobDev *jobs, int n_jobs, Dims d, int64_t s_base) {
     const int64_t s = s_base + blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * ROW_BLOCK + threadIdx.x;

@@ -21,6 +21,7 @@ SHAPES = [(70, 1024), (130, 2520), (66, 4096), (5, 1501), (3, 1027)]   # C = 16 
 def every_wave_form(monkeypatch):
     """the library uses by default only the wave forms that beat the lane-per-symbol body they replace (csrc/wt.hip); here all"""
     monkeypatch.setenv("PQ_WT_ALL", "1")
+    monkeypatch.setenv("PQ_MIDPRICE_SEQ", "1")     # (a direct MIDPRICE call is a ROW launch by default: csrc/overlap.hip)
 
 
 @pytest.fixture(scope="module")
@@ -203,10 +204,11 @@ def test_short_warm_up_forces_re_runs_and_stays_exact(pq, oracle, monkeypatch):
 def test_default_policy_uses_the_forms_that_win(pq, oracle, monkeypatch):
     from polars_quant_amd import api
     monkeypatch.delenv("PQ_WT_ALL")
+    monkeypatch.delenv("PQ_MIDPRICE_SEQ")
     d = oracle.gen_ohlcv(SEED + 6, 64, 2520, 0)
     g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
     for nm, cols, used in (("ema", ("close",), True), ("trix", ("close",), True), ("rsi", ("close",), True), ("atr", ("high", "low", "close"), True),
-                           ("midprice", ("high", "low"), True), ("tema", ("close",), False), ("macd", ("close",), False), ("adx", ("high", "low", "close"), False)):
+                           ("midpoint", ("close",), True), ("midprice", ("high", "low"), False), ("tema", ("close",), False), ("macd", ("close",), False), ("adx", ("high", "low", "close"), False)):
         api.wt_stats(reset=True)
         got = api.call(nm, *[g[c] for c in cols])
         assert (api.wt_stats()[0] == 64) == used, nm
