@@ -409,7 +409,7 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
     // kernels recorded in place of their jobs against 4.0 ms).  PQ_WT_SUITE=1 records them anyway (A/B runs).
     if (ctx->rec && !getenv("PQ_WT_SUITE")) return false;
     if (!wt_on() || !wt_op_on(WtOp::NAME) || b->offsets || b->len < WT_MIN_LEN || b->len > WT_MAX_LEN || b->n_series <= 0 || b->n_series > 0x7fffffffLL) return false;
-    if (!seq_can_lds(b, sop, in, out)) return false; // the gated general path is the tiled body
+    if (seq_lds_bytes(sop) > SEQ_LDS_LIMIT || seq_cols_tiling<SeqOp::NIN, SeqOp::NOUT>(b, in.p, out.p) != 0) return false; // the gated general path is the (16-byte) tiled body
     WtBlob<WtOp, SeqOp> w{};
     const int T = (int)b->len;
     w.a.C = (T + 63) / 64;

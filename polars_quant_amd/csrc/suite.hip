@@ -22,6 +22,7 @@ struct SeqJob { // device-visible
     int heavy, masked;
     int cls;                   // CLS_*: the grid the job runs in (suite_finalize)
     int prio;                  // s_setprio of the job's waves: by its cost relative to the longest job of the phase (suite_finalize)
+    int unal;                  // rows only 8-byte aligned: the grid of its class runs the 8-byte form of the tiled body (seq_jobs_kernel<3>)
     double summary_bytes;
     int alg_cols;                  // f64 column transfers credited (per reference call)
     unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
@@ -141,7 +142,7 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
         __builtin_memcpy(&op, job.op, sizeof(OP));                                                                   \
         if constexpr (V == 2) run_seq(op, job.in, job.out, d, s);                                                    \
         else                                                                                                         \
-            run_seq_lds(op, job.in, job.out, d, s0, jobs_lds); \
+            run_seq_lds<OP, V == 3>(op, job.in, job.out, d, s0, jobs_lds); \
     } break;
     // the two lists must agree with the ops' HEAVY trait (which is what the class assignment in suite_finalize looks at)
 #define XL(OP) static_assert(!IsHeavy<OP>::value, "light list holds an op marked HEAVY"); X(OP)
@@ -180,7 +181,7 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
-template <int V>
+template <int V> // 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 3: light ops, tiled, rows only 8-byte aligned (UNAL)
 __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<V>(jobs, d, dbg, wg);
 }
@@ -243,6 +244,7 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
     memset(&j, 0, sizeof j);
     j.kind = tr.kind; j.nin = nin; j.nout = nout; j.cost = tr.cost; j.heavy = tr.heavy; j.masked = tr.masked;
     j.lds_bytes = (unsigned)tr.lds_bytes; j.tile_bytes = (unsigned)tr.tile_bytes;
+    j.unal = tr.unal ? 1 : 0;
     j.alg_cols = tr.alg_cols > 0 ? tr.alg_cols : nin + nout;
     j.summary_bytes = tr.summary_bytes_per_series;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
@@ -519,8 +521,11 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             PQ_HIP_TRY(timed(p.gs[c], st, true));
             unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
             const dim3 grid(tiles, (unsigned)nj);
-            const int v = k_variant[c];
-            if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
+            int v = k_variant[c];
+            if (v == 0) // one job with 8-byte rows: the whole grid runs the 8-byte form (it handles aligned columns as well)
+                for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) v = 3;
+            if (v == 3) hipLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
+            else if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
             else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             PQ_HIP_TRY(timed(p.gs[c], st, false));
@@ -789,6 +794,8 @@ pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
             if ((c < NCLS ? p.gs[c] : p.gs_row).n_jobs == 0) continue;
             if (idx++ != k) continue;
             *variant = c < NCLS ? k_variant[c] : 3; // 3 = the chain of ROW launches
+            if (c < NCLS && k_variant[c] == 0)
+                for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) *variant = 4; // 4 = seq_jobs_kernel<3>: the 8-byte form of the tiled body
             return PQ_OK;
         }
     pq_set_error("pq_suite_grid_variant: grid index out of range");

@@ -79,7 +79,7 @@ def test_single_functions(pq, oracle, data, name, cols, prm):
     st = api.wt_stats()
     n = data["close"].shape[0]
     # outside the form's scope (the gated general path must be the tiled body): rings above 64 KB, an odd row pitch
-    outside = (name == "midprice" and prm.get("timeperiod", 0) > 30) or data["close"].shape[1] % 2 == 1
+    outside = (name == "midprice" and prm.get("timeperiod", 0) > 30) or data["close"].shape[1] % 2 == 1   # (an odd pitch runs the 8-byte tiled body)
     assert (st == (0, 0, 0, 0)) if outside else (st[0] == n and st[3] == 0), f"the wave form did not run: {st}"
     exp = oracle.call(name, *[data[c] for c in cols], **prm)
     for k, (g, e) in enumerate(zip(got, exp)):
