@@ -388,6 +388,7 @@ struct WtBlob {
     OutCols<SeqOp::NOUT> out;
     pq_batch b;
     unsigned lds_wt, lds_seq;
+    int gather; // the gated general path is the per-lane gather body (ragged batches)
 };
 template <class WtOp, class SeqOp>
 static void wt_launch_blob(const void *blob, hipStream_t stream) {
@@ -397,8 +398,14 @@ static void wt_launch_blob(const void *blob, hipStream_t stream) {
         return;
     hipLaunchKernelGGL(wt_kernel<WtOp>, dim3((unsigned)w.b.n_series), dim3(64), w.lds_wt, stream, w.wop, w.a, dims_of(&w.b));
     // the general path, gated: a workgroup whose tile is not flagged returns at once
-    hipLaunchKernelGGL((seq_kernel<SeqOp, true>), dim3((unsigned)((w.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK)), dim3(SEQ_LDS_BLOCK), w.lds_seq, stream, w.sop,
-                       w.in, w.out, dims_of(&w.b), w.a.gate);
+    const dim3 tiles((unsigned)((w.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
+    if constexpr (!IsLdsOnly<SeqOp>::value) {
+        if (w.gather) {
+            hipLaunchKernelGGL((seq_kernel<SeqOp, false>), tiles, dim3(SEQ_BLOCK), 0, stream, w.sop, w.in, w.out, dims_of(&w.b), w.a.gate);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((seq_kernel<SeqOp, true>), tiles, dim3(SEQ_LDS_BLOCK), w.lds_seq, stream, w.sop, w.in, w.out, dims_of(&w.b), w.a.gate);
 }
 // true: handled (launched or recorded; *st holds the status).  false: outside the wave form's scope -- the caller takes its usual path.
 template <class WtOp, class SeqOp>
@@ -408,8 +415,20 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
     // wave-per-symbol job holds 21 KB of LDS per column and symbol (measured at 5 000 x 2 520: the step takes 6.6 ms with these
     // kernels recorded in place of their jobs against 4.0 ms).  PQ_WT_SUITE=1 records them anyway (A/B runs).
     if (ctx->rec && !getenv("PQ_WT_SUITE")) return false;
-    if (!wt_on() || !wt_op_on(WtOp::NAME) || b->offsets || b->len < WT_MIN_LEN || b->len > WT_MAX_LEN || b->n_series <= 0 || b->n_series > 0x7fffffffLL) return false;
-    if (seq_lds_bytes(sop) > SEQ_LDS_LIMIT || seq_cols_tiling<SeqOp::NIN, SeqOp::NOUT>(b, in.p, out.p) != 0) return false; // the gated general path is the (16-byte) tiled body
+    if (!wt_on() || !wt_op_on(WtOp::NAME) || b->len > WT_MAX_LEN || b->n_series <= 0 || b->n_series > 0x7fffffffLL) return false;
+    const bool ragged = b->offsets != nullptr;
+    if (ragged) {
+        // RAGGED batches (the groups of `.over("symbol")`: pq_batch.offsets) would otherwise run the per-lane gather body, the slowest
+        // shape of the library; a wavefront per group takes any length and any 8-byte aligned start.  Worth it when the groups are
+        // long on average (a wave costs ~250 serial steps per chain whatever its group's length); the gated general path is the gather
+        // body, so the function must have one (the fused multi-output forms do not: their entry points take ragged batches apart).
+        if (IsLdsOnly<SeqOp>::value || b->stride / b->n_series < WT_MIN_LEN) return false; // (stride = the total row count of a ragged batch)
+        for (int k = 0; k < SeqOp::NIN; k++) if (reinterpret_cast<uintptr_t>(in.p[k]) % 8) return false;
+        for (int k = 0; k < SeqOp::NOUT; k++) if (reinterpret_cast<uintptr_t>(out.p[k]) % 8) return false;
+    } else {
+        if (b->len < WT_MIN_LEN) return false;
+        if (seq_lds_bytes(sop) > SEQ_LDS_LIMIT || seq_cols_tiling<SeqOp::NIN, SeqOp::NOUT>(b, in.p, out.p) != 0) return false; // the gated general path is the (16-byte) tiled body
+    }
     WtBlob<WtOp, SeqOp> w{};
     const int T = (int)b->len;
     w.a.C = (T + 63) / 64;
@@ -420,6 +439,7 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
     w.lds_wt = (unsigned)((size_t)WtOp::NCOL * 64 * w.a.P * 8);
     if (w.lds_wt > 160 * 1024) return false;
     w.lds_seq = (unsigned)seq_lds_bytes(sop);
+    w.gather = ragged ? 1 : 0;
     w.wop = wop; w.sop = sop; w.in = in; w.out = out; w.b = *b;
     const size_t tiles = (size_t)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
     *st = PQ_OK;

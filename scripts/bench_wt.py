@@ -70,5 +70,37 @@ for name, (cols, fn) in CALLS.items():
     res[name] = {"wave_ms": round(t_wave, 4), "lane_ms": round(t_lane, 4), "columns_GB": round(gb, 3), "wave_TBps": round(gb / t_wave, 3),
                  "lane_TBps": round(gb / t_lane, 3), "failed_chunks_per_call": st[1] / 23, "reruns_per_call": st[2] / 23}
     print(name, res[name], flush=True)
+# the same functions on a RAGGED batch (pq_batch.offsets: the long columns of `.over("symbol")`, here N groups of T rows each, dense):
+# the wave form against the per-lane gather body these batches ran before
+import numpy as np  # noqa: E402
+long_cols = {k: torch.from_numpy(np.ascontiguousarray(v.reshape(-1))).cuda() for k, v in d.items()}
+offs = torch.arange(0, (N + 1) * T, T, dtype=torch.int64, device="cuda")
+rb = Batch(N, T, N * T, C.c_void_p(offs.data_ptr()))
+routs = [torch.empty(N * T, dtype=torch.float64, device="cuda") for _ in range(3)]
+RP = lambda k: C.c_void_p(long_cols[k].data_ptr())
+RV = lambda m: [C.c_void_p(t.data_ptr()) for t in routs[:m]]
+RCALLS = {
+    "ragged ema": (2, lambda: L.pq_ema(h, C.byref(rb), RP("close"), 30, *RV(1))),
+    "ragged trix": (2, lambda: L.pq_trix(h, C.byref(rb), RP("close"), 30, *RV(1))),
+    "ragged rsi": (2, lambda: L.pq_rsi(h, C.byref(rb), RP("close"), 14, *RV(1))),
+    "ragged macd": (4, lambda: L.pq_macd(h, C.byref(rb), RP("close"), 12, 26, 9, *RV(3))),
+    "ragged atr": (4, lambda: L.pq_atr(h, C.byref(rb), RP("high"), RP("low"), RP("close"), 14, *RV(1))),
+    "ragged midpoint": (2, lambda: L.pq_midpoint(h, C.byref(rb), RP("close"), 14, *RV(1))),
+    "ragged tema": (2, lambda: L.pq_tema(h, C.byref(rb), RP("close"), 30, *RV(1))),
+    "ragged dema": (2, lambda: L.pq_dema(h, C.byref(rb), RP("close"), 30, *RV(1))),
+    "ragged adx": (4, lambda: L.pq_adx(h, C.byref(rb), RP("high"), RP("low"), RP("close"), 14, *RV(1))),
+    "ragged dx": (4, lambda: L.pq_dx(h, C.byref(rb), RP("high"), RP("low"), RP("close"), 14, *RV(1))),
+    "ragged plus_dm": (3, lambda: L.pq_plus_dm(h, C.byref(rb), RP("high"), RP("low"), 14, *RV(1))),
+    "ragged natr": (4, lambda: L.pq_natr(h, C.byref(rb), RP("high"), RP("low"), RP("close"), 14, *RV(1))),
+}
+rres = {}
+for name, (cols, fn) in RCALLS.items():
+    os.environ.pop("PQ_NO_WT", None)
+    os.environ["PQ_WT_ALL"] = "1"
+    t_wave = timed(fn, 10)
+    os.environ["PQ_NO_WT"] = "1"
+    t_lane = timed(fn, 5)
+    rres[name] = {"wave_ms": round(t_wave, 4), "gather_ms": round(t_lane, 4)}
+    print(name, rres[name], flush=True)
 os.environ.pop("PQ_NO_WT", None)
-print(json.dumps({"symbols": N, "days": T, "row_pitch_elements": S, "results": res}))
+print(json.dumps({"symbols": N, "days": T, "row_pitch_elements": S, "results": res, "ragged": rres}))

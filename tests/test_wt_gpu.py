@@ -201,6 +201,40 @@ def test_short_warm_up_forces_re_runs_and_stays_exact(pq, oracle, monkeypatch):
     assert st[1] <= 64 * 3, f"too many speculative chunks fail at the default warm-up: {st}"
 
 
+def test_ragged_groups_one_wavefront_each(pq, oracle):
+    """RAGGED batches (pq_batch.offsets: the groups of `.over("symbol")`, any lengths, any starts) in the wave form: every group
+    equals the oracle run on that group alone; groups with a NULL go to the gated gather body; empty and one-row groups are fine"""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(31)
+    lens = np.r_[2520, 1024, 3001, 1, 0, 4096, 700, 2000, 1501, 33, 2520, rng.integers(900, 3500, size=20)].astype(np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    d = oracle.gen_ohlcv(SEED + 8, 1, int(off[-1]), 0)
+    d = {k: np.ascontiguousarray(v[0]) for k, v in d.items()}
+    c_null = d["close"].copy()
+    c_null[off[2] + 100] = oracle.NULL               # group 2 and group 7 carry a NULL
+    c_null[off[7] + 5] = oracle.NULL
+    for name, cols, prm, nulls in (("ema", ("close",), dict(timeperiod=30), True), ("trix", ("close",), dict(timeperiod=10), False),
+                                   ("rsi", ("close",), dict(timeperiod=14), False), ("atr", ("high", "low", "close"), dict(timeperiod=14), True),
+                                   ("natr", ("high", "low", "close"), dict(timeperiod=5), False), ("plus_dm", ("high", "low"), dict(timeperiod=14), False),
+                                   ("midpoint", ("close",), dict(timeperiod=14), True), ("macd", ("close",), dict(), False),
+                                   ("adx", ("high", "low", "close"), dict(timeperiod=14), False), ("tema", ("close",), dict(timeperiod=9), True)):
+        src = dict(d)
+        if nulls:
+            src["close"] = c_null
+        api.wt_stats(reset=True)
+        got = [t.cpu().numpy() for t in api.call(name, *[torch.from_numpy(src[c]).cuda() for c in cols], offsets=off, **prm)]
+        st = api.wt_stats()
+        live = int((lens > 0).sum())
+        assert st[0] + st[3] == live and st[3] == (2 if nulls else 0), (name, st)
+        for gi in range(len(lens)):
+            lo, hi = off[gi], off[gi + 1]
+            if hi == lo:
+                continue
+            exp = oracle.call(name, *[src[c][lo:hi] for c in cols], **prm)
+            for k, (g, e) in enumerate(zip(got, exp)):
+                same(f"{name}[{k}] group {gi} (len {hi - lo})", g[lo:hi], np.asarray(e).reshape(-1))
+
+
 def test_default_policy_uses_the_forms_that_win(pq, oracle, monkeypatch):
     from polars_quant_amd import api
     monkeypatch.delenv("PQ_WT_ALL")
