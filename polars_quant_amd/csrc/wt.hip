@@ -8,7 +8,8 @@ static inline bool wt_period_ok(int64_t p) { return p >= 1 && p <= 1024; }
 // Which forms are used by default: those that are faster than the lane-per-symbol body on their own at 5 000 x 2 520
 // (scripts/bench_wt.py, profiles/r04_bench_wt.json).  The others -- DEMA / TEMA alone, MACD alone, the DI / DX / ADX family, whose three
 // LDS columns leave two waves per CU -- are built and tested (PQ_WT_ALL=1 selects them) but lose to the body they would replace.
-static inline bool wt_all() { return getenv("PQ_WT_ALL") != nullptr; }
+// On RAGGED batches every form wins: the alternative there is the per-lane gather body (1.1 ... 11 x slower, profiles/r04_bench_wt.json).
+static inline bool wt_all(const pq_batch *b) { return b->offsets != nullptr || getenv("PQ_WT_ALL") != nullptr; }
 
 bool wt_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *ema, double *dema, double *tema, double *trix, pq_status *st) {
     if (!wt_period_ok(p)) return false;
@@ -22,7 +23,7 @@ bool wt_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, d
     }
     if (n != 1) return false;
     if (ema) { EmaOp op{}; op.p = p; return wt_try(ctx, b, WtEmaOp{real, ema, (int32_t)p}, op, in, OutCols<1>{{ema}}, st); }
-    if (!wt_all() && !trix) return false; // DEMA / TEMA alone: 0.26 ms against 0.16 ms
+    if (!wt_all(b) && !trix) return false; // DEMA / TEMA alone: 0.26 ms against 0.16 ms
     if (dema) { DemaOp op{}; op.p = p; return wt_try(ctx, b, w, op, in, OutCols<1>{{dema}}, st); }
     if (tema) { TemaOp op{}; op.p = p; return wt_try(ctx, b, w, op, in, OutCols<1>{{tema}}, st); }
     TrixOp op{}; op.p = p;
@@ -40,7 +41,7 @@ bool wt_macd(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t fast, i
         op.a.fast = fast; op.a.slow = slow; op.a.sig = sig; op.b.fast = 12; op.b.slow = 26; op.b.sig = sig2;
         return wt_try(ctx, b, w, op, in, OutCols<6>{{macd, signal, hist, macd2, signal2, hist2}}, st);
     }
-    if (!wt_all()) return false; // MACD alone: 0.29 ms against 0.27 ms (the pair with MACDFIX: 0.31 against 0.40)
+    if (!wt_all(b)) return false; // MACD alone: 0.29 ms against 0.27 ms (the pair with MACDFIX: 0.31 against 0.40)
     WtMacdOp w{real, macd, signal, hist, nullptr, nullptr, nullptr, (int32_t)fast, (int32_t)slow, (int32_t)sig, (int32_t)sig};
     MacdOp op{}; op.fast = fast; op.slow = slow; op.sig = sig;
     return wt_try(ctx, b, w, op, in, OutCols<3>{{macd, signal, hist}}, st);
@@ -65,7 +66,7 @@ bool wt_dm_pair(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l
 
 bool wt_dmi(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, const double *c, int64_t p, double *dx, double *plus_di, double *minus_di,
             double *adx, double *adxr, pq_status *st) {
-    if (!wt_period_ok(p) || !wt_all()) return false; // 1.35 ms against 1.20 ms for the five columns, 1.28 against 0.89 for ADX alone
+    if (!wt_period_ok(p) || !wt_all(b)) return false; // 1.35 ms against 1.20 ms for the five columns, 1.28 against 0.89 for ADX alone
     WtDmiOp w{h, l, c, dx, plus_di, minus_di, adx, adxr, (int32_t)p};
     InCols<3> in{{h, l, c}};
     const int n = (dx != nullptr) + (plus_di != nullptr) + (minus_di != nullptr) + (adx != nullptr) + (adxr != nullptr);
