@@ -216,6 +216,15 @@ static pq_status over_batch(pq_ctx *ctx, const pq_series_export &key, int64_t n,
                           (k[(size_t)i].null || (k[(size_t)i].len == k[(size_t)i - 1].len && !memcmp(k[(size_t)i].p, k[(size_t)i - 1].p, (size_t)k[(size_t)i].len)));
         if (!same) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
     }
+    // groups of one common length (a balanced panel) are a REGULAR batch with stride = len: the tiled bodies instead of the ragged
+    // forms (the per-lane gather body, or a wavefront per group for the functions that have that form)
+    bool uniform = off.size() >= 2;
+    for (size_t i = 1; uniform && i < off.size(); i++) uniform = off[i] - off[i - 1] == longest;
+    if (uniform) {
+        *d_off = nullptr;
+        *b = pq_batch{(int64_t)off.size() - 1, longest, longest, nullptr};
+        return PQ_OK;
+    }
     PQ_TRY(pq_malloc(ctx, off.size() * 8, d_off));
     PQ_TRY(pq_memcpy_h2d(ctx, *d_off, off.data(), off.size() * 8));
     PQ_TRY(pq_ctx_sync(ctx)); // `off` is a pageable local
