@@ -502,3 +502,39 @@ def test_batched_over_symbols_equal_one_call_per_group(oracle):
     ins = (SeriesExport * 2)(ses[0], se2)
     ret = SeriesExport(); L._polars_plugin_ema_over(ins, 2, None, 0, C.byref(ret), None)
     assert not ret.release
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_groups,glen", [(5, 64), (3, 1100), (1, 300), (7, 33)])
+def test_batched_over_balanced_panel(oracle, n_groups, glen):
+    """groups of ONE common length are passed on as a regular batch (tiled bodies; the wave-per-symbol forms from 1 024 rows on):
+    the same values as one call per group"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    n = n_groups * glen
+    d = oracle.gen_ohlcv(0x5EED0012, 1, n, 0)
+    d = {k: np.ascontiguousarray(v[0]) for k, v in d.items()}
+    d["real"] = d["close"]
+    sym = np.repeat(np.arange(n_groups), glen).astype(np.int64)
+
+    def run(fn, cols, literals=()):
+        ses, keep = [], []
+        for c in cols:
+            se, k = _export([pa.array(d[c])], c); ses.append(se); keep.append(k)
+        se, k = _export([pa.array(sym)], "symbol"); ses.append(se); keep.append(k)
+        for v in literals:
+            se, k = _export([pa.array([v], type=pa.int64())], "literal"); ses.append(se); keep.append(k)
+        ins = (SeriesExport * len(ses))(*ses)
+        ret = SeriesExport(); fn(ins, len(ses), None, 0, C.byref(ret), None)
+        assert ret.release, L._polars_plugin_get_last_error_message()
+        return _import(ret)
+
+    for name, cols, lits, prm in (("ema", ["real"], [9], dict(timeperiod=9)), ("sma", ["real"], [5], dict(timeperiod=5)),
+                                  ("atr", ["high", "low", "close"], [7], dict(timeperiod=7)), ("rsi", ["real"], [14], dict(timeperiod=14))):
+        got = run(getattr(L, f"_polars_plugin_{name}_over"), cols, lits)
+        exp = np.concatenate([np.asarray(oracle.call(name, *[d[c][g * glen:(g + 1) * glen] for c in cols], **prm)[0]).reshape(-1) for g in range(n_groups)])
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert len(got) == n and (np.asarray(got.is_null()) == en).all(), name
+        assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all(), name
