@@ -291,11 +291,13 @@ pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close,
 pq_status pq_backtest_wave_stats(pq_ctx *, int64_t *out3, int32_t reset);
 /* The contractive recurrences of the indicator suite -- calc_ema (overlap.rs:660-730) and its cascades DEMA / TEMA / TRIX, MACD
  * (momentum.rs:250-283), Wilder's calc_rma behind RSI (momentum.rs:507-541), +DM / -DM, DX / DI / ADX / ADXR (momentum.rs:668-727),
- * ATR / NATR (volatility.rs:18-48) -- and the extrema of MIDPOINT / MIDPRICE run ONE SYMBOL PER WAVEFRONT on regular, aligned
- * batches with 1 024 <= len <= 4 096 (csrc/wt_dev.h): 64 row chunks per symbol, started from prefix-scanned seeds, whose hand-over
- * states are compared bit for bit (a chunk that fails is re-run from its predecessor's state: results are the serial walk's either
- * way).  A symbol with a NULL / NaN input is left to the lane-per-symbol kernel of the same function, launched gated behind.
- * out4 (host): [0] symbols computed that way since the last reset, [1] chunks that failed the bit test, [2] chunk re-runs,
+ * ATR / NATR (volatility.rs:18-48) -- and the extrema of MIDPOINT have a ONE-SYMBOL-PER-WAVEFRONT form (csrc/wt_dev.h): 64 row chunks
+ * per symbol, started from prefix-scanned seeds, whose hand-over states are compared bit for bit (a chunk that fails is re-run from
+ * its predecessor's state: results are the serial walk's either way).  DIRECT calls (not recorded into a suite) take it on regular
+ * batches with 1 024 <= len <= 4 096 where it beats the lane-per-symbol kernel of the function (EMA, TRIX, RSI, +DM / -DM, ATR / NATR,
+ * MIDPOINT, pq_ema_all, pq_macd_pair, pq_dm_pair, pq_atr_all), and on RAGGED batches whose groups average >= 1 024 rows (every function
+ * named above).  A symbol / group with a NULL or NaN input is left to the lane-per-symbol kernel of the same function, launched gated
+ * behind.  out4 (host): [0] symbols computed that way since the last reset, [1] chunks that failed the bit test, [2] chunk re-runs,
  * [3] symbols handed to the gated general path.  Synchronises the context's stream. */
 pq_status pq_wt_stats(pq_ctx *, int64_t *out4, int32_t reset);
 
