@@ -38,12 +38,11 @@ PMC_FILE = ROOT / "profiles" / "r04_pmc_traffic.json"
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): the PMC traffic file is only quoted for the build it was
-    collected on (scripts/pmc_summary.py writes the same hash into it; .git does not travel to the GPU box)"""
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h): the PMC traffic file is only quoted for the build it was collected on
+    (scripts/pmc_summary.py writes the same hash into it; .git does not travel to the GPU box)"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(list((ROOT / "polars_quant_amd" / "csrc").glob("*.hip")) + list((ROOT / "polars_quant_amd" / "csrc").glob("*.h")) +
-                    list((ROOT / "include").glob("*.h"))):
+    for f in sorted(list((ROOT / "polars_quant_amd" / "csrc").glob("*.hip")) + list((ROOT / "polars_quant_amd" / "csrc").glob("*.h"))):
         h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

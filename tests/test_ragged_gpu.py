@@ -213,3 +213,21 @@ def test_recorded_suite_on_a_ragged_batch(pq, oracle, groups):
         for g_, e_ in zip(res["bt"], (ep, ec, ee)):
             assert (bits(g_[lo:hi]) == bits(e_)).all(), ("backtest", s)
         np.testing.assert_allclose(summ[s], esum, rtol=1e-12, atol=1e-13)
+
+
+def test_offsets_must_start_at_row_zero_and_rule_inputs_must_agree_in_shape(pq, oracle):
+    """(round-3 advisor) rows in front of the first group would belong to no group and their outputs stayed unwritten; a rule kernel
+    indexes all its columns with ONE batch, so a shorter column was read out of bounds / left output rows unwritten"""
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import PqError
+    x = torch.from_numpy(oracle.gen_ohlcv(SEED + 9, 1, 100, 0)["close"][0]).cuda()
+    with pytest.raises(PqError, match="starting at 0"):
+        api.call("ema", x, timeperiod=5, offsets=np.array([10, 60, 100]))
+    (ok,) = api.call("ema", x, timeperiod=5, offsets=np.array([0, 60, 100]))
+    assert ok.shape == (100,)
+    a = torch.rand((4, 50), dtype=torch.float64, device="cuda")
+    buy = torch.zeros((4, 50), dtype=torch.uint8, device="cuda")
+    with pytest.raises(PqError, match="shapes differ"):
+        api.gate_signals(buy, buy[:, :40].contiguous(), a, 0, 0.5)
+    with pytest.raises(PqError, match="shapes differ"):
+        api.zscore(a, a[:3].contiguous(), a)
