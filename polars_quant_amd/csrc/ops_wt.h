@@ -455,8 +455,6 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
         memcpy(t.blob, &w, sizeof w);
         for (int k = 0; k < SeqOp::NIN; k++) t.reads[t.n_reads++] = in.p[k];
         for (int k = 0; k < SeqOp::NOUT; k++) if (out.p[k]) t.writes[t.n_writes++] = out.p[k];
-        t.wt_cols = SeqOp::NIN + SeqOp::NOUT;
-        t.wt_alg_cols = AlgCols<SeqOp>::value;
         *st = rec_add_row(ctx, t);
         return true;
     }

@@ -856,8 +856,6 @@ struct RowThunk { // type-erased ROW launch for replay
     int n_reads;
     void *writes[64];
     int n_writes;
-    int wt_cols = 0;     // > 0: a wave-per-symbol job (ops_wt.h) that moves this many f64 columns; the suite schedules it as sequential work
-    int wt_alg_cols = 0; // f64 column transfers credited (per reference call)
 };
 pq_status rec_add_row(pq_ctx *ctx, const RowThunk &t);
 void rec_set_shared_out(pq_ctx *ctx, bool on); // jobs recorded while on may write disjoint rows of one column

@@ -28,9 +28,11 @@
 //     column (a recurrence that does not contract) costs time, never correctness.
 // Cascades (DEMA / TEMA / TRIX, the MACD signal line, ADX over DX) are chains over columns that earlier chains have made exact.
 //
-// Scope: null-free symbols of a regular batch, 1 024 <= len <= 4 096.  A symbol with a NULL / NaN input sets its 64-symbol tile's
-// flag in `gate`, and the lane-per-symbol kernel of the same function -- launched behind this one, gated by those flags -- redoes
-// that tile (it exits at once when no flag is set).  Nothing here is a second definition of an indicator's semantics for nulls.
+// Scope: null-free symbols, len <= 4 096; regular batches from 1 024 rows on, ragged batches (pq_batch.offsets: one wavefront per
+// group) whose groups average 1 024 rows.  A symbol with a NULL / NaN input sets its 64-symbol tile's flag in `gate`, and the
+// lane-per-symbol kernel of the same function -- launched behind this one, gated by those flags -- redoes that tile (it exits at once
+// when no flag is set).  Nothing here is a second definition of an indicator's semantics for nulls.  Which functions use the form by
+// default, and why a recorded suite does not: wt.hip, ops_wt.h (wt_try), DESIGN.md section 3c.
 #pragma once
 #include "pq_cores.h"
 #include "wave_util.h"
@@ -175,9 +177,6 @@ __device__ __forceinline__ void wt_map(const WtCtx &w, F &&f) {
 template <class F>
 __device__ __forceinline__ void wt_store(const WtCtx &w, double *gcol, F &&f) {
     if (!gcol) return;
-#ifdef WT_EXP_NOSTORE
-    if (w.g.T > 0) return;
-#endif
     double *dst = gcol + w.base;
     const int T = w.g.T, lane = w.lane;
     if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
@@ -207,9 +206,6 @@ __device__ __forceinline__ void wt_store(const WtCtx &w, double *gcol, F &&f) {
 // two columns from one pass over the rows (f writes both values)
 template <class F>
 __device__ __forceinline__ void wt_store2(const WtCtx &w, double *g0, double *g1, F &&f) {
-#ifdef WT_EXP_NOSTORE
-    if (w.g.T > 0) return;
-#endif
     double *d0 = g0 ? g0 + w.base : nullptr, *d1 = g1 ? g1 + w.base : nullptr;
     const int T = w.g.T, lane = w.lane;
     const bool wide = (((d0 ? reinterpret_cast<uintptr_t>(d0) : 0) | (d1 ? reinterpret_cast<uintptr_t>(d1) : 0)) & 15) == 0;
@@ -246,177 +242,12 @@ __device__ __forceinline__ void wt_store2(const WtCtx &w, double *g0, double *g1
     WT_T(const_cast<WtCtx &>(w), 8);
 }
 
-// dst[i] = out(i, e_i) for i >= rs = r0 + p - 1, NULL below, where e_rs = (in(src[r0]) + ... + in(src[rs])) / p with the adds in row
-// order and e_i = rec.step(e_{i-1}, in(src[i])): the serial walk's values, bit for bit (header).  dst may be src (in place).
-// `in` maps a stored value to the recurrence's operand (identity, or None -> 0.0); `out` may read other LDS columns at row i.
-template <int KIND, class InF, class OutF>
-__device__ __forceinline__ void wt_chain(WtCtx &w, const double *src, double *dst, const WtRec<KIND> rec, int p, int r0, InF in, OutF out) {
-    const int T = w.g.T, C = w.g.C, P = w.g.P, c = w.lane;
-    const int rs = r0 + p - 1;
-#ifdef WT_EXP_NOCHAIN
-    if (T > 0) { wt_map(w, [&](int i, int a) { dst[a] = out(i, in(src[a])); }); btw_lds_fence(); return; }
-#endif
-    if (p <= 0 || rs >= T) { // no row has p operands: every row NULL (overlap.rs:663-665)
-        wt_map(w, [&](int, int a) { dst[a] = pq_null(); });
-        btw_lds_fence();
-        return;
-    }
-    const int hc = (int)(((unsigned)rs * w.g.magic) >> 20); // the anchor chunk
-    const int nlive = (T + C - 1) / C;
-    const int nW = w.nW(rec.gain());
-    // 1. the anchor lane: the seed as the reference forms it, then the rest of its chunk
-    double e = 0.0, e_seed = 0.0;
-    if (c == hc) {
-        double sum = 0.0;
-        int i = r0;
-        for (; i + 8 <= rs + 1; i += 8) { // (eight LDS reads in flight; the adds stay in row order)
-            double x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = in(src[w.g.addr(i + u)]);
-#pragma unroll
-            for (int u = 0; u < 8; u++) sum += x[u];
-        }
-        for (; i <= rs; i++) sum += in(src[w.g.addr(i)]);
-        e_seed = sum / (double)p;
-        e = e_seed;
-        const double *row = src + hc * P;
-        int b = rs - hc * C + 1;
-        for (; b + 8 <= C; b += 8) {
-            double x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = in(row[b + u]);
-#pragma unroll
-            for (int u = 0; u < 8; u++) e = rec.step(e, x[u]);
-        }
-        for (; b < C; b++) e = rec.step(e, in(row[b]));
-    }
-    WT_T(w, 1);
-    // 2. the affine map of my chunk in exact-arithmetic terms, e -> A e + B, and its prefix composition over the lanes
-    const double q = rec.q(), gn = rec.gain();
-    double A = 1.0, B = 0.0;
-    {
-        const double *row = src + c * P;
-        int b = 0;
-        for (; b + 8 <= C; b += 8) {
-            double x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = in(row[b + u]);
-#pragma unroll
-            for (int u = 0; u < 8; u++) { B = fma(q, B, gn * x[u]); A *= q; }
-        }
-        for (; b < C; b++) { B = fma(q, B, gn * in(row[b])); A *= q; }
-    }
-    if (c < hc) { A = 1.0; B = 0.0; }
-    if (c == hc) { A = 0.0; B = e; } // the constant map onto the exact state after chunk hc
-#define WT_AFFINE(CTRL, RM) { const double pA = btw_dpp<CTRL, RM>(1.0, A), pB = btw_dpp<CTRL, RM>(0.0, B); B = fma(A, pB, B); A *= pA; }
-    BTW_SCAN_STEPS(WT_AFFINE)
-#undef WT_AFFINE
-    WT_T(w, 2);
-    // B: the value after chunk c (lane hc: exact; above: to ~1e-15).  Lane c starts in front of chunk q0:
-    const int q0 = (c - nW > hc + 1) ? c - nW : hc + 1;
-    const bool act = c > hc && c < nlive;
-    const bool spec = act && q0 > hc + 1; // speculative start; the others start from the anchor's exact state
-    {
-        const double seed = __shfl(B, q0 - 1);
-        if (act) e = seed;
-    }
-    // 3. warm-up: chunks q0 .. c-1 with the true recurrence
-    for (int kk = 0; kk < nW; kk++) {
-        const int k = __builtin_amdgcn_readfirstlane(kk);
-        const bool on = act && q0 + k < c;
-        if (btw_ballot(on) == 0) break;
-        const double *row = src + (on ? q0 + k : 0) * P;
-        if (on) {
-            int b = 0;
-            for (; b + 8 <= C; b += 8) {
-                double x[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) x[u] = in(row[b + u]);
-#pragma unroll
-                for (int u = 0; u < 8; u++) e = rec.step(e, x[u]);
-            }
-            for (; b < C; b++) e = rec.step(e, in(row[b]));
-        }
-    }
-    WT_T(w, 3);
-    // 4. my own chunk, state only
-    double s_start = e;
-    auto walk_own = [&]() {
-        const double *row = src + c * P;
-        int b = 0;
-        for (; b + 8 <= C; b += 8) {
-            double x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = in(row[b + u]);
-#pragma unroll
-            for (int u = 0; u < 8; u++) e = rec.step(e, x[u]);
-        }
-        for (; b < C; b++) e = rec.step(e, in(row[b]));
-    };
-    if (act) walk_own();
-    WT_T(w, 4);
-    // 5. the bit test, and the re-runs (lowest failing chunk first: its predecessor is exact)
-    auto mismatch = [&]() { // (the cross-lane read first, by every lane: under a branch a DPP source lane that is switched off yields `old`)
-        const unsigned long long pe = btw_bits(btw_prev_lane(0.0, e));
-        return spec && btw_bits(s_start) != pe;
-    };
-    unsigned long long mism = btw_ballot(mismatch());
-    w.nfail += (unsigned long long)__popcll(mism);
-    while (mism) {
-        const int cs = __builtin_ctzll(mism);
-        mism &= mism - 1;
-        const double pe = btw_readlane(e, cs - 1);
-        if (c == cs) { s_start = pe; e = pe; walk_own(); }
-        w.nrerun++;
-        const bool again = mismatch();
-        mism |= btw_ballot(again && c == cs + 1); // the re-run changed lane cs's end state: its successor is tested again
-    }
-    WT_T(w, 5);
-    // 6. emit (in place allowed: a lane reads a row of its own chunk before it writes it; nothing reads another lane's chunk here)
-    {
-        const double *row = src + c * P;
-        double *drow = dst + c * P;
-        if (c < hc && c < nlive) {
-            for (int b = 0; b < C; b++) drow[b] = pq_null();
-        } else if (c == hc) {
-            const int bs = rs - hc * C;
-            e = e_seed;
-            for (int b0 = 0; b0 < C; b0 += 8) {
-                double x[8], y[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) x[u] = b0 + u < C ? in(row[b0 + u]) : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int b = b0 + u;
-                    if (b > bs) e = rec.step(e, x[u]);
-                    y[u] = (b < bs) ? pq_null() : (b < C ? out(hc * C + b, e) : 0.0);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (b0 + u < C) drow[b0 + u] = y[u];
-            }
-        } else if (act) {
-            e = s_start;
-            int b = 0;
-            for (; b + 8 <= C; b += 8) {
-                double x[8], y[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) x[u] = in(row[b + u]);
-#pragma unroll
-                for (int u = 0; u < 8; u++) { e = rec.step(e, x[u]); y[u] = out(c * C + b + u, e); }
-#pragma unroll
-                for (int u = 0; u < 8; u++) drow[b + u] = y[u];
-            }
-            for (; b < C; b++) { e = rec.step(e, in(row[b])); drow[b] = out(c * C + b, e); }
-        }
-    }
-    btw_lds_fence();
-    WT_T(w, 6);
-}
-
-// K independent chains of one kind in ONE set of walks: their dependency chains interleave (a dependent f64 step costs ~44 clocks on
-// a lone wave, three interleaved ones ~56 together: scripts/ubench/f64lat.hip), which is what a wave that has a SIMD to itself needs.
-// Chain k: dst[k][i] = out(k, i, e) from src[k] with (rec[k], p[k], r0[k]), exactly as wt_chain.  Aliasing rule: a chain that runs in
-// place over ANOTHER chain's source must come after it in the list (the emit order below relies on it).
+// K independent chains of one kind in ONE set of walks.  Chain k: dst[k][i] = out(k, i, e_i) for i >= rs = r0 + p - 1, NULL below, where
+// e_rs = (in(src[r0]) + ... + in(src[rs])) / p with the adds in row order and e_i = rec.step(e_{i-1}, in(src[i])): the serial walk's
+// values, bit for bit (header).  dst may be src (in place).  `in` maps a stored value to the recurrence's operand (identity, or None ->
+// 0.0); `out` may read other LDS columns at row i.  The chains' dependency chains interleave (a dependent f64 step costs ~44 clocks on a
+// lone wave, three interleaved ones ~56 together: scripts/ubench/f64lat.hip), which is what a wave that has a SIMD to itself needs.
+// Aliasing rule: a chain that runs in place over ANOTHER chain's source must come after it in the list (the emit order relies on it).
 template <int KIND>
 struct WtChainSpec {
     const double *src;
@@ -637,6 +468,13 @@ __device__ __forceinline__ void wt_chains(WtCtx &w, const WtChainSpec<KIND> (&ch
     }
     btw_lds_fence();
     WT_T(w, 6);
+}
+
+// one chain: dst[i] = out(i, e_i)
+template <int KIND, class InF, class OutF>
+__device__ __forceinline__ void wt_chain(WtCtx &w, const double *src, double *dst, const WtRec<KIND> rec, int p, int r0, InF in, OutF out) {
+    const WtChainSpec<KIND> ch[1] = {{src, dst, rec, p, r0}};
+    wt_chains<1>(w, ch, in, [&](int, int i, double e) { return out(i, e); });
 }
 
 // The kernel: one wavefront = one symbol; Op::run(w) composes the primitives.  Op contract:
