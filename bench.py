@@ -312,10 +312,19 @@ def main():
         box = {}
 
         def mk_comm():
+            # on a side stream, with one trial gather: a communicator that cannot be built -- or whose first collective never returns --
+            # then hangs THAT stream and this thread, not the stream the step runs on
             try:
                 torch.cuda.set_device(dev)   # (the current device is per thread)
                 from polars_quant_amd.distributed import CabiComm
-                box["comm"] = CabiComm(dev, rank, world)
+                side = torch.cuda.Stream(dev)
+                with torch.cuda.stream(side):
+                    c = CabiComm(dev, rank, world)
+                    trial = c.gather_summaries(torch.full((1, 8), float(rank), dtype=torch.float64, device=dev), world)
+                    side.synchronize()
+                    if not torch.equal(trial[:, 0].cpu(), torch.arange(world, dtype=torch.float64)):
+                        raise RuntimeError("trial gather returned the wrong rows")
+                box["comm"] = c
             except Exception as e:  # noqa: BLE001
                 box["err"] = str(e)
 
