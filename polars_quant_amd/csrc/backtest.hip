@@ -31,14 +31,13 @@ static void btw_launch_blob(const void *blob, hipStream_t stream) {
     const BtWaveBlob &w = *reinterpret_cast<const BtWaveBlob *>(blob);
     // above 64 KB of dynamic LDS a kernel has to opt in; the attribute belongs to the CURRENT device's copy of the function, so it
     // is set on every such launch (a host-side table write) rather than remembered in a process-wide flag
-    if (w.lds > 64 * 1024) {
-        const hipError_t e = w.macd ? hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                                    : hipFuncSetAttribute(reinterpret_cast<const void *>(&bt_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return; // the launch below would fail with a less specific error; hipGetLastError reports this one
-    }
-    const dim3 grid((unsigned)w.b.n_series);
-    if (w.macd) hipLaunchKernelGGL(bt_wave_kernel<true>, grid, dim3(64), w.lds, stream, w.a, dims_of(&w.b));
-    else hipLaunchKernelGGL(bt_wave_kernel<false>, grid, dim3(64), w.lds, stream, w.a, dims_of(&w.b));
+    using Kern = void (*)(BtWaveArgs, Dims);
+    const bool two = w.a.C > 64; // chunks of more than 64 rows (len > 4096): two mask words per lane
+    const Kern kern = w.macd ? (two ? &bt_wave_kernel<true, 2> : &bt_wave_kernel<true, 1>) : (two ? &bt_wave_kernel<false, 2> : &bt_wave_kernel<false, 1>);
+    if (w.lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return; // the launch below would fail with a less specific error; hipGetLastError reports this one
+    hipLaunchKernelGGL(kern, dim3((unsigned)w.b.n_series), dim3(64), w.lds, stream, w.a, dims_of(&w.b));
 }
 // true: handled (launched or recorded, *st holds the status); false: the shape is outside the wave form
 static bool bt_wave(pq_ctx *ctx, const pq_batch *b, bool macd, const BtArgs &g, pq_status *st) {
@@ -85,7 +84,7 @@ static void lev_wave_launch_blob(const void *blob, hipStream_t stream) {
         return;
     hipLaunchKernelGGL(lev_wave_kernel, dim3((unsigned)lb.b.n_series), dim3(64), lb.lds, stream, lb.w, dims_of(&lb.b));
 }
-// the leveraged engine, one symbol per wavefront (len <= 4096); true: handled
+// the leveraged engine, one symbol per wavefront (len <= 8192); true: handled
 static bool lev_wave(pq_ctx *ctx, const pq_batch *b, const LevArgs &a, pq_status *st) {
     if (getenv("PQ_BT_LANE_FORM") || b->len > 64 * BTW_MAX_C || b->n_series > 0x7fffffffLL) return false;
     LevWaveBlob lb{};
@@ -146,7 +145,7 @@ pq_status pq_backtest_vectorized(pq_ctx *ctx, const pq_batch *b, const double *p
     a.position = position; a.cash = cash; a.summary = summary; a.prm = *params;
     a.equity = equity;
     pq_status wst;
-    if (bt_wave(ctx, b, false, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
+    if (bt_wave(ctx, b, false, a, &wst)) return wst; // one symbol per wavefront (len <= 8192)
     if (!equity) {
         PQ_TRY(pq_ws_reserve(ctx, sizeof(double) * batch_rows(b) * 8));
         a.equity = pq_ws_col(ctx, b, 0);
@@ -165,7 +164,7 @@ pq_status pq_backtest_macd_cross(pq_ctx *ctx, const pq_batch *b, const double *c
     a.fast = fast; a.slow = slow; a.sig = sig;
     a.equity = equity;
     pq_status wst;
-    if (bt_wave(ctx, b, true, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
+    if (bt_wave(ctx, b, true, a, &wst)) return wst; // one symbol per wavefront (len <= 8192)
     if (position && cash && equity) { // all three state columns: the tiled SEQ op (coalesced column traffic)
         BtMacdOp op{};
         op.prm = *params; op.fast = fast; op.slow = slow; op.sig = sig; op.summary = summary;
@@ -231,7 +230,7 @@ pq_status pq_backtest_leveraged(pq_ctx *ctx, const pq_batch *b, const double *pr
     a.summary = summary; a.prm = *params;
     PQ_REQUIRE(!(b->offsets && benchmark), "pq_backtest_leveraged: a shared benchmark series has no meaning for a ragged batch (pass NULL)");
     pq_status wst;
-    if (lev_wave(ctx, b, a, &wst)) return wst; // one symbol per wavefront (len <= 4096)
+    if (lev_wave(ctx, b, a, &wst)) return wst; // one symbol per wavefront (len <= 8192)
     if (!b->offsets && b->stride % 8 == 0 && reinterpret_cast<uintptr_t>(buy) % 8 == 0 && reinterpret_cast<uintptr_t>(sell) % 8 == 0) {
         LevOp op{};                        // tiled path: coalesced column traffic
         op.a = a; op.stride = b->stride;

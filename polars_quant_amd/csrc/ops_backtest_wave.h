@@ -23,6 +23,7 @@
 //      win_rate / total_trades are exact; the ordered f64 sums of calculate_summary (mean, variance, covariance) are summed
 //      per chunk and then across lanes in a fixed order: <= 1e-12 relative (they are tolerance columns of the parity bar).
 #pragma once
+#include <type_traits>
 #include "ops_backtest.h"
 #include "wave_util.h"
 
@@ -217,12 +218,42 @@ __device__ __forceinline__ void btw_summary(const BtwGeom &g, int lane, double *
     }
 }
 
+// Per-lane row masks: bit b = row b of the lane's chunk (MACD signals) or of the lane's 64-row block (signals as inputs).  NW = 1
+// covers len <= 4096 (C <= 64); NW = 2 -- chunks of up to 128 rows, two blocks per lane (lane w: blocks w and w + 64) -- len <= 8192.
+template <int NW>
+struct BtwBits {
+    unsigned long long w[NW];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = 0;
+    }
+    __device__ __forceinline__ void or_bit(int b, bool v) { // b runtime (the general per-row path)
+        if constexpr (NW == 1) w[0] |= (unsigned long long)v << b;
+        else {
+            const unsigned long long bit = (unsigned long long)v << (b & 63);
+            if (b < 64) w[0] |= bit; else w[1] |= bit;
+        }
+    }
+    __device__ __forceinline__ int popc() const {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) n += __popcll(w[k]);
+        return n;
+    }
+};
+// lane-held table of 64-bit words indexed by a wave-uniform j < 64 * NW: entry j lives in lane j & 63, word j >> 6
+template <int NW>
+__device__ __forceinline__ unsigned long long btw_word(const BtwBits<NW> &m, int j) {
+    if constexpr (NW == 1) return btw_readlane(m.w[0], j);
+    else return j < 64 ? btw_readlane(m.w[0], j) : btw_readlane(m.w[1], j - 64);
+}
+
 #ifdef PQ_BTW_PROF // scripts/ab_build.sh only: per-phase device time summed over the waves, stats[4 + k] in 10 ns ticks
 #define BTW_T(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && a.stats) atomicAdd(a.stats + 4 + (k), t__ - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BTW_T(k)
 #endif
-template <bool MACD>
+template <bool MACD, int NW = 1>
 __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
 #ifdef PQ_BTW_PROF
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
@@ -235,9 +266,9 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     const int64_t base = dims_base(d, s);
     double *px = reinterpret_cast<double *>(btw_lds);   // [64 * P]: row i at i + (i / C) * (P - C); later the equity row, then r
     double *bm = px + 64 * P;                           // [64 * P] when a.bench
-    unsigned long long *evw = reinterpret_cast<unsigned long long *>(bm + (a.bench ? 64 * P : 0)); // [64] event flags per block
-    double *evp = reinterpret_cast<double *>(evw + 64); // [kcap] event prices, then the cash after each event
-    double *evr = evp + a.kcap;                         // [kcap] 1 / exec of the buys, then the position after each event
+    unsigned long long *evw = reinterpret_cast<unsigned long long *>(bm + (a.bench ? 64 * P : 0)); // [64 * NW] event flags per block
+    double *evp = reinterpret_cast<double *>(evw + 64 * NW); // [kcap + 1] event prices; then [k] = the cash after k events (k = 0: the initial capital)
+    double *evr = evp + a.kcap + 1;                     // [kcap + 1] then [k] = the position after k events
     auto addr = [&](int i) { return i + (int)(((unsigned)i * magic) >> 20) * PC; };
     const pq_bt_params prm = a.prm;
     if (T == 0) {
@@ -246,7 +277,8 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     }
 
     // ---- phase 0: the symbol's rows, coalesced, into LDS; signal masks when the signals are inputs
-    unsigned long long bmask = 0, smask = 0; // MACD: bit b of lane c = row c*C + b; else: bit b of lane w = row 64*w + b
+    BtwBits<NW> bmask, smask; // MACD: bit b of lane c = row c*C + b; else: bit b of word k of lane w = row 64 * (w + 64 * k) + b
+    bmask.clear(); smask.clear();
     bool null_seen;
     const BtwGeom geo{T, C, P, magic};
     null_seen = btw_stage(geo, lane, a.price + base, px, pq_null());
@@ -268,7 +300,10 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     const double v = px[addr(64 * (j0 + u) + lane)];
                     const bool valid = !(isnan(v) || v <= 0.0); // vectorized.rs:141: such rows leave the state untouched (a NULL is a NaN)
                     const unsigned long long wb = btw_ballot(bb[u] != 0 && valid), ws = btw_ballot(sb[u] != 0 && valid);
-                    if (lane == j0 + u) { bmask = wb; smask = ws; }
+                    if (lane == ((j0 + u) & 63)) {
+                        if (NW == 1 || j0 + u < 64) { bmask.w[0] = wb; smask.w[0] = ws; }
+                        else { bmask.w[NW - 1] = wb; smask.w[NW - 1] = ws; }
+                    }
                 }
             }
         }
@@ -312,18 +347,24 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             // (a NaN average is absorbing -- every later m, g is NaN and both predicates stay false --, so "not greater on the
             // previous row" can stand for the reference's "less or equal")
             auto steady_rows_keep = [&](const double *row, int b0) {
-                unsigned long long gt = 0, lt = 0, vm = 0;
-                const bool pgt = st.prev_m > st.prev_s, plt = st.prev_m < st.prev_s;
-                for (int b = b0; b < C; b++) {
-                    const double x = row[b];
-                    st.fast_nosig(x);
-                    gt |= (unsigned long long)(st.prev_m > st.prev_s) << b;
-                    lt |= (unsigned long long)(st.prev_m < st.prev_s) << b;
-                    vm |= (unsigned long long)(x > 0.0) << b; // valid price (NaN / NULL compare false)
+#pragma unroll
+                for (int k = 0; k < NW; k++) { // rows [64 k, 64 k + 64) of the chunk -> word k
+                    const int lo = 64 * k, hi = C < lo + 64 ? C : lo + 64;
+                    const int s0 = (b0 > lo ? b0 : lo) - lo; // first bit of this word that is walked
+                    unsigned long long gt = 0, lt = 0, vm = 0;
+                    const bool pgt = st.prev_m > st.prev_s, plt = st.prev_m < st.prev_s; // the row in front of bit s0
+                    for (int b = lo + s0; b < hi; b++) {
+                        const double x = row[b];
+                        st.fast_nosig(x);
+                        gt |= (unsigned long long)(st.prev_m > st.prev_s) << (b - lo);
+                        lt |= (unsigned long long)(st.prev_m < st.prev_s) << (b - lo);
+                        vm |= (unsigned long long)(x > 0.0) << (b - lo); // valid price (NaN / NULL compare false)
+                    }
+                    const unsigned s1 = s0 < 64 ? s0 : 63; // (s0 >= 64: the word is not walked, gt = lt = 0)
+                    const unsigned long long pvg = (gt << 1) | ((unsigned long long)pgt << s1), pvl = (lt << 1) | ((unsigned long long)plt << s1);
+                    bmask.w[k] = gt & ~pvg & vm;
+                    smask.w[k] = lt & ~pvl & vm;
                 }
-                const unsigned long long pvg = (gt << 1) | ((unsigned long long)pgt << b0), pvl = (lt << 1) | ((unsigned long long)plt << b0);
-                bmask = gt & ~pvg & vm;
-                smask = lt & ~pvl & vm;
             };
             BTW_T(14);
             if (head) {
@@ -451,7 +492,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     }
                 } else if (fastk) {
                     if (active) {
-                        const unsigned long long kb = bmask, ks = smask;
+                        const BtwBits<NW> kb = bmask, ks = smask;
                         steady_rows_keep(row, 0);
                         if (!rec) { bmask = kb; smask = ks; }
                     }
@@ -463,8 +504,8 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                             st.step(q * C + b, x, bu, se);
                             if (rec) {
                                 const bool valid = !(isnan(x) || x <= 0.0);
-                                bmask |= (unsigned long long)(bu && valid) << b;
-                                smask |= (unsigned long long)(se && valid) << b;
+                                bmask.or_bit(b, bu && valid);
+                                smask.or_bit(b, se && valid);
                             }
                         }
                 }
@@ -475,10 +516,17 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             }
             // verification: my state at my first row == my predecessor's state after its last row, as raw bits
             auto mismatch = [&]() {
+                // every cross-lane read BEFORE any lane-dependent control flow: a DPP move executed under a short-circuited `&&`
+                // finds the source lanes that already failed switched off and returns `old` for them -- lane c then fails its
+                // k-th comparison because lane c - 1 failed its (k-1)-th (lane 1 always fails its first: lane 0 walked on), and
+                // with five comparisons the lanes up to 5 were flagged (and re-run) for nothing (rounds 3-4: every symbol, whenever
+                // fewer than five warm-up chunks were planned)
                 const bool p_steady = btw_prev_lane(0, (int)st.steady()) != 0;
-                const bool same = s_steady && p_steady && btw_bits(s_f) == btw_bits(btw_prev_lane(0.0, st.ef.ema)) &&
-                                  btw_bits(s_s) == btw_bits(btw_prev_lane(0.0, st.es.ema)) && btw_bits(s_g) == btw_bits(btw_prev_lane(0.0, st.eg.ema)) &&
-                                  btw_bits(s_pm) == btw_bits(btw_prev_lane(0.0, st.prev_m)) && btw_bits(s_ps) == btw_bits(btw_prev_lane(0.0, st.prev_s));
+                const unsigned long long q_f = btw_bits(btw_prev_lane(0.0, st.ef.ema)), q_s = btw_bits(btw_prev_lane(0.0, st.es.ema)),
+                                         q_g = btw_bits(btw_prev_lane(0.0, st.eg.ema)), q_pm = btw_bits(btw_prev_lane(0.0, st.prev_m)),
+                                         q_ps = btw_bits(btw_prev_lane(0.0, st.prev_s));
+                const bool same = s_steady & p_steady & (btw_bits(s_f) == q_f) & (btw_bits(s_s) == q_s) & (btw_bits(s_g) == q_g) &
+                                  (btw_bits(s_pm) == q_pm) & (btw_bits(s_ps) == q_ps);
                 return spec && !same;
             };
             unsigned long long mism = btw_ballot(mismatch());
@@ -493,7 +541,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                 if (lane == cs) {
                     st = pr;
                     s_f = st.ef.ema; s_s = st.es.ema; s_g = st.eg.ema; s_pm = st.prev_m; s_ps = st.prev_s; s_steady = true;
-                    bmask = 0; smask = 0;
+                    bmask.clear(); smask.clear();
                     const double *row = px + cs * P;
                     if (!any_null && st.steady()) steady_rows_keep(row, 0);
                     else
@@ -502,8 +550,8 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                             bool bu, se;
                             st.step(cs * C + b, x, bu, se);
                             const bool valid = !(isnan(x) || x <= 0.0);
-                            bmask |= (unsigned long long)(bu && valid) << b;
-                            smask |= (unsigned long long)(se && valid) << b;
+                            bmask.or_bit(b, bu && valid);
+                            smask.or_bit(b, se && valid);
                         }
                 }
                 n_rerun++;
@@ -526,47 +574,71 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     // events among its own rows.  (A pool that cannot afford one share makes a buy signal a non-event: the walks below notice
     // -- qty <= 0 -- and fall back to searching the signal masks row by row from there.)
     const int CQ = MACD ? C : 64;
-    unsigned long long myword; // lane j: bit l = row 64 * j + l is an event
-    unsigned long long evm;    // the same events in the mapping of bmask / smask
-    int K = 0, kexcl = 0;      // events of the symbol; events in front of my rows
+    BtwBits<NW> myword; // entry j (lane j & 63, word j >> 6): bit l = row 64 * j + l is an event
+    BtwBits<NW> evm;    // the same events in the mapping of bmask / smask
+    constexpr int NGRP = MACD ? 1 : NW; // scan groups in row order: the lane's whole chunk (MACD) / one group per block word (inputs)
+    int K = 0, kexcl[NGRP];             // events of the symbol; events in front of my rows (of each group)
     {
-        unsigned long long m = bmask | smask, ev0 = 0, ev1 = 0; // events among my rows if the pool arrives flat / long
-        int st0 = 0, st1 = 1;                                   // state after my rows
-        while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            const bool isb = (bmask >> b) & 1, iss = (smask >> b) & 1;
-            if (st0 ? iss : isb) { st0 ^= 1; ev0 |= 1ULL << b; }
-            if (st1 ? iss : isb) { st1 ^= 1; ev1 |= 1ULL << b; }
-        }
-        int f0 = st0, f1 = st1; // inclusive scan of the composition: state after lanes 0..c given the state in front of lane 0
+        int s_in = 0; // the pool (0 flat, 1 long) in front of the group's first row
+        evm.clear();
+#pragma unroll
+        for (int gi = 0; gi < NGRP; gi++) {
+            BtwBits<NW> ev0, ev1; // events among my rows if the pool arrives flat / long
+            ev0.clear(); ev1.clear();
+            int st0 = 0, st1 = 1; // state after my rows
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                if (!MACD && k != gi) continue;
+                unsigned long long m = bmask.w[k] | smask.w[k];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const bool isb = (bmask.w[k] >> b) & 1, iss = (smask.w[k] >> b) & 1;
+                    if (st0 ? iss : isb) { st0 ^= 1; ev0.w[k] |= 1ULL << b; }
+                    if (st1 ? iss : isb) { st1 ^= 1; ev1.w[k] |= 1ULL << b; }
+                }
+            }
+            int f0 = st0, f1 = st1; // inclusive scan of the composition: state after lanes 0..c given the state in front of lane 0
 #define BTW_AUTO(CTRL, RM)                                                                                   \
     {                                                                                                        \
         const int p0 = btw_dpp<CTRL, RM>(0, f0), p1 = btw_dpp<CTRL, RM>(1, f1); /* identity: 0 -> 0, 1 -> 1 */ \
         const int n0 = p0 ? f1 : f0, n1 = p1 ? f1 : f0;                                                      \
         f0 = n0; f1 = n1;                                                                                    \
     }
-        BTW_SCAN_STEPS(BTW_AUTO)
+            BTW_SCAN_STEPS(BTW_AUTO)
 #undef BTW_AUTO
-        const int in = btw_prev_lane(0, f0);
-        evm = (lane > 0 && in) ? ev1 : ev0;
-        int cnt = __popcll(evm);
-        const int mine = cnt;
+            const int q0 = btw_prev_lane(0, f0), q1 = btw_prev_lane(1, f1); // the lower lanes' rows as a map (lane 0: identity)
+            const int in = s_in ? q1 : q0;
+            int mine = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                if (!MACD && k != gi) continue;
+                evm.w[k] = in ? ev1.w[k] : ev0.w[k];
+                mine += __popcll(evm.w[k]);
+            }
+            int cnt = mine;
 #define BTW_ADD(CTRL, RM) cnt += btw_dpp<CTRL, RM>(0, cnt);
-        BTW_SCAN_STEPS(BTW_ADD)
+            BTW_SCAN_STEPS(BTW_ADD)
 #undef BTW_ADD
-        kexcl = cnt - mine;
-        K = __builtin_amdgcn_readlane(cnt, 63);
+            kexcl[gi] = K + cnt - mine;
+            K += __builtin_amdgcn_readlane(cnt, 63);
+            if (gi + 1 < NGRP) s_in = s_in ? __builtin_amdgcn_readlane(f1, 63) : __builtin_amdgcn_readlane(f0, 63);
+        }
         if (MACD) { // chunk-mapped bits -> block words, through LDS
-            evw[lane] = 0;
-            unsigned long long e = evm;
-            while (e) {
-                const int row = lane * C + __builtin_ctzll(e);
-                e &= e - 1;
-                atomicOr(&evw[row >> 6], 1ULL << (row & 63));
+#pragma unroll
+            for (int k = 0; k < NW; k++) evw[lane + 64 * k] = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                unsigned long long e = evm.w[k];
+                while (e) {
+                    const int row = lane * C + 64 * k + __builtin_ctzll(e);
+                    e &= e - 1;
+                    atomicOr(&evw[row >> 6], 1ULL << (row & 63));
+                }
             }
             btw_lds_fence();
-            myword = evw[lane];
+#pragma unroll
+            for (int k = 0; k < NW; k++) myword.w[k] = evw[lane + 64 * k];
         } else myword = evm;
     }
     BTW_T(1);
@@ -633,12 +705,16 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     bool dense = K <= a.kcap;
     if (dense) {
         { // event k of the symbol -> evp[k] = its price (the lane that owns the row knows k)
-            unsigned long long e = evm;
-            int k = kexcl;
-            while (e) {
-                const int b = __builtin_ctzll(e);
-                e &= e - 1;
-                evp[k++] = MACD ? px[lane * P + b] : px[addr(64 * lane + b)];
+            int k = kexcl[0];
+#pragma unroll
+            for (int wk = 0; wk < NW; wk++) {
+                unsigned long long e = evm.w[wk];
+                if (!MACD) k = kexcl[wk < NGRP ? wk : 0];
+                while (e) {
+                    const int b = __builtin_ctzll(e);
+                    e &= e - 1;
+                    evp[k++] = MACD ? px[lane * P + 64 * wk + b] : px[addr(64 * (lane + 64 * wk) + b)];
+                }
             }
         }
         btw_lds_fence();
@@ -673,10 +749,11 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                 }
             }
         }
-        // after event k: evr[k] = position, evp[k] = cash (the fill looks states up by event count)
+        // after k events: evr[k] = position, evp[k] = cash (the fill looks states up by event count; no event yet: flat, the initial capital)
 #pragma unroll
         for (int g = 0; g < BTW_NG; g++)
-            if (64 * g + lane < K) { evr[64 * g + lane] = tpv[g]; evp[64 * g + lane] = tcv[g]; }
+            if (64 * g + lane < K) { evr[64 * g + lane + 1] = tpv[g]; evp[64 * g + lane + 1] = tcv[g]; }
+        if (lane == 0) { evr[0] = 0.0; evp[0] = prm.initial_capital; }
         flat = !(K & 1);
         btw_lds_fence();
         BTW_T(9);
@@ -685,28 +762,64 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             pos = 0.0; avail = prm.initial_capital; entry_cost = 0.0; trades = 0; wins = 0; flat = true;
         }
     }
-    if (dense) { // fill: 128 rows per step, lane l = rows 128 * jj + 2 * l, + 1
+    if (dense) { // fill: tiles of 128 rows, lane l = rows 128 * jj + 2 * l, + 1
         const int nb2 = (T + 127) / 128;
         const bool wide = (((a.position ? reinterpret_cast<uintptr_t>(a.position + base) : 0) | (a.cash ? reinterpret_cast<uintptr_t>(a.cash + base) : 0) |
                             (a.equity ? reinterpret_cast<uintptr_t>(a.equity + base) : 0)) & 15) == 0;
+        const double NANV = __longlong_as_double(0x7FF8000000000000LL);
         int kbase = 0;
         const int b0 = (2 * lane) & 63;
         const bool upper = lane >= 32;
-        for (int jj0 = 0; jj0 < nb2; jj0++) {
-            const int jj = __builtin_amdgcn_readfirstlane(jj0);
-            const unsigned long long w0 = btw_readlane(myword, 2 * jj), w1 = btw_readlane(myword, 2 * jj + 1);
-            const int i0 = 128 * jj + 2 * lane;
+        const unsigned long long upto = (2ULL << b0) - 1ULL;
+        struct Tile { int i0, a0, a1, idx0, idx1; double x0, x1; };
+        auto open = [&](int jj, Tile &t) { // my two rows of tile jj: their prices, and how many events lie at or before each
+            const unsigned long long w0 = btw_word(myword, 2 * jj), w1 = btw_word(myword, 2 * jj + 1);
             const unsigned long long ws = upper ? w1 : w0;
             const int c0 = __popcll(w0);
-            const int idx0 = kbase + (upper ? c0 : 0) + __popcll(ws & ((2ULL << b0) - 1ULL)); // events at rows <= i0
-            const int idx1 = idx0 + (int)((ws >> (b0 + 1)) & 1ULL);
-            const int a0 = addr(i0), a1 = addr(i0 + 1);
-            double x0 = px[a0], x1 = px[a1];
-            double p0 = 0.0, c_0 = prm.initial_capital, p1 = 0.0, c_1 = prm.initial_capital;
-            if (idx0 > 0) { p0 = evr[idx0 - 1]; c_0 = evp[idx0 - 1]; }
-            if (idx1 > 0) { p1 = evr[idx1 - 1]; c_1 = evp[idx1 - 1]; }
-            if (pq_isnull(x0)) x0 = __longlong_as_double(0x7FF8000000000000LL); // null -> NaN (vectorized.rs:70-78)
-            if (pq_isnull(x1)) x1 = __longlong_as_double(0x7FF8000000000000LL);
+            t.i0 = 128 * jj + 2 * lane;
+            t.idx0 = kbase + (upper ? c0 : 0) + __popcll(ws & upto);
+            t.idx1 = t.idx0 + (int)((ws >> (b0 + 1)) & 1ULL);
+            t.a0 = addr(t.i0); t.a1 = addr(t.i0 + 1);
+            t.x0 = px[t.a0]; t.x1 = px[t.a1];
+            kbase += c0 + __popcll(w1);
+        };
+        // A lone wave (a 625-symbol shard leaves most SIMDs with one) issues a DEPENDENT instruction every ~32 clocks and an
+        // independent one every ~8 (scripts/ubench/valu_issue.hip), and a tile is one dependency chain -- event count, table look-up,
+        // equity, store --: four whole tiles at a time, written as four interleavable streams without a branch, when all three
+        // columns are wanted on 16-byte aligned rows (or none: summary only).
+        const int nfull = T / 128;
+        int jj0 = 0;
+        auto groups = [&](auto store) {
+            for (; jj0 + 4 <= nfull; jj0 += 4) {
+                const int jb = __builtin_amdgcn_readfirstlane(jj0);
+                Tile t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) open(jb + u, t[u]);
+                double p0[4], p1[4], c_0[4], c_1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { p0[u] = evr[t[u].idx0]; c_0[u] = evp[t[u].idx0]; p1[u] = evr[t[u].idx1]; c_1[u] = evp[t[u].idx1]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double x0 = pq_isnull(t[u].x0) ? NANV : t[u].x0, x1 = pq_isnull(t[u].x1) ? NANV : t[u].x1; // null -> NaN (vectorized.rs:70-78)
+                    const double e0 = c_0[u] + p0[u] * x0, e1 = c_1[u] + p1[u] * x1;
+                    if constexpr (decltype(store)::value) {
+                        nt_store2(a.position + base + t[u].i0, make_double2(p0[u], p1[u]));
+                        nt_store2(a.cash + base + t[u].i0, make_double2(c_0[u], c_1[u]));
+                        nt_store2(a.equity + base + t[u].i0, make_double2(e0, e1));
+                    }
+                    px[t[u].a0] = e0; px[t[u].a1] = e1;
+                }
+            }
+        };
+        if (wide && a.position && a.cash && a.equity) groups(std::true_type{});
+        else if (!a.position && !a.cash && !a.equity) groups(std::false_type{});
+        for (; jj0 < nb2; jj0++) { // the last, partial tiles; any other combination of outputs
+            const int jj = __builtin_amdgcn_readfirstlane(jj0);
+            Tile t;
+            open(jj, t);
+            const int i0 = t.i0;
+            const double p0 = evr[t.idx0], c_0 = evp[t.idx0], p1 = evr[t.idx1], c_1 = evp[t.idx1];
+            const double x0 = pq_isnull(t.x0) ? NANV : t.x0, x1 = pq_isnull(t.x1) ? NANV : t.x1;
             const double e0 = c_0 + p0 * x0, e1 = c_1 + p1 * x1;
             if (wide && i0 + 1 < T) {
                 if (a.position) nt_store2(a.position + base + i0, make_double2(p0, p1));
@@ -724,8 +837,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
                     if (a.equity) __builtin_nontemporal_store(e1, &a.equity[base + i0 + 1]);
                 }
             }
-            if (i0 < 64 * C) { px[a0] = e0; px[a1] = e1; }
-            kbase += c0 + __popcll(w1);
+            if (i0 < 64 * C) { px[t.a0] = e0; px[t.a1] = e1; }
         }
     }
 
@@ -734,15 +846,47 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     bool searching = false; // true after a buy failed: the precomputed events no longer hold, search the signal masks instead
     int cq = 0, cb = 0;     // search cursor: chunk / word, bit
     auto find = [&]() -> int { // next row >= cursor whose (valid-price) signal the pool can act on; -1 if none
-        unsigned long long m = flat ? bmask : smask;
-        if (lane < cq) m = 0;
-        if (lane == cq) m = cb >= 64 ? 0 : (m >> cb) << cb;
-        const unsigned long long bal = btw_ballot(m != 0);
-        if (!bal) return -1;
-        const int c1 = __builtin_ctzll(bal);
-        const int b1 = __builtin_ctzll(btw_readlane(m, c1));
-        cq = c1; cb = b1 + 1;
-        return c1 * CQ + b1;
+        if constexpr (MACD) { // cursor: chunk cq (= lane), bit cb of its up to 64 * NW rows
+            unsigned long long m[NW], any = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                m[k] = flat ? bmask.w[k] : smask.w[k];
+                if (lane < cq) m[k] = 0;
+                if (lane == cq) {
+                    const int sh = cb - 64 * k;
+                    if (sh >= 64) m[k] = 0;
+                    else if (sh > 0) m[k] = (m[k] >> sh) << sh;
+                }
+                any |= m[k];
+            }
+            const unsigned long long bal = btw_ballot(any != 0);
+            if (!bal) return -1;
+            const int c1 = __builtin_ctzll(bal);
+            int b1 = -1;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const unsigned long long mk = btw_readlane(m[k], c1);
+                if (b1 < 0 && mk) b1 = 64 * k + __builtin_ctzll(mk);
+            }
+            cq = c1; cb = b1 + 1;
+            return c1 * CQ + b1;
+        } else { // cursor: block cq (word cq >> 6 of lane cq & 63), bit cb
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                unsigned long long m = flat ? bmask.w[k] : smask.w[k];
+                const int blk = lane + 64 * k;
+                if (blk < cq) m = 0;
+                if (blk == cq) m = cb >= 64 ? 0 : (m >> cb) << cb;
+                const unsigned long long bal = btw_ballot(m != 0);
+                if (bal) {
+                    const int c1 = __builtin_ctzll(bal);
+                    const int b1 = __builtin_ctzll(btw_readlane(m, c1));
+                    cq = c1 + 64 * k; cb = b1 + 1;
+                    return cq * 64 + b1;
+                }
+            }
+            return -1;
+        }
     };
     int r = -1;
     const int nblk = dense ? 0 : (T + 63) / 64;
@@ -752,7 +896,7 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
         const int ai = addr(i);
         double x = px[ai];
         double tp = pos, tc = avail; // state after the last event at or before my row
-        unsigned long long w = searching ? 0ULL : btw_readlane(myword, j);
+        unsigned long long w = searching ? 0ULL : btw_word(myword, j);
         while (w) {
             const int l = __builtin_ctzll(w);
             if (!trade(btw_readlane(x, l))) {
@@ -954,9 +1098,10 @@ static inline bool btw_plan(const pq_batch *b, int64_t fast, int64_t slow, int64
         if (nW < 1) nW = 1;
         a.nW = (int32_t)(nW > 64 ? 64 : nW);
         // with seeds from the affine prefix scan (null-free series) only the last ulps have to merge.  Measured at 5 000 x 2 520,
-        // MACD(12, 26, 9): 160 rows of warm-up leave 1.6 % of the 315 000 chunks unmerged, 200 rows none (scripts/bench_backtest.py
-        // with PQ_BT_WARM_CHUNKS2 = 4 / 5)
-        double rows2 = 10.8 / af + 10.8 / ag;
+        // MACD(12, 26, 9), of 315 000 chunks: 80 rows of warm-up leave 4 454 unmerged, 120 rows 195, 160 rows 13, 200 rows none;
+        // a chunk that has not merged costs one re-run of its C rows, a warm-up chunk costs C rows on every wave: 160 rows
+        // (PQ_BT_WARM_CHUNKS2 = 4 at this shape) is the fastest setting, 0.305 ms against 0.323 at 200
+        double rows2 = 8.5 / af + 8.5 / ag;
         if (!(rows2 < 1e9)) rows2 = 1e9;
         int64_t nW2 = ((int64_t)rows2 + C - 1) / C;
         if (const char *e = getenv("PQ_BT_WARM_CHUNKS2")) nW2 = atoll(e);
@@ -965,6 +1110,6 @@ static inline bool btw_plan(const pq_batch *b, int64_t fast, int64_t slow, int64
     }
     a.kcap = 8 * C < T + 1 ? 8 * C : T + 1; // ~12 % of the rows may be events (MACD(12,26,9): 8 %) before the block form takes over
     if (a.kcap > 64 * BTW_NG) a.kcap = 64 * BTW_NG;
-    lds_bytes = (size_t)64 * a.P * 8 * (bench ? 2 : 1) + 64 * 8 + 2 * (size_t)a.kcap * 8;
+    lds_bytes = (size_t)64 * a.P * 8 * (bench ? 2 : 1) + 64 * 8 * (C > 64 ? 2 : 1) + 2 * ((size_t)a.kcap + 1) * 8;
     return true;
 }

@@ -3,7 +3,7 @@
 #pragma once
 #include "pq_dev.h"
 
-constexpr int BTW_MAX_C = 64;            // rows per lane chunk: one 64-bit signal mask per lane => len <= 4096
+constexpr int BTW_MAX_C = 128;           // rows per lane chunk: up to two 64-bit signal masks per lane (BtwBits<2>) => len <= 8192
 __device__ __forceinline__ unsigned long long btw_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
 __device__ __forceinline__ unsigned long long btw_readlane(unsigned long long v, int l) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);

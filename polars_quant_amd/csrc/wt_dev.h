@@ -38,7 +38,7 @@
 #include "wave_util.h"
 
 constexpr int WT_MIN_LEN = 1024; // below: chunks shorter than 16 rows, the serial head dominates -- the lane-per-symbol body is the better shape
-constexpr int WT_MAX_LEN = 64 * BTW_MAX_C;
+constexpr int WT_MAX_LEN = 4096; // 64 chunks of at most 64 rows
 enum { WT_EMA = 0, WT_RMA = 1 };
 
 struct WtArgs {

@@ -62,7 +62,7 @@ def special_prices(oracle, n, T):
     return d, close
 
 
-@pytest.mark.parametrize("T", [2520, 4096, 1000, 641, 640, 129, 65, 64, 63, 2, 1])
+@pytest.mark.parametrize("T", [2520, 4096, 1000, 641, 640, 129, 65, 64, 63, 2, 1, 4097, 5040, 8191, 8192])  # > 4096: two mask words per lane
 def test_macd_cross_wave_form(pq, oracle, T, monkeypatch):
     from polars_quant_amd import api
     n = 24
@@ -97,7 +97,7 @@ def test_macd_cross_wave_form(pq, oracle, T, monkeypatch):
         assert st[0] == 64 and st[1] <= 64, st
 
 
-@pytest.mark.parametrize("T", [2520, 4096, 777, 65, 1])
+@pytest.mark.parametrize("T", [2520, 4096, 777, 65, 1, 4097, 5040, 8192])
 def test_vectorized_wave_form(pq, oracle, T):
     from polars_quant_amd import api
     n = 20
@@ -121,7 +121,7 @@ def test_vectorized_wave_form(pq, oracle, T):
 
 
 def test_wave_form_equals_lane_form_and_long_series_fall_back(pq, oracle, monkeypatch):
-    """len > 4096 keeps the lane-per-symbol kernels; PQ_BT_LANE_FORM forces them for an A/B on the same inputs."""
+    """len > 8192 keeps the lane-per-symbol kernels; PQ_BT_LANE_FORM forces them for an A/B on the same inputs."""
     from polars_quant_amd import api
     close = oracle.gen_ohlcv(SEED + 1, 70, 2520, 0)["close"]
     w = [t.cpu().numpy() for t in api.backtest_macd_cross(torch.from_numpy(close).cuda())]
@@ -135,7 +135,7 @@ def test_wave_form_equals_lane_form_and_long_series_fall_back(pq, oracle, monkey
     for k in EXACT:
         assert (bits(w[3][:, k]) == bits(l[3][:, k])).all()
     np.testing.assert_allclose(w[3], l[3], rtol=1e-12, atol=1e-13)
-    long = oracle.gen_ohlcv(SEED + 2, 6, 4100, 0)["close"]
+    long = oracle.gen_ohlcv(SEED + 2, 6, 8200, 0)["close"]
     ebuy, esell = oracle.macd_cross_signals(long)
     epos, ecash, eeq, es = oracle.backtest(long, ebuy, esell)
     api.backtest_wave_stats(reset=True)

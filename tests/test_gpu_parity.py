@@ -313,6 +313,34 @@ def test_backtest_macd_cross_fused(pq, oracle, data):
     assert (bits(s2.cpu().numpy()) == bits(s)).all()
 
 
+@pytest.mark.parametrize("T", [4097, 5040, 8192, 8200])
+def test_backtest_leveraged_long_series(pq, oracle, T):
+    """20-year daily series (5040 rows) and up to 8192 rows stay on the wave-per-symbol leveraged kernel (chunks of up to 128 rows
+    in LDS); beyond that the lane-per-symbol form takes over.  Same results either way."""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(T)
+    d = oracle.gen_ohlcv(0x5EED0031, 9, T, 0)
+    price = d["close"].copy()
+    price[1, T - 50] = np.nan
+    price[2, 4090:4100] = oracle.NULL
+    buy = (rng.random(price.shape) < 0.02).astype(np.uint8)
+    sell = (rng.random(price.shape) < 0.02).astype(np.uint8)
+    bench = d["open"][0].copy()
+    kw = dict(leverage=3.0, slippage=0.002, interest_rate=0.5, margin_call_threshold=0.6)
+    e = oracle.backtest_leveraged(price, buy, sell, benchmark=bench, max_trades=64, **kw)
+    g = api.backtest_leveraged(torch.from_numpy(price).cuda(), torch.from_numpy(buy).cuda(), torch.from_numpy(sell).cuda(),
+                               benchmark=torch.from_numpy(bench).cuda(), max_trades=64, **kw)
+    for k in ("cash", "stock_value", "total_value"):
+        ge, ee = g[k].cpu().numpy(), e[k]
+        assert ((bits(ge) == bits(ee)) | (np.isnan(ge) & np.isnan(ee))).all(), k
+    assert (g["trade_count"].cpu().numpy() == e["trade_count"]).all() and e["trade_count"].sum() > 0
+    s, es = g["summary"].cpu().numpy(), e["summary"]
+    ok = ~np.isnan(es).any(axis=1)
+    for k in (1, 5, 6, 7):
+        assert (bits(s[ok, k]) == bits(es[ok, k])).all(), pq.SUMMARY_KEYS[k]
+    np.testing.assert_allclose(s[ok], es[ok], rtol=1e-12, atol=1e-13)
+
+
 def test_backtest_leveraged_matches_oracle(pq, oracle, data):
     """SURVEY 8(f) rank 1 (decision D-10): leveraged multi-symbol engine, bit-exact against the oracle."""
     from polars_quant_amd import api

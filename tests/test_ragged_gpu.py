@@ -105,6 +105,10 @@ def test_patterns_and_parameters_on_ragged_groups(pq, oracle, groups):
                 check(f"{name}.{oname}{{{prm} group {s}}}", g[lo:hi], np.asarray(e).reshape(-1), True, d["close"][lo:hi])
 
 
+def same(g, e):
+    return (bits(g) == bits(e)) | (np.isnan(g) & np.isnan(e))
+
+
 def test_backtests_on_ragged_groups(pq, oracle):
     from polars_quant_amd import api
     rng = np.random.default_rng(5)
@@ -131,6 +135,33 @@ def test_backtests_on_ragged_groups(pq, oracle):
             for k in (1, 5, 6, 7):
                 assert bits(gs[s, k:k + 1])[0] == bits(es2[k:k + 1])[0], (s, k)
             np.testing.assert_allclose(gs[s], es2, rtol=1e-12, atol=1e-13)
+
+
+def test_backtests_with_groups_longer_than_4096_rows(pq, oracle):
+    """A group of 4097 .. 8192 rows puts the whole batch on chunks of more than 64 rows (two mask words per lane, BtwBits<2>): the
+    short groups beside it then use a few lanes only, each with one or two words."""
+    from polars_quant_amd import api
+    rng = np.random.default_rng(6)
+    lens = np.array([5040, 1, 70, 129, 8192, 300, 4097, 64, 2520, 130], dtype=np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    close = np.ascontiguousarray(oracle.gen_ohlcv(SEED + 12, 1, int(off[-1]), 0)["close"][0])
+    close[off[4] + 5000: off[4] + 5003] = oracle.NULL
+    buy = (rng.random(close.shape) < 0.05).astype(np.uint8)
+    sell = (rng.random(close.shape) < 0.05).astype(np.uint8)
+    api.backtest_wave_stats(reset=True)
+    m = [t.cpu().numpy() for t in api.backtest_macd_cross(torch.from_numpy(close).cuda(), offsets=off)]
+    v = [t.cpu().numpy() for t in api.backtest_vectorized(torch.from_numpy(close).cuda(), torch.from_numpy(buy).cuda(), torch.from_numpy(sell).cuda(), offsets=off)]
+    assert api.backtest_wave_stats()[0] == 2 * len(lens), "the wave form must have run"
+    for s in range(len(lens)):
+        lo, hi = off[s], off[s + 1]
+        eb, es_ = oracle.macd_cross_signals(close[lo:hi])
+        for g, e in ((m, oracle.backtest(close[lo:hi], eb, es_)), (v, oracle.backtest(close[lo:hi], buy[lo:hi], sell[lo:hi]))):
+            for k in range(3):
+                assert (same(g[k][lo:hi], e[k])).all(), (s, k)
+            for k in (1, 5, 6, 7):
+                assert bits(g[3][s, k:k + 1])[0] == bits(e[3][k:k + 1])[0], (s, k)
+            ok = ~np.isnan(e[3])
+            np.testing.assert_allclose(g[3][s][ok], e[3][ok], rtol=1e-12, atol=1e-13)
 
 
 def test_backtest_short_aligned_groups_beside_a_long_one(pq, oracle):
