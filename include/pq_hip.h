@@ -284,7 +284,7 @@ pq_status pq_backtest_macd_cross(pq_ctx *, const pq_batch *, const double *close
                                  double *position, double *cash, double *equity, double *summary);
 pq_status pq_macd_cross_signals(pq_ctx *, const pq_batch *, const double *close, int64_t fastperiod,
                                 int64_t slowperiod, int64_t signalperiod, uint8_t *buy, uint8_t *sell);
-/* Both backtests run ONE SYMBOL PER WAVEFRONT for len <= 4096 (csrc/ops_backtest_wave.h): the MACD state machine is run in
+/* Both backtests run ONE SYMBOL PER WAVEFRONT for len <= 8192 (csrc/ops_backtest_wave.h): the MACD state machine is run in
  * 64 speculative row chunks per symbol whose hand-over states are compared bit for bit (a chunk that fails is re-run from
  * its predecessor's state, so results are exact either way).  out3 (host): [0] symbols processed that way since the last
  * reset, [1] chunks that failed the bit test, [2] chunk re-runs.  Synchronises the context's stream. */
