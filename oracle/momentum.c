@@ -2,6 +2,7 @@
  * composites of python/polars_quant/talib/momentum.py.  All momentum.rs functions are N-B
  * (rechunk().cont_slice()? -> error on nulls, momentum.rs:12-13): inputs here are null-free;
  * the host layer rejects nulls before calling.  Compile with -ffp-contract=off. */
+#include <math.h>
 #include "pqo_common.h"
 
 static double *dalloc(int64_t n) { return (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1)); }
@@ -249,18 +250,26 @@ void pqo_returns(const double *v, int64_t n, int64_t period, int64_t method, dou
         out[i] = method == 0 ? (c - pr) / pr : log(c / pr);
     }
 }
-/* Polars rolling_max / rolling_min(window) (python/polars_quant/talib/momentum.py:181-183): null until the frame of the last
- * `window` rows holds `window` non-null rows */
+/* Polars rolling_max / rolling_min(window) (python/polars_quant/talib/momentum.py:181-183; py-polars 1.39.3, uv.lock:213-214 -- a
+ * dependency whose source is not in the tree: decision D-14): null until the frame of the last `window` rows holds `window` non-null
+ * rows; a NaN VALUE is ignored like in Polars' max() / min() (the rolling kernels' NaN-ignoring policy), the result is NaN only if
+ * every value of the frame is NaN. */
+static double frame_ext(const double *v, int64_t lo, int64_t hi, int is_max, int *ok) { /* rows lo .. hi */
+    double best = NAN;
+    *ok = 1;
+    for (int64_t j = lo; j <= hi; j++) {
+        if (pqo_isnull(v[j])) { *ok = 0; return best; }
+        if (v[j] != v[j]) continue;
+        if (best != best || (is_max ? v[j] > best : v[j] < best)) best = v[j];
+    }
+    return best;
+}
 static void roll_ext(const double *v, int64_t n, int64_t w, int is_max, double *out) {
     pqo_fill_null(out, n);
     if (w <= 0) return;
     for (int64_t i = w - 1; i < n; i++) {
-        double best = v[i];
-        int ok = !pqo_isnull(best);
-        for (int64_t j = i + 1 - w; j < i && ok; j++) {
-            if (pqo_isnull(v[j])) { ok = 0; break; }
-            if (is_max ? v[j] > best : v[j] < best) best = v[j];
-        }
+        int ok;
+        const double best = frame_ext(v, i + 1 - w, i, is_max, &ok);
         if (ok) out[i] = best;
     }
 }
@@ -371,19 +380,7 @@ void pqo_macdfix(const double *v, int64_t n, int64_t sig, double *macd, double *
 }
 /* Polars rolling_min/rolling_max(window) (py-polars 1.39.3): null until `window` non-null values
  * are inside the `window`-row frame (min_samples = window), i.e. null if any row in the frame is null. */
-static void rolling_ext(const double *x, int64_t n, int64_t w, int is_max, double *out) {
-    pqo_fill_null(out, n);
-    if (w <= 0) return;
-    for (int64_t i = w - 1; i < n; i++) {
-        int ok = 1;
-        double m = x[i];
-        for (int64_t j = i + 1 - w; j <= i; j++) {
-            if (pqo_isnull(x[j])) { ok = 0; break; }
-            m = is_max ? (x[j] > m ? x[j] : m) : (x[j] < m ? x[j] : m);
-        }
-        if (ok) out[i] = m;
-    }
-}
+static void rolling_ext(const double *x, int64_t n, int64_t w, int is_max, double *out) { roll_ext(x, n, w, is_max, out); }
 static void fastk_of(const double *h, const double *l, const double *c, int64_t n, int64_t k, double *fk) {
     double *ln = dalloc(n), *hn = dalloc(n);
     rolling_ext(l, n, k, 0, ln); rolling_ext(h, n, k, 1, hn);

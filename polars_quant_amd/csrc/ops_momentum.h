@@ -52,12 +52,12 @@ struct RollingExtOp {
     __device__ void eval(const Row<1> &r, int64_t t, double (&y)[1]) {
         y[0] = pq_null();
         if (p <= 0 || t < p - 1) return;
-        double best = r.in[0][t];
-        if (pq_isnull(best)) return;
-        for (int64_t j = t + 1 - p; j < t; j++) {
+        double best = __longlong_as_double(0x7FF8000000000000LL); // decision D-14: NaN values are ignored; a frame of NaNs gives NaN
+        for (int64_t j = t + 1 - p; j <= t; j++) {
             const double v = r.in[0][j];
             if (pq_isnull(v)) return;
-            best = IS_MAX ? (v > best ? v : best) : (v < best ? v : best);
+            if (v != v) continue;
+            if (best != best || (IS_MAX ? v > best : v < best)) best = v;
         }
         y[0] = best;
     }
@@ -150,12 +150,12 @@ struct FastkOp {
         if (k <= 0 || t < k - 1) return;
         double c = r.in[2][t];
         if (pq_isnull(c)) return;
-        double hn = r.in[0][t], ln = r.in[1][t];
+        double hn = __longlong_as_double(0x7FF8000000000000LL), ln = hn; // decision D-14: NaN values are ignored (a frame of NaNs: NaN)
         for (int64_t j = t + 1 - k; j <= t; j++) {
             double h = r.in[0][j], l = r.in[1][j];
             if (pq_isnull(h) || pq_isnull(l)) return;
-            hn = h > hn ? h : hn;
-            ln = l < ln ? l : ln;
+            if (h == h && (hn != hn || h > hn)) hn = h;
+            if (l == l && (ln != ln || l < ln)) ln = l;
         }
         y[0] = (c - ln) * 100.0 / (hn - ln);
     }

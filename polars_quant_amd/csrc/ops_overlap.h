@@ -458,31 +458,39 @@ struct MidpointOp { // overlap.rs:180-278 incl. quirk Q-MID (min never expires =
     int64_t p;
     RollExt<true> mx;
     double mn;
-    bool any;
-    __device__ void init(const Row<1> &) { mx.init(p); mn = 0.0; any = false; }
+    bool any, frozen; // frozen: a NaN value has entered the minimum's deque -- it is never popped (no `>=` holds for it, and that deque
+                      // never expires its front), so nothing newer reaches the front again: the minimum stays what it was
+    const double *col; // the series (tiled bodies: kept for roll_ext_ref)
+    __device__ void init(const Row<1> &r) { mx.init(p); mn = 0.0; any = false; frozen = false; col = r.in[0]; }
+    __device__ __forceinline__ void low(double v) {
+        if (!any) { mn = v; any = true; }
+        else if (!frozen && v <= mn) mn = v;
+        frozen |= v != v;
+    }
     __device__ void step(const Row<1> &r, int64_t t, const double (&x)[1], double (&y)[1]) {
         double v = x[0];
         if (p <= 0 || pq_isnull(v)) { y[0] = pq_null(); return; } // p <= 0: decision D-7b
-        double m = mx.step(r.in[0], t, v);
-        if (!any || v <= mn) { mn = v; any = true; }
+        double m = mx.nan_row(r.in[0], t, v, mx.step(r.in[0], t, v));
+        low(v);
         y[0] = (m + mn) / 2.0;
     }
     Ring wc, ws;
     __host__ __device__ int64_t ring_slots() const { return p > 0 ? 2 * p : 2; }
     __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { init(r); mx.init_ring(); wc = ra.make(p); ws = ra.make(p); }
-    __device__ void step_lds(int64_t, const double (&x)[1], double (&y)[1]) {
+    __device__ void step_lds(int64_t t, const double (&x)[1], double (&y)[1]) {
         double v = x[0];
         if (p <= 0 || pq_isnull(v)) { y[0] = pq_null(); return; }
-        double m = mx.step_ring2(wc, ws, v);
-        if (!any || v <= mn) { mn = v; any = true; }
+        double m = mx.nan_row(col, t, v, mx.step_ring2(wc, ws, v));
+        low(v);
         y[0] = (m + mn) / 2.0;
     }
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return p > 0 && any; }
-    __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) {
+    __device__ void step_fast(int64_t t, const double (&x)[1], double (&y)[1]) {
         const double v = x[0];
-        const double m = mx.step_ring2(wc, ws, v);
-        mn = (v <= mn) ? v : mn;
+        const double m = mx.nan_row(col, t, v, mx.step_ring2(wc, ws, v));
+        mn = (!frozen && v <= mn) ? v : mn;
+        frozen |= v != v;
         y[0] = (m + mn) / 2.0;
     }
 };
@@ -494,12 +502,13 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
     int64_t p;
     RollExt<true> mx;
     RollExt<false> mn;
-    __device__ void init(const Row<2> &) { mx.init(p); mn.init(p); }
+    const double *ch, *cl; // the two series (tiled bodies: kept for roll_ext_ref)
+    __device__ void init(const Row<2> &r) { mx.init(p); mn.init(p); ch = r.in[0]; cl = r.in[1]; }
     __device__ void step(const Row<2> &r, int64_t t, const double (&x)[2], double (&y)[1]) {
         double hm = pq_null(), lm = pq_null();
         if (p <= 0) { y[0] = pq_null(); return; } // decision D-7b
-        if (!pq_isnull(x[0])) hm = mx.step(r.in[0], t, x[0]);
-        if (!pq_isnull(x[1])) lm = mn.step(r.in[1], t, x[1]);
+        if (!pq_isnull(x[0])) hm = mx.nan_row(r.in[0], t, x[0], mx.step(r.in[0], t, x[0]));
+        if (!pq_isnull(x[1])) lm = mn.nan_row(r.in[1], t, x[1], mn.step(r.in[1], t, x[1]));
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
     }
     Ring whc, whs, wlc, wls;
@@ -508,18 +517,18 @@ struct MidpriceOp { // overlap.rs:281-404, no-bitmap branches; null in either in
         init(r); mx.init_ring(); mn.init_ring();
         whc = ra.make(p); whs = ra.make(p); wlc = ra.make(p); wls = ra.make(p);
     }
-    __device__ void step_lds(int64_t, const double (&x)[2], double (&y)[1]) {
+    __device__ void step_lds(int64_t t, const double (&x)[2], double (&y)[1]) {
         if (p <= 0) { y[0] = pq_null(); return; }
         double hm = pq_null(), lm = pq_null();
-        if (!pq_isnull(x[0])) hm = mx.step_ring2(whc, whs, x[0]);
-        if (!pq_isnull(x[1])) lm = mn.step_ring2(wlc, wls, x[1]);
+        if (!pq_isnull(x[0])) hm = mx.nan_row(ch, t, x[0], mx.step_ring2(whc, whs, x[0]));
+        if (!pq_isnull(x[1])) lm = mn.nan_row(cl, t, x[1], mn.step_ring2(wlc, wls, x[1]));
         y[0] = (pq_isnull(hm) || pq_isnull(lm)) ? pq_null() : (hm + lm) / 2.0;
     }
     static constexpr bool HAS_FAST = true;
     __device__ bool steady(int64_t) const { return p > 0; }
-    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) {
-        const double hm = mx.step_ring2(whc, whs, x[0]);
-        const double lm = mn.step_ring2(wlc, wls, x[1]);
+    __device__ void step_fast(int64_t t, const double (&x)[2], double (&y)[1]) {
+        const double hm = mx.nan_row(ch, t, x[0], mx.step_ring2(whc, whs, x[0]));
+        const double lm = mn.nan_row(cl, t, x[1], mn.step_ring2(wlc, wls, x[1]));
         y[0] = (hm + lm) / 2.0;
     }
 };
@@ -538,12 +547,7 @@ struct MidpriceRowOp {
         if (p <= 0) return;                                   // decision D-7b
         const double h0 = r.in[0][t], l0 = r.in[1][t];
         if (pq_isnull(h0) || pq_isnull(l0)) return;          // a null in either input -> null row (D-7)
-        double mx = h0, mn = l0;
-        int64_t cnt = 1;
-        for (int64_t j = t - 1; j >= 0 && cnt < p; j--) { const double v = r.in[0][j]; if (!pq_isnull(v)) { mx = fmax(mx, v); cnt++; } }
-        cnt = 1;
-        for (int64_t j = t - 1; j >= 0 && cnt < p; j--) { const double v = r.in[1][j]; if (!pq_isnull(v)) { mn = fmin(mn, v); cnt++; } }
-        y[0] = (mx + mn) / 2.0;                               // overlap.rs:401
+        y[0] = (roll_ext_ref<true>(r.in[0], t, p) + roll_ext_ref<false>(r.in[1], t, p)) / 2.0; // overlap.rs:401
     }
 };
 

@@ -209,18 +209,45 @@ struct RmaCore {
 // Rolling extremum over the last p valid values with a lazy rescan when the extremum expires.
 // Value-equivalent to the reference's monotonic deques (overlap.rs:205-218, :330-343, :383-396);
 // `count - p` wraps for count < p, i.e. nothing expires until the window is full.
+// The front of the reference's monotonic deque (overlap.rs:203-217 / :325-345 / :378-398) when a NaN VALUE (not a NULL) is among the last
+// p valid values.  The deque pops its back while `back <= value` (`>=` for the minimum), which no NaN satisfies in either role: a NaN is
+// never popped from the back and nothing older can be popped past it, so the front is the extremum of the values OLDER than the oldest
+// NaN of the window -- the NaN itself once nothing older is left -- and everything newer is hidden until that NaN expires.  Without a
+// NaN in the window this is the window's extremum (the newest of equal ones, as `<=` / `>=` keep it).  One backward pass, newest first.
+template <bool IS_MAX>
+__device__ __forceinline__ double roll_ext_ref(const double *col, int64_t t, int64_t p) {
+    double run = 0.0;
+    bool have = false;
+    int64_t cnt = 0;
+    for (int64_t i = t; i >= 0 && cnt < p; i--) {
+        const double w = col[i];
+        if (pq_isnull(w)) continue;
+        cnt++;
+        if (w != w) have = false;
+        else if (!have || (IS_MAX ? w > run : w < run)) { run = w; have = true; }
+    }
+    return have ? run : __longlong_as_double(0x7FF8000000000000LL);
+}
 template <bool IS_MAX>
 struct RollExt {
     int64_t p, j;      // j = number of valid values seen (1-based index of the newest)
     double best;
     int64_t best_j;    // 1-based valid-index of the current extremum
     Regular reg;
+    int64_t nan_left;  // valid rows for which a NaN value is still among the last p (the structures below ignore NaNs: see nan_row)
     __device__ void init(int64_t p_) {
         p = p_;
         j = 0;
         best = 0.0;
         best_j = 0;
+        nan_left = 0;
         reg.init();
+    }
+    // after step() / step_ring2() on the valid value v of row t: the reference's value while a NaN sits in the window (roll_ext_ref)
+    __device__ __forceinline__ double nan_row(const double *col, int64_t t, double v, double m) {
+        if (v != v) nan_left = p;
+        if (nan_left > 0) { nan_left -= 1; m = roll_ext_ref<IS_MAX>(col, t, p); }
+        return m;
     }
     __device__ static bool beats(double a, double b) { return IS_MAX ? (a >= b) : (a <= b); }
     __device__ double step(const double *col, int64_t t, double v) {

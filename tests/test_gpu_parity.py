@@ -5,6 +5,8 @@ kernels follow the reference's operation order, so everything that does not pass
 transcendental (atan/sin/pow) is in fact compared BIT-FOR-BIT; the HT_*/MAMA family and the summary's
 annualised return / sharpe use the stated 1e-12 tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -491,6 +493,24 @@ def test_randomised_parity_sweep(pq, oracle):
     msgs = []
     n_bad = mod.sweep(21, 800, log=lambda *a: msgs.append(" ".join(str(x) for x in a)))
     assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
+    # the same with NaN VALUES (not NULLs) in half of the cases: they are inside every function's domain, and the reference's answer
+    # is an artefact of its loops more often than a rule (monotonic deques that a NaN blocks: tests/test_oracle_nan.py)
+    mod.NAN_RATE = 0.03
+    n_bad = mod.sweep(22, 600, log=lambda *a: msgs.append(" ".join(str(x) for x in a)))
+    assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
+
+
+def test_randomised_parity_sweep_long_series(pq, oracle):
+    """150 random long cases (scripts/fuzz_parity.py sweep_long): the one-symbol-per-wavefront indicator forms at 1024 .. 4096 rows with
+    shortened warm-ups, flat stretches, NaNs and (where the reference accepts them) nulls; both backtests at 1 .. 8192 rows."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("fuzz_parity", Path(__file__).resolve().parent.parent / "scripts" / "fuzz_parity.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    msgs = []
+    n_bad = mod.sweep_long(31, 150, log=lambda *a: msgs.append(" ".join(str(x) for x in a)))
+    assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
 
 
 def test_error_paths_leave_the_context_usable(pq, oracle, data):
@@ -851,6 +871,80 @@ def test_recorded_suite_nulls_and_parameters_on_the_tiled_bodies(pq, oracle):
             exp = oracle.call(name, *[src[c] for c in pq.SPEC[name][0]], **prm)
             for (oname, _), g, e in zip(pq.SPEC[name][2], outs, exp):
                 assert_same(f"{name}.{oname}{{recorded {prm}}}", g.cpu().numpy(), e, exact=name not in TRANSCENDENTAL, price=src["close"])
+    finally:
+        check(L.pq_suite_destroy(h, suite))
+
+
+@pytest.mark.parametrize("shape", [(70, 300, 300), (9, 127, 127), (130, 2520, 2528), (66, 1024, 1024), (5, 1501, 1501), (64, 64, 80)],
+                         ids=lambda s: f"{s[0]}x{s[1]}p{s[2]}")
+def test_nan_values_in_rolling_extrema(pq, oracle, shape):
+    """NaN VALUES (not NULLs) in MIDPOINT / MIDPRICE follow the reference's monotonic deques (a NaN is never popped and shields
+    everything older: tests/test_oracle_nan.py has the hand-derived cases), on every body that computes them: gather, tiled + its
+    straight-line tiles, the one-symbol-per-wavefront form (which hands such a symbol to the lane-per-symbol kernel), MIDPRICE's
+    row-parallel launch, and the recorded job grid."""
+    import ctypes as C
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import Batch, check, lib
+    N, TT, PITCH = shape
+    rng = np.random.default_rng(N * 7919 + TT)
+    d = oracle.gen_ohlcv(0x5EED0041, N, TT, 0)
+    d = {k: v.copy() for k, v in d.items()}
+    for s in range(N):
+        r = s % 8
+        cols = ("high", "low", "close")
+        if r == 0:                      # a NaN now and then
+            for k in cols: d[k][s, rng.random(TT) < 0.01] = np.nan
+        elif r == 1:                    # the very first value
+            for k in cols: d[k][s, 0] = np.nan
+        elif r == 2 and TT > 40:        # a run of NaNs, then one alone within the next window
+            for k in cols: d[k][s, 20:23] = np.nan; d[k][s, 30] = np.nan
+        elif r == 3:                    # the last row
+            for k in cols: d[k][s, TT - 1] = np.nan
+        elif r == 4 and TT > 50:        # NaNs and NULLs mixed (MIDPOINT skips NULL rows, a NULL in either MIDPRICE input gives a NULL row)
+            d["close"][s, 10] = np.nan; d["close"][s, 12] = oracle.NULL; d["close"][s, 40] = np.nan
+            d["high"][s, 15] = np.nan; d["low"][s, 17] = oracle.NULL
+        elif r == 5:                    # only one of the two MIDPRICE inputs
+            d["high"][s, TT // 2] = np.nan
+    def dev(a):
+        buf = torch.full((N, PITCH), 1e300, dtype=torch.float64, device="cuda")
+        buf[:, :TT] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return buf[:, :TT]
+    g = {k: dev(v) for k, v in d.items()}
+    periods = [1, 2, 3, 14, 30, min(100, TT), TT + 3]
+    def check_all(tag, call):
+        for p_ in periods:
+            (got,) = call("midpoint", g["close"], timeperiod=p_)
+            (exp,) = oracle.call("midpoint", d["close"], timeperiod=p_)
+            assert_same(f"{tag} midpoint p={p_}", got.cpu().numpy(), exp, price=d["close"])
+            (got,) = call("midprice", g["high"], g["low"], timeperiod=p_)
+            (exp,) = oracle.call("midprice", d["high"], d["low"], timeperiod=p_)
+            assert_same(f"{tag} midprice p={p_}", got.cpu().numpy(), exp, price=d["close"])
+    check_all("direct", api.call)
+    for env in ("PQ_NO_WT", "PQ_MIDPRICE_SEQ"):   # the lane-per-symbol bodies without the wave form in front / instead of the row-parallel launch
+        os.environ[env] = "1"
+        try:
+            check_all(env, api.call)
+        finally:
+            del os.environ[env]
+    # the same calls recorded into one job grid
+    L, h, b = lib(), api.ctx(0), Batch(N, TT, PITCH)
+    check(L.pq_suite_begin(h, C.byref(b)))
+    rec = []
+    try:
+        for p_ in periods[:5]:
+            rec.append(("midpoint", p_, api.call("midpoint", g["close"], timeperiod=p_)[0]))
+            rec.append(("midprice", p_, api.call("midprice", g["high"], g["low"], timeperiod=p_)[0]))
+    except Exception:
+        L.pq_suite_abort(h)
+        raise
+    suite = C.c_void_p()
+    check(L.pq_suite_end(h, C.byref(suite)))
+    try:
+        check(L.pq_suite_run(h, suite)); check(L.pq_suite_run(h, suite))
+        torch.cuda.synchronize()
+        for name, p_, out in rec:
+            exp = oracle.call(name, *([d["close"]] if name == "midpoint" else [d["high"], d["low"]]), timeperiod=p_)[0]
+            assert_same(f"recorded {name} p={p_}", out.cpu().numpy(), exp, price=d["close"])
     finally:
         check(L.pq_suite_destroy(h, suite))
 
