@@ -60,8 +60,8 @@ void pqo_summary(const double *equity, const double *bench, int64_t n, int64_t n
     free(ret);
 }
 
-/* vectorized.rs:69-224 VectorizedBacktester::run.  price null -> NaN (:70-78) is applied by the
- * caller: a null price row arrives here as PQO null (a NaN) and takes the is_nan() branch. */
+/* vectorized.rs:69-224 VectorizedBacktester::run.  price null -> f64::NAN (:70-78): a null price row arrives here as PQO null and
+ * becomes the plain NaN before anything is computed from it, so the row's equity is a NaN VALUE (not a null), as in the reference. */
 void pqo_backtest(const double *price, const uint8_t *buy, const uint8_t *sell,
                   const double *benchmark, int64_t n, const pqo_bt_params *prm,
                   double *position, double *cash, double *equity, double *summary) {
@@ -69,6 +69,7 @@ void pqo_backtest(const double *price, const uint8_t *buy, const uint8_t *sell,
     int64_t trades = 0, wins = 0;
     for (int64_t i = 0; i < n; i++) {
         double px = price[i];
+        if (pqo_isnull(px)) px = NAN;                                                     /* :70-78 */
         if (isnan(px) || px <= 0.0) {                                                     /* :141-144 */
             position[i] = pos; cash[i] = avail; equity[i] = avail + pos * px;
             continue;

@@ -203,6 +203,213 @@ def _long_backtest(rng, log) -> int:
     return bad
 
 
+# ---- candlestick recognisers: comparisons of candle parts.  Generic float prices almost never tie; quantised prices make equal
+# bodies / shadows / opens the common case (`<=` against `<` then matters), NaN cells make `!(a > b)` differ from `a <= b`.
+def _pattern_case(rng, log) -> int:
+    from polars_quant_amd._spec import PATTERN_NAMES
+    N, T = int(rng.integers(1, 80)), int(rng.integers(1, 400))
+    d = oracle.gen_ohlcv(int(rng.integers(1, 1 << 30)), N, T, 0)
+    o, h, l, c = (d[k].copy() for k in ("open", "high", "low", "close"))
+    mode = int(rng.integers(0, 4))
+    if mode >= 1:      # a price grid: ties everywhere (the coarser, the more dojis / marubozus / equal highs)
+        q = float(rng.choice([0.01, 0.05, 0.25, 1.0]))
+        o, h, l, c = (np.round(x / q) * q for x in (o, h, l, c))
+        h = np.maximum(h, np.maximum(o, c)); l = np.minimum(l, np.minimum(o, c))
+    if mode == 2:      # NaN cells
+        for x in (o, h, l, c):
+            x[rng.random(x.shape) < 0.01] = np.nan
+    if mode == 3:      # flat stretches (zero ranges: every average of bodies / ranges is 0)
+        for s_ in range(N):
+            if rng.random() < 0.3 and T > 8:
+                t0 = int(rng.integers(0, T - 4)); t1 = min(T, t0 + int(rng.integers(2, 40)))
+                o[s_, t0:t1] = h[s_, t0:t1] = l[s_, t0:t1] = c[s_, t0:t1] = c[s_, t0]
+    pens = {nm: float(rng.choice([0.0, 0.1, 0.3, 0.5, 0.9])) for nm in PATTERN_NAMES}
+    dv = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (o, h, l, c)]
+    got = api.cdl_all(*dv, penetrations=pens)
+    bad = 0
+    single = PATTERN_NAMES[int(rng.integers(0, len(PATTERN_NAMES)))]
+    for nm in PATTERN_NAMES:
+        exp = oracle.pattern(nm, o, h, l, c, penetration=pens[nm])
+        g = got[nm].cpu().numpy()
+        if not (g == exp).all():
+            bad += 1
+            log(f"MISMATCH pattern {nm} N={N} T={T} mode={mode} pen={pens[nm]}: {int((g != exp).sum())} cells, first {np.argwhere(g != exp)[:3].tolist()} "
+                f"got {g[g != exp][:3]} exp {exp[g != exp][:3]}")
+        if nm == single:
+            g1 = api.cdl(nm, *dv, penetration=pens[nm]).cpu().numpy()
+            if not (g1 == exp).all():
+                bad += 1
+                log(f"MISMATCH pattern(single) {nm} N={N} T={T} mode={mode}")
+    return bad
+
+
+def sweep_patterns(seed: int, iters: int, log=print) -> int:
+    rng = np.random.default_rng(seed)
+    return sum(_pattern_case(rng, log) for _ in range(iters))
+
+
+# ---- ragged batches (what the Polars plugin's `_over` entry points launch): one long column, groups of any length
+def _ragged_case(rng, name, log) -> int:
+    cols, pspec, outs, fam = SPEC[name]
+    big = rng.random() < 0.35   # groups averaging >= 1024 rows take the one-symbol-per-wavefront forms where one exists
+    ng = int(rng.integers(1, 12 if big else 60))
+    lens = rng.integers(600, 3000, size=ng) if big else rng.choice([0, 1, 2, 7, 31, 32, 33, 64, 65, 100, 255, 256, 300], size=ng)
+    lens = np.asarray(lens, dtype=np.int64)
+    if big and rng.random() < 0.5:
+        lens[int(rng.integers(0, ng))] = int(rng.choice([0, 1, 5, 64]))
+    off = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    total = int(off[-1])
+    if total == 0:
+        return 0
+    d = {k: np.ascontiguousarray(v[0]) for k, v in oracle.gen_ohlcv(int(rng.integers(1, 1 << 30)), 1, total, 0).items()}
+    d["real"] = d["close"]
+    d["periods"] = rng.integers(0, 40, size=total).astype(np.float64)
+    r = rng.random()
+    if r < 0.3 and fam in ("N-A", "N-C", "N-0") and name != "stochrsi":
+        for k in ("open", "high", "low", "close", "volume", "real"):
+            d[k] = d[k].copy(); d[k][rng.random(total) < 0.01] = oracle.NULL
+    elif r < 0.5:
+        for k in ("open", "high", "low", "close", "volume", "real"):
+            d[k] = d[k].copy(); d[k][rng.random(total) < 0.003] = np.nan
+    params = {}
+    for pname, kind, _default in pspec:
+        if kind == I:
+            params[pname] = int(rng.integers(0, 9)) if "matype" in pname else int(rng.choice([1, 2, 3, 5, 9, 14, 30, 64, int(rng.integers(1, 80))]))
+        elif name == "mama":
+            params[pname] = float(rng.choice([0.02, 0.05, 0.2, 0.5]))
+        else:
+            params[pname] = float(rng.choice([0.02, 0.2, 0.5, 2.0]))
+    if name == "mavp":
+        lo_ = int(rng.integers(2, 10)); params["minperiod"], params["maxperiod"] = lo_, lo_ + int(rng.integers(0, 30))
+    got = [g.cpu().numpy() for g in api.call(name, *[torch.from_numpy(d[c]).cuda() for c in cols], offsets=off, **params)]
+    bad = 0
+    for s_ in range(ng):
+        lo, hi = int(off[s_]), int(off[s_ + 1])
+        if hi == lo:
+            continue
+        exp = oracle.call(name, *[d[c][lo:hi] for c in cols], **params)
+        for (oname, dt), g, e in zip(outs, got, exp):
+            g, e = g[lo:hi], np.asarray(e).reshape(-1)
+            if name in TRANSC:
+                ok = np.isclose(g, e, rtol=1e-12, atol=1e-12, equal_nan=True) | (_bits(g) == _bits(e))
+            else:
+                ok = (_bits(g) == _bits(e))
+                if dt == "f8":
+                    gn, en = _bits(g) == np.uint64(oracle.NULL_BITS), _bits(e) == np.uint64(oracle.NULL_BITS)
+                    ok = (ok | ((g != g) & (e != e))) & (gn == en)
+            if not np.all(ok):
+                bad += 1
+                log(f"MISMATCH ragged {name}.{oname} group {s_} len {hi - lo} of {lens.tolist()} {params}: {int((~ok).sum())} cells, first {np.argwhere(~ok)[:3].tolist()} got {g[~ok][:2]} exp {e[~ok][:2]}")
+                break
+    return bad
+
+
+def sweep_ragged(seed: int, iters: int, log=print) -> int:
+    rng = np.random.default_rng(seed)
+    names = sorted(SPEC)
+    return sum(_ragged_case(rng, names[it % len(names)], log) for it in range(iters))
+
+
+# ---- the callers either side of the path: leveraged multi-symbol backtest, signal rules, cross-sectional IC, returns / rolling extrema
+def _poison(rng, x, p_null=0.0, p_nan=0.0, p_neg=0.0):
+    x = x.copy()
+    if p_null: x[rng.random(x.shape) < p_null] = oracle.NULL
+    if p_nan: x[rng.random(x.shape) < p_nan] = np.nan
+    if p_neg: x[rng.random(x.shape) < p_neg] = -1.0
+    return x
+
+
+def _eq(g, e):
+    g, e = np.asarray(g), np.asarray(e)
+    if g.dtype.kind != "f":
+        return bool((g == e).all())
+    return bool(((_bits(g) == _bits(e)) | ((g != g) & (e != e) & ((_bits(g) == np.uint64(oracle.NULL_BITS)) == (_bits(e) == np.uint64(oracle.NULL_BITS))))).all())
+
+
+def _callers_case(rng, it, log) -> int:
+    N, T = int(rng.integers(1, 60)), int(rng.choice([1, 2, 30, 64, 65, 200, 700, int(rng.integers(1, 1200))]))
+    d = oracle.gen_ohlcv(int(rng.integers(1, 1 << 30)), N, T, 0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bad = 0
+    kind = it % 5
+    if kind == 0:   # leveraged engine
+        price = _poison(rng, d["close"], p_null=float(rng.choice([0, 0.01])), p_nan=float(rng.choice([0, 0.005])), p_neg=float(rng.choice([0, 0.005])))
+        dens = float(rng.choice([0.01, 0.05, 0.3]))
+        buy = (rng.random(price.shape) < dens).astype(np.uint8); sell = (rng.random(price.shape) < dens).astype(np.uint8)
+        bench = d["open"][0].copy() if rng.random() < 0.6 else None
+        kw = dict(leverage=float(rng.choice([1.0, 2.0, 3.0, 10.0])), slippage=float(rng.choice([0.0, 0.002])), interest_rate=float(rng.choice([0.0, 0.06, 0.5])),
+                  margin_call_threshold=float(rng.choice([0.3, 0.6, 0.9])), position_size=float(rng.choice([1.0, 0.5])),
+                  min_commission=float(rng.choice([5.0, 0.0, 50.0])), initial_capital=float(rng.choice([100000.0, 5000.0, 300.0])))
+        mt = int(rng.choice([1, 4, 64]))
+        e = oracle.backtest_leveraged(price, buy, sell, benchmark=bench, max_trades=mt, **kw)
+        g = api.backtest_leveraged(dev(price), dev(buy), dev(sell), benchmark=None if bench is None else dev(bench), max_trades=mt, **kw)
+        for k in ("cash", "stock_value", "total_value"):
+            if not _eq(g[k].cpu().numpy(), e[k]):
+                bad += 1; log(f"MISMATCH leveraged.{k} N={N} T={T} {kw}")
+        if not (g["trade_count"].cpu().numpy() == e["trade_count"]).all():
+            bad += 1; log(f"MISMATCH leveraged.trade_count N={N} T={T} {kw}")
+        for k, v in e["trades"].items():
+            if not _eq(g["trades"][k].cpu().numpy(), v):
+                bad += 1; log(f"MISMATCH leveraged.trades.{k} N={N} T={T} {kw} max_trades={mt}")
+        s_, es = g["summary"].cpu().numpy(), e["summary"]
+        okr = ~np.isnan(es).any(axis=1)
+        if not (all((_bits(s_[okr, k]) == _bits(es[okr, k])).all() for k in (1, 5, 6, 7)) and np.allclose(s_[okr], es[okr], rtol=1e-12, atol=1e-13)):
+            bad += 1; log(f"MISMATCH leveraged.summary N={N} T={T} {kw}")
+    elif kind == 1:  # signal rules
+        a = _poison(rng, d["close"], p_null=0.01, p_nan=0.01); b = _poison(rng, d["open"], p_null=0.01, p_nan=0.01)
+        if rng.random() < 0.5:
+            q = 0.25; a, b = np.round(a / q) * q, np.round(b / q) * q   # ties: a touch is not a cross
+        for tag, g, e in (("cross", api.cross_signals(dev(a), dev(b)), oracle.cross_signals(a, b)),
+                          ("band", api.band_signals(dev(a), 9.0, 11.0), oracle.band_signals(a, 9.0, 11.0)),
+                          ("channel0", api.channel_signals(dev(a), dev(d["low"]), dev(d["high"]), 0), oracle.channel_signals(a, d["low"], d["high"], 0)),
+                          ("channel1", api.channel_signals(dev(a), dev(d["low"]), dev(d["high"]), 1), oracle.channel_signals(a, d["low"], d["high"], 1))):
+            for k in range(2):
+                if not (g[k].cpu().numpy() == e[k]).all():
+                    bad += 1; log(f"MISMATCH rule {tag}[{k}] N={N} T={T}")
+    elif kind == 2:  # cross-sectional IC / Rank-IC (days are columns)
+        f = rng.standard_normal((N, T)); r = 0.1 * f + rng.standard_normal((N, T))
+        if rng.random() < 0.5: f = np.round(f * 4) / 4     # ties in the ranks
+        f = _poison(rng, f, p_null=0.02, p_nan=0.01); r = _poison(rng, r, p_null=0.02, p_nan=0.01)
+        if rng.random() < 0.3: f[rng.random(f.shape) < 0.01] = np.inf
+        for m in (0, 1):
+            ic, nv = api.factor_ic(dev(f), dev(r), method=m)
+            eic, env = oracle.factor_ic(f, r, method=m)
+            if not ((nv.cpu().numpy() == env).all() and _eq(ic.cpu().numpy(), eic)):
+                bad += 1; log(f"MISMATCH factor_ic method={m} N={N} T={T}")
+    elif kind == 3:  # returns, rolling extrema
+        x = _poison(rng, d["close"], p_null=float(rng.choice([0, 0.01])), p_nan=float(rng.choice([0, 0.02])))
+        if rng.random() < 0.3: x[rng.random(x.shape) < 0.01] = 0.0
+        w = int(rng.choice([0, 1, 2, 5, 20, T, T + 1]))
+        for nm, prm in (("rolling_max", dict(window=w)), ("rolling_min", dict(window=w)), ("returns", dict(period=w, method=0)), ("returns", dict(period=w, method=1))):
+            e = oracle.call(nm, x, **prm)[0]
+            g = api.call(nm, dev(x), **prm)[0].cpu().numpy()
+            ok = (_bits(g) == _bits(e)) | ((g != g) & (e != e)) if nm != "returns" or prm["method"] == 0 else np.isclose(g, e, rtol=1e-14, atol=0, equal_nan=True) | (_bits(g) == _bits(e))
+            if not ok.all():
+                bad += 1; log(f"MISMATCH {nm} {prm} N={N} T={T}: first {np.argwhere(~ok)[:3].tolist()} got {g[~ok][:2]} exp {e[~ok][:2]}")
+    else:            # single-asset backtest, signals as inputs, small shapes with poisoned prices and a benchmark
+        price = _poison(rng, d["close"], p_null=0.01, p_nan=0.005, p_neg=0.005)
+        dens = float(rng.choice([0.02, 0.2, 1.0]))
+        buy = (rng.random(price.shape) < dens).astype(np.uint8); sell = (rng.random(price.shape) < dens).astype(np.uint8)
+        bm = _poison(rng, d["open"], p_nan=float(rng.choice([0, 0.01]))) if rng.random() < 0.5 else None
+        kw = dict(initial_capital=float(rng.choice([100000.0, 30.0])), position_size=float(rng.choice([1.0, 0.3])), min_commission=float(rng.choice([5.0, 0.0])))
+        e = oracle.backtest(price, buy, sell, benchmark=bm, **kw)
+        g = api.backtest_vectorized(dev(price), dev(buy), dev(sell), benchmark=None if bm is None else dev(bm), **kw)
+        for k, nm in enumerate(("position", "cash", "equity")):
+            if not _eq(g[k].cpu().numpy(), e[k]):
+                bad += 1; log(f"MISMATCH backtest.{nm} N={N} T={T} {kw}")
+        s_, es = g[3].cpu().numpy(), e[3]
+        okr = ~np.isnan(es).any(axis=1)
+        if not (all((_bits(s_[okr, k]) == _bits(es[okr, k])).all() for k in (1, 5, 6, 7)) and np.allclose(s_[okr], es[okr], rtol=1e-12, atol=1e-13)
+                and np.isnan(s_[~okr]).any(axis=1).all()):
+            bad += 1; log(f"MISMATCH backtest.summary N={N} T={T} {kw} bench={bm is not None}")
+    return bad
+
+
+def sweep_callers(seed: int, iters: int, log=print) -> int:
+    rng = np.random.default_rng(seed)
+    return sum(_callers_case(rng, it, log) for it in range(iters))
+
+
 def sweep_long(seed: int, iters: int, log=print) -> int:
     """-> mismatching outputs over `iters` random long-series cases: two wave-form indicators, then one backtest, in turn"""
     rng = np.random.default_rng(seed)
@@ -213,6 +420,15 @@ def sweep_long(seed: int, iters: int, log=print) -> int:
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "callers":
+        print("done, mismatching outputs:", sweep_callers(int(sys.argv[1]), int(sys.argv[2])))
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "ragged":
+        print("done, mismatching outputs:", sweep_ragged(int(sys.argv[1]), int(sys.argv[2])))
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "patterns":
+        print("done, mismatching outputs:", sweep_patterns(int(sys.argv[1]), int(sys.argv[2])))
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "long":
         print("done, mismatching outputs:", sweep_long(int(sys.argv[1]), int(sys.argv[2])))
         sys.exit(0)

@@ -500,6 +500,21 @@ def test_randomised_parity_sweep(pq, oracle):
     assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
 
 
+@pytest.mark.parametrize("which, seed, iters", [("sweep_patterns", 41, 40), ("sweep_ragged", 42, 250), ("sweep_callers", 43, 200)])
+def test_randomised_parity_sweeps_beside_the_indicators(pq, oracle, which, seed, iters):
+    """scripts/fuzz_parity.py: the 61 recognisers on quantised / flat / NaN-holed candles with random penetrations; every function on
+    random ragged batches (nulls where the reference accepts them, NaNs everywhere); the leveraged engine, the signal rules, IC /
+    Rank-IC with ties, NaN, inf and nulls, returns / rolling extrema, and the single-asset backtest on poisoned prices."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("fuzz_parity", Path(__file__).resolve().parent.parent / "scripts" / "fuzz_parity.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    msgs = []
+    n_bad = getattr(mod, which)(seed, iters, log=lambda *a: msgs.append(" ".join(str(x) for x in a)))
+    assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
+
+
 def test_randomised_parity_sweep_long_series(pq, oracle):
     """150 random long cases (scripts/fuzz_parity.py sweep_long): the one-symbol-per-wavefront indicator forms at 1024 .. 4096 rows with
     shortened warm-ups, flat stretches, NaNs and (where the reference accepts them) nulls; both backtests at 1 .. 8192 rows."""
