@@ -410,6 +410,90 @@ def sweep_callers(seed: int, iters: int, log=print) -> int:
     return sum(_callers_case(rng, it, log) for it in range(iters))
 
 
+# ---- recorded suites: a random mix of calls recorded into one job grid (pq_suite_begin / end), replayed twice
+def _suite_case(rng, log) -> int:
+    import ctypes as C
+    from polars_quant_amd._lib import Batch, check, lib
+    N = int(rng.choice([1, 3, 64, 65, 130, int(rng.integers(1, 200))]))
+    T = int(rng.choice([1, 8, 63, 64, 200, 256, 257, 1024, int(rng.integers(1, 700))]))
+    pitch = T if N == 1 else int(rng.choice([T, T + (T % 2), (T + 15) // 16 * 16, T + 1, T + 3]))   # (one series: the wrapper passes stride = len)
+    d = oracle.gen_ohlcv(int(rng.integers(1, 1 << 30)), N, T, 0)
+    d["real"] = d["close"]
+    d["periods"] = rng.integers(0, 40, size=(N, T)).astype(np.float64)
+    holes = {k: v.copy() for k, v in d.items()}
+    mode = int(rng.integers(0, 3))
+    for k in ("open", "high", "low", "close", "volume", "real"):
+        if mode == 1: holes[k][rng.random((N, T)) < 0.02] = oracle.NULL
+        if mode == 2: holes[k][rng.random((N, T)) < 0.01] = np.nan
+    clean = d if mode != 2 else holes      # N-B functions reject nulls; NaN values are fine everywhere
+    def dev(a):
+        buf = torch.full((N, pitch), 1e300, dtype=torch.float64, device="cuda")
+        buf[:, :T] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return buf[:, :T]
+    gd = {id(x): {k: dev(v) for k, v in x.items()} for x in (clean, holes)}
+    names = sorted(SPEC)
+    picks = [names[i] for i in rng.choice(len(names), size=int(rng.integers(3, 30)), replace=True)]
+    L, h, b = lib(), api.ctx(0), Batch(N, T, pitch)
+    check(L.pq_suite_begin(h, C.byref(b)))
+    rec = []
+    try:
+        for name in picks:
+            cols, pspec, outs, fam = SPEC[name]
+            params = {}
+            for pname, kind, _default in pspec:
+                if kind == I:
+                    params[pname] = int(rng.integers(0, 9)) if "matype" in pname else max(int(rng.choice([0, 1, 2, 3, 5, 9, 14, 30, T, int(rng.integers(1, 60))])), 0)
+                elif name == "mama":
+                    params[pname] = float(rng.choice([0.02, 0.05, 0.2, 0.5]))
+                else:
+                    params[pname] = float(rng.choice([0.02, 0.2, 0.5, 2.0]))
+            if name == "mavp":
+                lo_ = int(rng.integers(0, 12)); params["minperiod"], params["maxperiod"] = lo_, lo_ + int(rng.integers(0, 30))
+            src = holes if (fam in ("N-A", "N-C", "N-0") and name != "stochrsi") else clean
+            rec.append((name, params, src, api.call(name, *[gd[id(src)][c] for c in cols], **params)))
+        if rng.random() < 0.5:
+            o_, h_, l_, c_ = (gd[id(clean)][k] for k in ("open", "high", "low", "close"))
+            rec.append(("cdl_all", {}, clean, api.cdl_all(o_, h_, l_, c_)))
+    except Exception:
+        L.pq_suite_abort(h)
+        raise
+    suite = C.c_void_p()
+    check(L.pq_suite_end(h, C.byref(suite)))
+    bad = 0
+    try:
+        check(L.pq_suite_run(h, suite)); check(L.pq_suite_run(h, suite))
+        torch.cuda.synchronize()
+        for name, params, src, got in rec:
+            if name == "cdl_all":
+                from polars_quant_amd._spec import PATTERN_NAMES
+                for nm in PATTERN_NAMES[:: 7]:
+                    if not (got[nm].cpu().numpy() == oracle.pattern(nm, src["open"], src["high"], src["low"], src["close"])).all():
+                        bad += 1; log(f"MISMATCH suite pattern {nm} N={N} T={T} pitch={pitch}")
+                continue
+            cols, pspec, outs, fam = SPEC[name]
+            exp = oracle.call(name, *[src[c] for c in cols], **params)
+            for (oname, dt), g, e in zip(outs, got, exp):
+                g = g.cpu().numpy()
+                if name in TRANSC:
+                    ok = np.isclose(g, e, rtol=1e-12, atol=1e-12, equal_nan=True) | (_bits(g) == _bits(e))
+                else:
+                    ok = _bits(g) == _bits(e)
+                    if dt == "f8":
+                        gn, en = _bits(g) == np.uint64(oracle.NULL_BITS), _bits(e) == np.uint64(oracle.NULL_BITS)
+                        ok = (ok | ((g != g) & (e != e))) & (gn == en)
+                if not np.all(ok):
+                    bad += 1
+                    log(f"MISMATCH suite {name}.{oname} N={N} T={T} pitch={pitch} mode={mode} {params}: {int((~ok).sum())} cells, first {np.argwhere(~ok)[:3].tolist()} got {g[~ok][:2]} exp {e[~ok][:2]}")
+    finally:
+        check(L.pq_suite_destroy(h, suite))
+    return bad
+
+
+def sweep_suites(seed: int, iters: int, log=print) -> int:
+    rng = np.random.default_rng(seed)
+    return sum(_suite_case(rng, log) for _ in range(iters))
+
+
 def sweep_long(seed: int, iters: int, log=print) -> int:
     """-> mismatching outputs over `iters` random long-series cases: two wave-form indicators, then one backtest, in turn"""
     rng = np.random.default_rng(seed)
@@ -420,6 +504,9 @@ def sweep_long(seed: int, iters: int, log=print) -> int:
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "suites":
+        print("done, mismatching outputs:", sweep_suites(int(sys.argv[1]), int(sys.argv[2])))
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "callers":
         print("done, mismatching outputs:", sweep_callers(int(sys.argv[1]), int(sys.argv[2])))
         sys.exit(0)

@@ -500,11 +500,12 @@ def test_randomised_parity_sweep(pq, oracle):
     assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
 
 
-@pytest.mark.parametrize("which, seed, iters", [("sweep_patterns", 41, 40), ("sweep_ragged", 42, 250), ("sweep_callers", 43, 200)])
+@pytest.mark.parametrize("which, seed, iters", [("sweep_patterns", 41, 40), ("sweep_ragged", 42, 250), ("sweep_callers", 43, 200), ("sweep_suites", 44, 80)])
 def test_randomised_parity_sweeps_beside_the_indicators(pq, oracle, which, seed, iters):
     """scripts/fuzz_parity.py: the 61 recognisers on quantised / flat / NaN-holed candles with random penetrations; every function on
     random ragged batches (nulls where the reference accepts them, NaNs everywhere); the leveraged engine, the signal rules, IC /
-    Rank-IC with ties, NaN, inf and nulls, returns / rolling extrema, and the single-asset backtest on poisoned prices."""
+    Rank-IC with ties, NaN, inf and nulls, returns / rolling extrema, and the single-asset backtest on poisoned prices; random
+    mixes of 3 .. 30 calls (+ the fused recognisers) recorded into one job grid on random shapes and row pitches, replayed twice."""
     import importlib.util
     from pathlib import Path
     spec = importlib.util.spec_from_file_location("fuzz_parity", Path(__file__).resolve().parent.parent / "scripts" / "fuzz_parity.py")
