@@ -455,8 +455,10 @@ __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
 // bytes off).  The cooperative accesses move 8 bytes per lane: K lanes cover the K rows (K * 8 contiguous bytes, the same piece as in the
 // aligned body) of one series, 64 / K series per instruction, twice the instructions for the same bytes; a lane's register pair
 // [k][i] holds accesses 2i and 2i + 1.  No pair mode (its 128-byte pieces are assembled from 16-byte chunks).  Measured at 5 000 x
-// 2 520 with a row pitch of 2 521: 8.0 ms per step against 19.8 ms in the per-lane gather body these batches ran before (255 VGPRs,
-// 92 of them spilled, one L1 tag lookup per lane and 8 bytes) and 3.9 ms at the 16-byte aligned pitch 2 528.
+// 2 520 with a row pitch of 2 521: 5.8 ms per step (7.7 with non-temporal stores, see g_store) against 19.8 ms in the per-lane gather
+// body these batches ran before (255 VGPRs, 92 of them spilled, one L1 tag lookup per lane and 8 bytes) and 3.9 ms at the 16-byte
+// aligned pitch 2 528.  (A form with 16-byte accesses on the 8-byte aligned addresses -- legal in the queue's unaligned access mode --
+// was built and measured the same 7.7 ms: the cost of an odd pitch is that every 64-byte piece straddles two cache lines.)
 template <class Op, bool UNAL = false>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
                                             int64_t tile_s0, unsigned char *lds) {
@@ -501,9 +503,11 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         else return PQ_HOOK_TILE_LOAD(at(col, i, t0), t0, i);
     };
     auto g_store = [&](double *col, int i, int64_t t0, const double2 &v) {
-        if constexpr (UNAL) {
-            if (live_i(2 * i)) PQ_HOOK_ROW_STORE(v.x, at_w(col, 2 * i, t0));
-            if (live_i(2 * i + 1)) PQ_HOOK_ROW_STORE(v.y, at_w(col, 2 * i + 1, t0));
+        if constexpr (UNAL) { // plain stores, not non-temporal ones: at an odd pitch every 64-byte piece of a tile straddles two cache
+            // lines and writes both partially; left in L2 in the usual order the halves of a line meet there (the next tile's piece
+            // brings the other one) more often than when they are marked evict-first: 7.07 against 8.37 ms per step at pitch 2 521
+            if (live_i(2 * i)) *at_w(col, 2 * i, t0) = v.x;
+            if (live_i(2 * i + 1)) *at_w(col, 2 * i + 1, t0) = v.y;
         } else if (live_i(i)) nt_store2(at_w(col, i, t0), v);
     };
     auto l_get = [&](int i, int koff) -> double2 { // (two b64 reads: LDS rows are only 8-byte aligned)
