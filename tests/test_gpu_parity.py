@@ -527,6 +527,10 @@ def test_randomised_parity_sweep_long_series(pq, oracle):
     msgs = []
     n_bad = mod.sweep_long(31, 150, log=lambda *a: msgs.append(" ".join(str(x) for x in a)))
     assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
+    # every function (not only those with a wave form) at 1 024 .. 4 096 rows: nulls / NaNs that arrive long after a tiled body
+    # has switched to its straight-line tiles, windows of up to 300 rows, all matypes
+    n_bad = mod.sweep_long(32, 250, log=lambda *a: msgs.append(" ".join(str(x) for x in a)), names=sorted(mod.SPEC))
+    assert n_bad == 0 and not msgs, "\n".join(msgs[:10])
 
 
 def test_error_paths_leave_the_context_usable(pq, oracle, data):
