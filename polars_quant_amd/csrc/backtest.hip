@@ -26,6 +26,7 @@ struct BtWaveBlob {
     pq_batch b;
     unsigned lds;
     int macd;
+    int waves; // wavefronts per symbol: 1, or 4 for small batches
 };
 static void btw_launch_blob(const void *blob, hipStream_t stream) {
     const BtWaveBlob &w = *reinterpret_cast<const BtWaveBlob *>(blob);
@@ -33,11 +34,15 @@ static void btw_launch_blob(const void *blob, hipStream_t stream) {
     // is set on every such launch (a host-side table write) rather than remembered in a process-wide flag
     using Kern = void (*)(BtWaveArgs, Dims);
     const bool two = w.a.C > 64; // chunks of more than 64 rows (len > 4096): two mask words per lane
-    const Kern kern = w.macd ? (two ? &bt_wave_kernel<true, 2> : &bt_wave_kernel<true, 1>) : (two ? &bt_wave_kernel<false, 2> : &bt_wave_kernel<false, 1>);
+    // Four waves per symbol share the staging, the fill and the summary (ops_backtest_wave.h, btw_helper_wave): a small batch (a
+    // 625-symbol shard of config 3 on 8 GPUs) leaves most SIMDs with one wave, whose instruction count is then the kernel's time
+    const bool multi = !two && w.waves > 1;
+    const Kern kern = multi ? (w.macd ? &bt_wave_kernel<true, 1, 4> : &bt_wave_kernel<false, 1, 4>)
+                            : w.macd ? (two ? &bt_wave_kernel<true, 2> : &bt_wave_kernel<true, 1>) : (two ? &bt_wave_kernel<false, 2> : &bt_wave_kernel<false, 1>);
     if (w.lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return; // the launch below would fail with a less specific error; hipGetLastError reports this one
-    hipLaunchKernelGGL(kern, dim3((unsigned)w.b.n_series), dim3(64), w.lds, stream, w.a, dims_of(&w.b));
+    hipLaunchKernelGGL(kern, dim3((unsigned)w.b.n_series), dim3(multi ? 256 : 64), w.lds, stream, w.a, dims_of(&w.b));
 }
 // true: handled (launched or recorded, *st holds the status); false: the shape is outside the wave form
 static bool bt_wave(pq_ctx *ctx, const pq_batch *b, bool macd, const BtArgs &g, pq_status *st) {
@@ -52,6 +57,19 @@ static bool bt_wave(pq_ctx *ctx, const pq_batch *b, bool macd, const BtArgs &g, 
     w.a.prm = g.prm; w.a.fast = (int32_t)g.fast; w.a.slow = (int32_t)g.slow; w.a.sig = (int32_t)g.sig;
     w.a.stats = reinterpret_cast<unsigned long long *>(ctx->d_flag) + 4;
     w.b = *b; w.lds = (unsigned)lds; w.macd = macd ? 1 : 0;
+    {   // Four waves per symbol (ops_backtest_wave.h, btw_helper_wave) are faster at every batch size measured -- 256 symbols 42 against
+        // 53 us, 625: 51 / 58, 2 500: 161 / 178, 5 000: 285 / 313 -- except just above what one round of four-wave workgroups holds
+        // (four per CU by registers): 1 250 symbols 103 against 96 us, where the one-wave form still fits a single round (six per CU by
+        // LDS).  PQ_BT_WAVES=1 / 4: A/B runs and tests.
+        const char *e = getenv("PQ_BT_WAVES");
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+        w.waves = e ? atoi(e) : ((b->n_series > (int64_t)cus * 4 && b->n_series <= (int64_t)cus * 5) ? 1 : 4);
+        // recorded into a suite the kernel runs in the tail of a step beside the job grids, where the waiting helper waves cost the
+        // other kernels wave slots and registers: 4.02 against 3.85 ms per step -- one wave per symbol there
+        if (ctx->rec && !e) w.waves = 1;
+        if (w.waves != 4) w.waves = 1;
+    }
     if (ctx->rec) {
         static_assert(sizeof(BtWaveBlob) <= sizeof(RowThunk::blob), "wave backtest blob too large");
         RowThunk t{};

@@ -248,18 +248,263 @@ __device__ __forceinline__ unsigned long long btw_word(const BtwBits<NW> &m, int
     else return j < 64 ? btw_readlane(m.w[0], j) : btw_readlane(m.w[1], j - 64);
 }
 
+// ---- several wavefronts per symbol (NWV > 1: small shards, where a symbol's wave would otherwise have a SIMD to itself and the
+// kernel time is that one wave's instruction count).  Wave 0 runs the kernel below; the HELPER waves take their share of the three
+// parts that are parallel over rows -- staging, the dense fill, the summary -- and meet wave 0 at workgroup barriers in between.
+// shd[]: doubles in LDS behind the event tables.
+enum { BTW_SH_NULL = 0 /* + wave */, BTW_SH_DENSE = 8, BTW_SH_RED = 16 /* 3 rounds x 3 values x waves */, BTW_SH_DOUBLES = 64 };
+
+// the dense fill of the tiles first, first + step, ...: the event words and the state tables come from LDS (any wave can run it)
+template <int NW>
+__device__ __forceinline__ void btw_fill_tiles(const BtWaveArgs &a, const BtwGeom &g, int64_t base, int lane, int first, int step, double *px,
+                                               const unsigned long long *evw, const double *evr, const double *evp) {
+    const int T = g.T, C = g.C;
+    BtwBits<NW> mw;
+    int pre[NW], carry = 0; // pre[k]: events in the blocks up to and including mine (block = lane + 64 k)
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        mw.w[k] = evw[lane + 64 * k];
+        int cnt = __popcll(mw.w[k]);
+#define BTW_ADD(CTRL, RM) cnt += btw_dpp<CTRL, RM>(0, cnt);
+        BTW_SCAN_STEPS(BTW_ADD)
+#undef BTW_ADD
+        pre[k] = carry + cnt;
+        carry += __builtin_amdgcn_readlane(cnt, 63);
+    }
+    auto before = [&](int blk) -> int { // events in the blocks in front of block `blk` (wave-uniform)
+        if (blk == 0) return 0;
+        const int j = blk - 1;
+        if constexpr (NW == 1) return __builtin_amdgcn_readlane(pre[0], j);
+        else return j < 64 ? __builtin_amdgcn_readlane(pre[0], j) : __builtin_amdgcn_readlane(pre[NW - 1], j - 64);
+    };
+    const int nb2 = (T + 127) / 128;
+    const bool wide = (((a.position ? reinterpret_cast<uintptr_t>(a.position + base) : 0) | (a.cash ? reinterpret_cast<uintptr_t>(a.cash + base) : 0) |
+                        (a.equity ? reinterpret_cast<uintptr_t>(a.equity + base) : 0)) & 15) == 0;
+    const double NANV = __longlong_as_double(0x7FF8000000000000LL);
+    const int b0 = (2 * lane) & 63;
+    const bool upper = lane >= 32;
+    const unsigned long long upto = (2ULL << b0) - 1ULL;
+    for (int jj0 = first; jj0 < nb2; jj0 += step) {
+        const int jj = __builtin_amdgcn_readfirstlane(jj0);
+        const unsigned long long w0 = btw_word(mw, 2 * jj), w1 = btw_word(mw, 2 * jj + 1);
+        const unsigned long long ws = upper ? w1 : w0;
+        const int i0 = 128 * jj + 2 * lane;
+        const int idx0 = before(2 * jj) + (upper ? __popcll(w0) : 0) + __popcll(ws & upto);
+        const int idx1 = idx0 + (int)((ws >> (b0 + 1)) & 1ULL);
+        const int a0 = g.addr(i0), a1 = g.addr(i0 + 1);
+        double x0 = px[a0], x1 = px[a1];
+        const double p0 = evr[idx0], c_0 = evp[idx0], p1 = evr[idx1], c_1 = evp[idx1];
+        if (pq_isnull(x0)) x0 = NANV; // null -> NaN (vectorized.rs:70-78)
+        if (pq_isnull(x1)) x1 = NANV;
+        const double e0 = c_0 + p0 * x0, e1 = c_1 + p1 * x1;
+        if (wide && i0 + 1 < T) {
+            if (a.position) nt_store2(a.position + base + i0, make_double2(p0, p1));
+            if (a.cash) nt_store2(a.cash + base + i0, make_double2(c_0, c_1));
+            if (a.equity) nt_store2(a.equity + base + i0, make_double2(e0, e1));
+        } else {
+            if (i0 < T) {
+                if (a.position) __builtin_nontemporal_store(p0, &a.position[base + i0]);
+                if (a.cash) __builtin_nontemporal_store(c_0, &a.cash[base + i0]);
+                if (a.equity) __builtin_nontemporal_store(e0, &a.equity[base + i0]);
+            }
+            if (i0 + 1 < T) {
+                if (a.position) __builtin_nontemporal_store(p1, &a.position[base + i0 + 1]);
+                if (a.cash) __builtin_nontemporal_store(c_1, &a.cash[base + i0 + 1]);
+                if (a.equity) __builtin_nontemporal_store(e1, &a.equity[base + i0 + 1]);
+            }
+        }
+        if (i0 < 64 * C) { px[a0] = e0; px[a1] = e1; }
+    }
+}
+
+// calculate_summary over NWV wavefronts: the lanes of the workgroup, in row order, own a QUARTER chunk each (global lane 4 c + q: rows
+// c * C + q * Cq ...), the running maximum and the sums are combined wave by wave through shd[] in a fixed order.  Same exact columns
+// (prefix maximum, max_drawdown, win_rate, total_trades); the ordered sums are summed per quarter chunk, then per wave, then over the
+// waves (<= 1e-12, as in the one-wave form).  Every wave passes the three barriers; only wave 0 writes the row.
+template <int NWV>
+__device__ __forceinline__ void btw_summary_mw(const BtwGeom &g, int lane, int wv, double *px, const double *bm, double initial_capital, int trades,
+                                               int wins, double *sm, double *shd) {
+    static_assert(NWV == 2 || NWV == 4, "sub-chunks per chunk: a power of two");
+    const int T = g.T, C = g.C, P = g.P;
+    const int Cq = (C + NWV - 1) / NWV;
+    const int gl = wv * 64 + lane, c = gl / NWV, q = gl % NWV;
+    const int lo = c * C + q * Cq;
+    int hi = lo + Cq;
+    if (hi > (c + 1) * C) hi = (c + 1) * C;
+    if (hi > T) hi = T;
+    const int nrow = hi - lo; // <= 0: idle lane
+    double *erow = px + c * P + q * Cq;
+    const bool has_bench = bm != nullptr;
+    const double *brow = has_bench ? bm + c * P + q * Cq : nullptr;
+    const double init = initial_capital;
+    const double NEG_INF = __longlong_as_double((long long)0xFFF0000000000000ULL);
+    double lm = NEG_INF;
+    for (int b0 = 0; b0 < nrow; b0 += 8) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) e[u] = b0 + u < nrow ? erow[b0 + u] : NEG_INF;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (e[u] > lm) lm = e[u];
+    }
+    double Mx = lm; // inclusive prefix max over this wave's lanes
+#define BTW_MAX(CTRL, RM) { const double t = btw_dpp<CTRL, RM>(NEG_INF, Mx); if (t > Mx) Mx = t; }
+    BTW_SCAN_STEPS(BTW_MAX)
+#undef BTW_MAX
+    double max_eq = btw_prev_lane(NEG_INF, Mx);
+    // everything another wave will overwrite with its returns is read BEFORE the barrier: my predecessor's last row, the last row
+    double prev = init;
+    if (gl > 0 && nrow > 0) prev = px[g.addr(lo - 1)];
+    const double last_eq = px[g.addr(T - 1)];
+    if (lane == 0) shd[BTW_SH_RED + wv] = btw_readlane(Mx, 63);
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NWV - 1; w++) { const double t = shd[BTW_SH_RED + w]; if (w < wv && t > max_eq) max_eq = t; }
+    if (gl == 0 || !(max_eq > init)) max_eq = init; // the running max starts at initial_capital (metrics.rs:21)
+    double max_dd = 0.0, rs = 0.0;
+    for (int b0 = 0; b0 < nrow; b0 += 4) { // metrics.rs:26-49
+        double e[4], mx[4], pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = b0 + u < nrow ? erow[b0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (b0 + u < nrow && e[u] > max_eq) max_eq = e[u];
+            mx[u] = max_eq;
+            pv[u] = prev;
+            if (b0 + u < nrow) prev = e[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double dd = (mx[u] > 0.0) ? (mx[u] - e[u]) / mx[u] : 0.0;
+            const double rr = (pv[u] > 0.0) ? (e[u] - pv[u]) / pv[u] : 0.0;
+            if (b0 + u < nrow) {
+                if (dd > max_dd) max_dd = dd;
+                rs += rr;
+                erow[b0 + u] = rr;
+            }
+        }
+    }
+    auto wave_sum3 = [&](double &v0, double &v1, double &v2) { // the wave's totals, the same value on every lane
+#define BTW_SUM3(CTRL, RM) { v0 += btw_dpp<CTRL, RM>(0.0, v0); v1 += btw_dpp<CTRL, RM>(0.0, v1); v2 += btw_dpp<CTRL, RM>(0.0, v2); }
+        BTW_SCAN_STEPS(BTW_SUM3)
+#undef BTW_SUM3
+        v0 = btw_readlane(v0, 63); v1 = btw_readlane(v1, 63); v2 = btw_readlane(v2, 63);
+    };
+    // the workgroup's totals of three values, waves in order (round = a region of shd[] of its own)
+    auto group3 = [&](int round, double &v0, double &v1, double &v2) {
+        double *r = shd + BTW_SH_RED + 4 + round * 3 * NWV;
+        if (lane == 0) { r[wv] = v0; r[NWV + wv] = v1; r[2 * NWV + wv] = v2; }
+        __syncthreads();
+        v0 = r[0]; v1 = r[NWV]; v2 = r[2 * NWV];
+#pragma unroll
+        for (int w = 1; w < NWV; w++) { v0 += r[w]; v1 += r[NWV + w]; v2 += r[2 * NWV + w]; }
+    };
+    double bs = 0.0, pb0 = 0.0;
+    if (has_bench) { // metrics.rs:86-140: the benchmark's daily returns
+        pb0 = (gl == 0 || nrow <= 0) ? bm[0] : bm[g.addr(lo - 1)];
+        double pb = pb0;
+        for (int b0 = 0; b0 < nrow; b0 += 4) {
+            double bv[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { bv[u] = b0 + u < nrow ? brow[b0 + u] : 0.0; pv[u] = pb; if (b0 + u < nrow) pb = bv[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const double br = (pv[u] > 0.0) ? (bv[u] - pv[u]) / pv[u] : 0.0; if (b0 + u < nrow) bs += br; }
+        }
+    }
+    {
+#define BTW_MAXDD(CTRL, RM) { const double t = btw_dpp<CTRL, RM>(0.0, max_dd); if (t > max_dd) max_dd = t; }
+        BTW_SCAN_STEPS(BTW_MAXDD)
+#undef BTW_MAXDD
+        max_dd = btw_readlane(max_dd, 63);
+        double zero = 0.0;
+        wave_sum3(rs, bs, zero);
+        // (the maximum rides in the third slot as a sum would: combined below by comparison instead)
+        double *r = shd + BTW_SH_RED + 4;
+        if (lane == 0) { r[wv] = rs; r[NWV + wv] = bs; r[2 * NWV + wv] = max_dd; }
+        __syncthreads();
+        rs = r[0]; bs = r[NWV]; max_dd = r[2 * NWV];
+#pragma unroll
+        for (int w = 1; w < NWV; w++) { rs += r[w]; bs += r[NWV + w]; if (r[2 * NWV + w] > max_dd) max_dd = r[2 * NWV + w]; }
+    }
+    const double ret_sum = rs;
+    const double DAYS = 252.0, RF = 0.03;
+    const double total_return = (last_eq - init) / init;
+    const double mean = ret_sum / (double)T;
+    const double dof = fmax((double)T - 1.0, 1.0);
+    const double bmean = bs / (double)T;
+    double vs = 0.0, bvs = 0.0, cvs = 0.0;
+    {
+        double pb = pb0;
+        for (int b0 = 0; b0 < nrow; b0 += 4) {
+            double rr[4], bv[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                rr[u] = b0 + u < nrow ? erow[b0 + u] : mean;
+                bv[u] = 0.0; pv[u] = pb;
+                if (has_bench) { bv[u] = b0 + u < nrow ? brow[b0 + u] : 0.0; if (b0 + u < nrow) pb = bv[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double dlt = rr[u] - mean;
+                if (b0 + u < nrow) vs += dlt * dlt;
+                if (has_bench) {
+                    const double br = (pv[u] > 0.0) ? (bv[u] - pv[u]) / pv[u] : 0.0;
+                    const double db = br - bmean;
+                    if (b0 + u < nrow) { bvs += db * db; cvs += dlt * db; }
+                }
+            }
+        }
+    }
+    wave_sum3(vs, bvs, cvs);
+    group3(1, vs, bvs, cvs);
+    if (wv != 0) return;
+    const double ann = (total_return > -1.0) ? pow(1.0 + total_return, DAYS / (double)T) - 1.0 : -1.0;
+    const double var = vs / dof;
+    const double vol = sqrt(var) * sqrt(DAYS);
+    const double sharpe = (vol > 0.0) ? (ann - RF) / vol : 0.0;
+    const double win_rate = (trades > 0) ? (double)wins / (double)trades : 0.0;
+    double alpha = 0.0, beta = 0.0;
+    if (has_bench) {
+        const double bvar = bvs / dof, cov = cvs / dof;
+        if (bvar > 0.0) beta = cov / bvar;
+        const double b0 = bm[0], b1 = bm[g.addr(T - 1)];
+        const double btr = (b0 > 0.0) ? (b1 - b0) / b0 : 0.0;
+        const double bann = (btr > -1.0) ? pow(1.0 + btr, DAYS / (double)T) - 1.0 : -1.0;
+        alpha = ann - (RF + beta * (bann - RF));
+    }
+    if (lane == 0) {
+        sm[0] = ann; sm[1] = max_dd; sm[2] = alpha; sm[3] = beta; sm[4] = sharpe;
+        sm[5] = fmax(total_return, 0.0); sm[6] = win_rate; sm[7] = (double)trades;
+    }
+}
+
+// what a helper wave does (see above); `a.summary` etc. are workgroup-uniform, so every wave passes the same barriers
+template <int NW, int NWV>
+__device__ __forceinline__ void btw_helper_wave(const BtWaveArgs &a, const BtwGeom &geo, int64_t base, int64_t s, int lane, int wv, double *px, double *bm,
+                                                const unsigned long long *evw, const double *evp, const double *evr, double *shd) {
+    const bool ns = btw_stage(geo, lane, a.price + base, px, pq_null(), wv, NWV);
+    if (a.bench) (void)btw_stage(geo, lane, a.bench + base, bm, 0.0, wv, NWV);
+    const bool any = btw_ballot(ns) != 0;
+    if (lane == 0) shd[BTW_SH_NULL + wv] = any ? 1.0 : 0.0;
+    __syncthreads(); // B1: the rows are staged
+    __syncthreads(); // B2: wave 0 has marked the events and run the cash chain
+    if (shd[BTW_SH_DENSE] != 0.0) btw_fill_tiles<NW>(a, geo, base, lane, wv, NWV, px, evw, evr, evp);
+    __syncthreads(); // B3: the equity row is complete
+    if (!a.summary) return;
+    btw_summary_mw<NWV>(geo, lane, wv, px, a.bench ? bm : nullptr, a.prm.initial_capital, 0, 0, a.summary + s * PQ_SUMMARY_COLS, shd);
+}
+
 #ifdef PQ_BTW_PROF // scripts/ab_build.sh only: per-phase device time summed over the waves, stats[4 + k] in 10 ns ticks
 #define BTW_T(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0 && a.stats) atomicAdd(a.stats + 4 + (k), t__ - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BTW_T(k)
 #endif
-template <bool MACD, int NW = 1>
-__global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
+template <bool MACD, int NW = 1, int NWV = 1>
+__global__ __launch_bounds__(64 * NWV) void bt_wave_kernel(BtWaveArgs a, Dims d) {
 #ifdef PQ_BTW_PROF
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __align__(16) unsigned char btw_lds[];
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6; // wv > 0: a helper wave (NWV > 1, btw_helper_wave)
     const int64_t s = blockIdx.x;
     const int T = (int)dims_len(d, s), C = a.C, P = a.P, PC = P - C; // (ragged: C, P, kcap are sized for the longest series)
     const unsigned magic = a.magic;
@@ -269,20 +514,29 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     unsigned long long *evw = reinterpret_cast<unsigned long long *>(bm + (a.bench ? 64 * P : 0)); // [64 * NW] event flags per block
     double *evp = reinterpret_cast<double *>(evw + 64 * NW); // [kcap + 1] event prices; then [k] = the cash after k events (k = 0: the initial capital)
     double *evr = evp + a.kcap + 1;                     // [kcap + 1] then [k] = the position after k events
+    double *shd = evr + a.kcap + 1;                     // [BTW_SH_DOUBLES] what the waves of a workgroup tell each other (NWV > 1)
     auto addr = [&](int i) { return i + (int)(((unsigned)i * magic) >> 20) * PC; };
     const pq_bt_params prm = a.prm;
     if (T == 0) {
-        if (a.summary && lane < 8) a.summary[s * PQ_SUMMARY_COLS + lane] = 0.0;
+        if (a.summary && wv == 0 && lane < 8) a.summary[s * PQ_SUMMARY_COLS + lane] = 0.0;
         return;
+    }
+    const BtwGeom geo{T, C, P, magic};
+    if constexpr (NWV > 1) {
+        if (wv != 0) { btw_helper_wave<NW, NWV>(a, geo, base, s, lane, wv, px, bm, evw, evp, evr, shd); return; }
     }
 
     // ---- phase 0: the symbol's rows, coalesced, into LDS; signal masks when the signals are inputs
     BtwBits<NW> bmask, smask; // MACD: bit b of lane c = row c*C + b; else: bit b of word k of lane w = row 64 * (w + 64 * k) + b
     bmask.clear(); smask.clear();
     bool null_seen;
-    const BtwGeom geo{T, C, P, magic};
-    null_seen = btw_stage(geo, lane, a.price + base, px, pq_null());
-    if (a.bench) (void)btw_stage(geo, lane, a.bench + base, bm, 0.0);
+    null_seen = btw_stage(geo, lane, a.price + base, px, pq_null(), 0, NWV);
+    if (a.bench) (void)btw_stage(geo, lane, a.bench + base, bm, 0.0, 0, NWV);
+    if constexpr (NWV > 1) {
+        __syncthreads(); // B1: the helpers' share of the rows is in LDS, their null flags in shd[]
+#pragma unroll
+        for (int w = 1; w < NWV; w++) null_seen |= shd[BTW_SH_NULL + w] != 0.0;
+    }
     if (!MACD) {
         btw_lds_fence();
         for (int j0 = 0; j0 < C; j0 += 8) {
@@ -369,21 +623,35 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             BTW_T(14);
             if (head) {
                 if (lane == 0) { // rows 0 .. H-1: no signal is possible yet (prev_m / prev_s are null until row H - 1)
-                    for (int b0 = 0; b0 < H; b0 += 8) { // (eight rows leave LDS together: the serial part is the sums, not the reads)
-                        double xr[8];
+                    // Rows 0 .. R1-2 only feed the two price averages, each a chain of its own (EmaCore::step's operations for the
+                    // counts 1 .. n: the sum in row order, the seed, then the recurrence): two plain loops instead of one loop with
+                    // three uniform branches per row and average -- this lane is alone on its SIMD here, every instruction counts.
+                    auto advance = [&](EmaCore &e, int p, int n) {
+                        const int ns = n < p ? n : p;
+                        for (int b0 = 0; b0 < ns; b0 += 8) { // (eight rows leave LDS together: the serial part is the sum, not the reads)
+                            double xr[8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) xr[u] = px[b0 + u < H ? b0 + u : H - 1];
+                            for (int u = 0; u < 8; u++) xr[u] = px[b0 + u < ns ? b0 + u : 0];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int cnt = b0 + u + 1;
-                            if (cnt <= H) {
-                                const double f = btw_ema_lock(st.ef, xr[u], cnt, pf), sl = btw_ema_lock(st.es, xr[u], cnt, ps);
-                                if (cnt >= R1) { // before that the signal line sees zeros: its sum and its seed stay +0.0
-                                    st.prev_m = f - sl;
-                                    st.prev_s = btw_ema_lock(st.eg, st.prev_m, cnt, pg);
-                                }
-                            }
+                            for (int u = 0; u < 8; u++) if (b0 + u < ns) e.sum += xr[u];
                         }
+                        if (n < p) return;
+                        e.ema = e.sum / (double)p;
+                        for (int b0 = p; b0 < n; b0 += 8) {
+                            double xr[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) xr[u] = px[b0 + u < n ? b0 + u : 0];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) if (b0 + u < n) e.ema = fma(e.alpha, xr[u] - e.ema, e.ema);
+                        }
+                    };
+                    advance(st.ef, pf, R1 - 1);
+                    advance(st.es, ps, R1 - 1);
+                    for (int cnt = R1; cnt <= H; cnt++) { // m exists from here on; before, the signal line saw zeros: its sum and its seed stay +0.0
+                        const double x = px[cnt - 1];
+                        const double f = btw_ema_lock(st.ef, x, cnt, pf), sl = btw_ema_lock(st.es, x, cnt, ps);
+                        st.prev_m = f - sl;
+                        st.prev_s = btw_ema_lock(st.eg, st.prev_m, cnt, pg);
                     }
                     st.ef.count = st.es.count = st.eg.count = H;
                     BTW_T(15);
@@ -762,7 +1030,16 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
             pos = 0.0; avail = prm.initial_capital; entry_cost = 0.0; trades = 0; wins = 0; flat = true;
         }
     }
-    if (dense) { // fill: tiles of 128 rows, lane l = rows 128 * jj + 2 * l, + 1
+    if constexpr (NWV > 1) {
+        if (!MACD) { // (MACD: the marking left the block words in evw[])
+#pragma unroll
+            for (int k = 0; k < NW; k++) evw[lane + 64 * k] = myword.w[k];
+        }
+        if (lane == 0) shd[BTW_SH_DENSE] = dense ? 1.0 : 0.0;
+        __syncthreads(); // B2: event words, state tables and `dense` are in LDS
+        if (dense) btw_fill_tiles<NW>(a, geo, base, lane, 0, NWV, px, evw, evr, evp);
+    }
+    if (NWV == 1 && dense) { // fill: tiles of 128 rows, lane l = rows 128 * jj + 2 * l, + 1
         const int nb2 = (T + 127) / 128;
         const bool wide = (((a.position ? reinterpret_cast<uintptr_t>(a.position + base) : 0) | (a.cash ? reinterpret_cast<uintptr_t>(a.cash + base) : 0) |
                             (a.equity ? reinterpret_cast<uintptr_t>(a.equity + base) : 0)) & 15) == 0;
@@ -929,9 +1206,11 @@ __global__ __launch_bounds__(64) void bt_wave_kernel(BtWaveArgs a, Dims d) {
     }
     btw_lds_fence();
     BTW_T(2);
+    if constexpr (NWV > 1) __syncthreads(); // B3: the equity row is complete (dense: every wave's tiles; else the block form above)
     if (!a.summary) return;
 
-    btw_summary(geo, lane, px, a.bench ? bm : nullptr, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS);
+    if constexpr (NWV > 1) btw_summary_mw<NWV>(geo, lane, 0, px, a.bench ? bm : nullptr, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS, shd);
+    else btw_summary(geo, lane, px, a.bench ? bm : nullptr, prm.initial_capital, trades, wins, a.summary + s * PQ_SUMMARY_COLS);
     BTW_T(3);
 }
 
@@ -1110,6 +1389,6 @@ static inline bool btw_plan(const pq_batch *b, int64_t fast, int64_t slow, int64
     }
     a.kcap = 8 * C < T + 1 ? 8 * C : T + 1; // ~12 % of the rows may be events (MACD(12,26,9): 8 %) before the block form takes over
     if (a.kcap > 64 * BTW_NG) a.kcap = 64 * BTW_NG;
-    lds_bytes = (size_t)64 * a.P * 8 * (bench ? 2 : 1) + 64 * 8 * (C > 64 ? 2 : 1) + 2 * ((size_t)a.kcap + 1) * 8;
+    lds_bytes = (size_t)64 * a.P * 8 * (bench ? 2 : 1) + 64 * 8 * (C > 64 ? 2 : 1) + 2 * ((size_t)a.kcap + 1) * 8 + BTW_SH_DOUBLES * 8;
     return true;
 }

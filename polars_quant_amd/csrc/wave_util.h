@@ -48,29 +48,32 @@ struct BtwGeom {
     unsigned magic; // ceil(2^20 / C)
     __device__ __forceinline__ int addr(int i) const { return i + (int)(((unsigned)i * magic) >> 20) * (P - C); }
 };
-// one column of the symbol, coalesced, into LDS (rows >= T: `fill`); returns whether this lane saw a NULL row
-__device__ __forceinline__ bool btw_stage(const BtwGeom &g, int lane, const double *src, double *dst, double fill) {
+// one column of the symbol, coalesced, into LDS (rows >= T: `fill`); returns whether this lane saw a NULL row.  `part` of `nparts`: the
+// waves of a workgroup that share one symbol take the access batches in turn
+__device__ __forceinline__ bool btw_stage(const BtwGeom &g, int lane, const double *src, double *dst, double fill, int part = 0, int nparts = 1) {
     const int T = g.T, C = g.C;
     bool null_seen = false;
     auto addr = [&](int i) { return g.addr(i); };
     {
         if (((reinterpret_cast<uintptr_t>(src) & 15) == 0)) { // 16 bytes per lane: rows 128 * j + 2 * lane, + 1
             const int npair = (64 * C + 127) / 128; // every LDS row below 64 * C is written (a ragged batch sizes C for its LONGEST group: rows in [T, 64 * C) get `fill`)
-            for (int j0 = 0; j0 < npair; j0 += 8) {
+            for (int j0 = 0; j0 * nparts < npair; j0 += 8) {
                 double2 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = 128 * (j0 + u) + 2 * lane;
+                    const int j = (j0 + u) * nparts + part;
+                    const int i = 128 * j + 2 * lane;
                     v[u] = make_double2(fill, fill);
-                    if (j0 + u < npair) {
+                    if (j < npair) {
                         if (i + 1 < T) v[u] = *reinterpret_cast<const double2 *>(src + i);
                         else if (i < T) v[u].x = src[i];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = 128 * (j0 + u) + 2 * lane;
-                    if (j0 + u < npair && i < 64 * C) {
+                    const int j = (j0 + u) * nparts + part;
+                    const int i = 128 * j + 2 * lane;
+                    if (j < npair && i < 64 * C) {
                         dst[addr(i)] = v[u].x;
                         dst[addr(i + 1)] = v[u].y;
                         null_seen |= (i < T && pq_isnull(v[u].x)) || (i + 1 < T && pq_isnull(v[u].y));
@@ -78,17 +81,19 @@ __device__ __forceinline__ bool btw_stage(const BtwGeom &g, int lane, const doub
                 }
             }
         } else {
-            for (int j0 = 0; j0 < C; j0 += 8) {
+            for (int j0 = 0; j0 * nparts < C; j0 += 8) {
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = 64 * (j0 + u) + lane;
-                    v[u] = (j0 + u < C && i < T) ? src[i] : fill;
+                    const int j = (j0 + u) * nparts + part;
+                    const int i = 64 * j + lane;
+                    v[u] = (j < C && i < T) ? src[i] : fill;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = 64 * (j0 + u) + lane;
-                    if (j0 + u < C) {
+                    const int j = (j0 + u) * nparts + part;
+                    const int i = 64 * j + lane;
+                    if (j < C) {
                         dst[addr(i)] = v[u];
                         null_seen |= i < T && pq_isnull(v[u]);
                     }

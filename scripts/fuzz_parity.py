@@ -178,8 +178,14 @@ def _long_backtest(rng, log) -> int:
     kw = dict(initial_capital=float(rng.choice([100000.0, 30.0, 1e7])), position_size=float(rng.choice([1.0, 0.5])),
               buy_slippage=float(rng.choice([0.0, 0.01])), sell_slippage=float(rng.choice([0.0, 0.02])), min_commission=float(rng.choice([5.0, 0.0, 1.0])))
     bad = 0
+    waves = str(rng.choice(["", "1", "4"]))   # "": the library's own choice; else the one-wave / four-wave form of the kernels, forced
+    if waves:
+        os.environ["PQ_BT_WAVES"] = waves
+    else:
+        os.environ.pop("PQ_BT_WAVES", None)
     def cmp(tag, got, exp):
         nonlocal bad
+        tag = f"{tag} waves={waves!r}"
         for nm, g, e in zip(("position", "cash", "equity"), got[:3], exp[:3]):
             g = g.cpu().numpy()
             ok = (_bits(g) == _bits(e)) | ((g != g) & (e != e))
@@ -213,6 +219,7 @@ def _long_backtest(rng, log) -> int:
             api.backtest_vectorized(torch.from_numpy(price).cuda(), torch.from_numpy(buy).cuda(), torch.from_numpy(sell).cuda(),
                                     benchmark=None if bm is None else torch.from_numpy(bm).cuda(), **kw),
             oracle.backtest(price, buy, sell, benchmark=bm, **kw))
+    os.environ.pop("PQ_BT_WAVES", None)
     return bad
 
 

@@ -65,8 +65,19 @@ def special_prices(oracle, n, T):
     return d, close
 
 
+@pytest.fixture(params=["auto", "1"], ids=["waves-auto", "one-wave"])
+def waves(request, monkeypatch):
+    """The kernels share a symbol among four wavefronts (staging, fill, summary) except on batches of 4-5 x #CUs symbols and on
+    series beyond 4096 rows: "1" forces the one-wave form, which small test batches would otherwise never run."""
+    if request.param == "auto":
+        monkeypatch.delenv("PQ_BT_WAVES", raising=False)
+    else:
+        monkeypatch.setenv("PQ_BT_WAVES", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("T", [2520, 4096, 1000, 641, 640, 129, 65, 64, 63, 2, 1, 4097, 5040, 8191, 8192])  # > 4096: two mask words per lane
-def test_macd_cross_wave_form(pq, oracle, T, monkeypatch):
+def test_macd_cross_wave_form(pq, oracle, T, monkeypatch, waves):
     from polars_quant_amd import api
     n = 24
     _, close = special_prices(oracle, n, T)
@@ -101,7 +112,7 @@ def test_macd_cross_wave_form(pq, oracle, T, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [2520, 4096, 777, 65, 1, 4097, 5040, 8192])
-def test_vectorized_wave_form(pq, oracle, T):
+def test_vectorized_wave_form(pq, oracle, T, waves):
     from polars_quant_amd import api
     n = 20
     d, price = special_prices(oracle, n, T)
@@ -147,7 +158,7 @@ def test_wave_form_equals_lane_form_and_long_series_fall_back(pq, oracle, monkey
     assert (bits(eq.cpu().numpy()) == bits(eeq)).all() and (bits(pos.cpu().numpy()) == bits(epos)).all()
 
 
-def test_full_size_config3_wave_backtest(pq, oracle):
+def test_full_size_config3_wave_backtest(pq, oracle, waves):
     """BASELINE config 3 (5000 x 2520) on the bench's layout (row pitch 2528): EVERY symbol against the oracle, plus the
     size-independent properties."""
     from polars_quant_amd import api
