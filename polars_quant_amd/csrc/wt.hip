@@ -16,6 +16,10 @@ bool wt_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, d
     WtEmaAllOp w{real, ema, dema, tema, trix, (int32_t)p};
     InCols<1> in{{real}};
     const int n = (ema != nullptr) + (dema != nullptr) + (tema != nullptr) + (trix != nullptr);
+    // DEMA / TEMA at timeperiod 1: every seeding branch of the reference's if-chain (overlap.rs:590-597, :1238-1240) falls on the first
+    // row and only the first is taken -- the later averages start from 0.0 instead of being seeded, and TEMA's first row is null.  The
+    // lane-per-symbol ops restate the chain literally; this form seeds every level properly, so it leaves p = 1 to them.
+    if ((dema || tema) && p < 2) return false;
     if (n == 4) {
         EmaAllOp op{};
         op.a.a.p = p; op.a.b.p = p; op.b.a.p = p; op.b.b.p = p;

@@ -130,7 +130,7 @@ def _long_indicator(rng, name, log) -> int:
     params = {}
     for pname, kind, _default in pspec:
         if kind == I:
-            params[pname] = int(rng.integers(0, 9)) if "matype" in pname else int(rng.choice([2, 3, 5, 9, 14, 26, 30, 60, 200, int(rng.integers(2, 300))]))
+            params[pname] = int(rng.integers(0, 9)) if "matype" in pname else int(rng.choice([1, 2, 3, 5, 9, 14, 26, 30, 60, 200, int(rng.integers(1, 300))]))
         elif name == "mama":
             params[pname] = float(rng.choice([0.02, 0.05, 0.2, 0.5]))
         else:

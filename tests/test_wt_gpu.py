@@ -86,6 +86,37 @@ def test_single_functions(pq, oracle, data, name, cols, prm):
         same(f"{name}[{k}]{prm}", g.cpu().numpy(), e)
 
 
+@pytest.mark.parametrize("name", ["dema", "tema", "ema", "trix", "rsi", "atr", "natr", "adx", "macd", "midpoint"])
+def test_timeperiod_one(pq, oracle, name):
+    """Period 1 is where the reference's if-chains degenerate: every seeding branch of DEMA / TEMA (overlap.rs:590-597, :1238-1240)
+    falls on the first row and only the first is taken -- the later averages start from 0.0 and TEMA's first row is null -- so
+    those two leave p = 1 to the lane-per-symbol ops that restate the chain literally (found by the ragged fuzz, seed 602); every
+    other form handles it itself.  Regular and ragged batches."""
+    from polars_quant_amd import api
+    cols, pspec = pq.SPEC[name][0], pq.SPEC[name][1]
+    prm = {pn: 1 for pn, kind, _ in pspec if kind == "i"}
+    d = oracle.gen_ohlcv(SEED + 21, 70, 1500, 0)
+    d["real"] = d["close"]
+    d["close"][3, 700] *= 5.0   # a jump of more than 2 x: (x - e) + e is no longer exactly x
+    d["real"] = d["close"]
+    got = api.call(name, *[torch.from_numpy(d[c]).cuda() for c in cols], **prm)
+    exp = oracle.call(name, *[d[c] for c in cols], **prm)
+    for k, (g, e) in enumerate(zip(got, exp)):
+        same(f"{name}[{k}] p=1", g.cpu().numpy(), e)
+    lens = np.array([1500, 1100, 1, 0, 2000], dtype=np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    long = {k: np.ascontiguousarray(v[0]) for k, v in oracle.gen_ohlcv(SEED + 22, 1, int(off[-1]), 0).items()}
+    long["real"] = long["close"]
+    got = [g.cpu().numpy() for g in api.call(name, *[torch.from_numpy(long[c]).cuda() for c in cols], offsets=off, **prm)]
+    for s_ in range(len(lens)):
+        lo, hi = int(off[s_]), int(off[s_ + 1])
+        if hi == lo:
+            continue
+        exp = oracle.call(name, *[long[c][lo:hi] for c in cols], **prm)
+        for k, (g, e) in enumerate(zip(got, exp)):
+            same(f"{name}[{k}] p=1 group {s_}", g[lo:hi], np.asarray(e).reshape(-1))
+
+
 def test_fused_forms_and_pitched_columns(pq, oracle):
     """the multi-output entry points the suite records (pq_ema_all, pq_macd_pair, pq_dm_system_all, pq_dm_pair, pq_cmo_rsi) on a row
     pitch that is not the row count"""
