@@ -251,6 +251,74 @@ def test_every_exported_function_through_its_plugin_symbol(oracle, name):
 
 
 @pytest.mark.gpu
+def test_plugin_randomised_chunks_lengths_and_periods(oracle):
+    """200 random calls through the plugin symbols: a random function, a series of 0 .. 3000 rows cut into 1 .. 5 chunks (some of them
+    slices with a non-zero offset, some empty), nulls where the reference accepts them, the period as default / pickled kwargs /
+    trailing literal -- against the oracle on the concatenated column."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from polars_quant_amd._spec import SPEC
+    L = _lib()
+    rng = np.random.default_rng(0x5EED0077)
+    names = sorted(PLUGIN_FUNCS)
+    for it in range(200):
+        name = names[int(rng.integers(0, len(names)))]
+        cols, params, _outs, fam = SPEC[name]
+        n = int(rng.choice([0, 1, 2, 31, 32, 33, 64, 65, 500, int(rng.integers(0, 3000))]))
+        d = oracle.gen_ohlcv(int(rng.integers(1, 1 << 30)), 1, max(n, 1), 0)
+        data = {c: d["close" if c == "real" else c][0][:n].copy() for c in cols}
+        mask = (rng.random(n) < 0.02) if (fam != "N-B" and rng.random() < 0.5) else np.zeros(n, bool)
+        nullcol = cols[-1] if cols[-1] != "volume" else cols[-2]
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 5)))]))
+        keep, ses = [], []
+        for c in cols:
+            arr = pa.array(data[c], mask=mask if c == nullcol else None)
+            chunks = []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                ch = arr.slice(lo, hi - lo)
+                if rng.random() < 0.3:   # a slice of a longer array: a non-zero offset into values and validity
+                    pad = int(rng.integers(1, 9))
+                    ch = pa.concat_arrays([pa.array(np.full(pad, 1e300)), ch]).slice(pad)
+                chunks.append(ch)
+            if not chunks:
+                chunks = [arr]
+            se, k = _export(chunks, c)
+            ses.append(se); keep.append(k)
+        has_tp = len(params) == 1
+        mode = int(rng.integers(0, 3)) if has_tp else 0
+        period = params[0][2] if has_tp else None
+        kwb, extra = None, []
+        if mode == 1:
+            period = int(rng.choice([0, 1, 2, 5, 14, 30, 100, n, n + 1]))
+            kwb = pickle.dumps({"timeperiod": period})
+        elif mode == 2:
+            period = int(rng.choice([1, 2, 5, 14, 30, 100, max(n, 1)]))
+            se1, k1 = _export([pa.array([period], type=pa.int64())], "literal")
+            extra, keep = [se1], keep + [k1]
+        ins = (SeriesExport * (len(ses) + len(extra)))(*ses, *extra)
+        ret = SeriesExport()
+        getattr(L, "_polars_plugin_" + name)(ins, len(ses) + len(extra), kwb, len(kwb) if kwb else 0, C.byref(ret), None)
+        assert ret.release, (name, n, cuts, mode, period, L._polars_plugin_get_last_error_message())
+        got = _import(ret)
+        assert len(got) == n, (name, n, len(got))
+        if n == 0:
+            continue
+        ref_in = {c: data[c].copy() for c in cols}
+        ref_in[nullcol][mask] = oracle.NULL
+        (exp,) = oracle.call(name, *[ref_in[c] for c in cols], **({"timeperiod": period} if has_tp else {}))
+        exp = np.asarray(exp).reshape(-1)
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert (np.asarray(got.is_null()) == en).all(), (name, n, cuts, mode, period)
+        g = got.to_numpy(zero_copy_only=False)[~en]
+        if name in ("ht_dcperiod", "ht_dcphase"):
+            np.testing.assert_allclose(g, exp[~en], rtol=1e-12, atol=1e-12)
+        else:
+            ok = (g.view(np.uint64) == exp[~en].view(np.uint64)) | (np.isnan(g) & np.isnan(exp[~en]))
+            assert ok.all(), (name, n, cuts, mode, period, int((~ok).sum()))
+
+
+@pytest.mark.gpu
 def test_every_pattern_through_its_plugin_symbol(oracle):
     """The 61 recognisers: (open, high, low, close) in two chunks -> Int32, penetration default 0.3 (pattern.rs:529-532) and as a
     Float64 literal; a null is refused (cont_slice)."""
