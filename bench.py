@@ -42,7 +42,10 @@ def source_hash() -> str:
     (scripts/pmc_summary.py writes the same hash into it; .git does not travel to the GPU box)"""
     import hashlib
     h = hashlib.sha256()
+    host_only = {"plugin.hip", "comm.hip"}     # no device code: the Polars plugin exporter and the RCCL binding
     for f in sorted(list((ROOT / "polars_quant_amd" / "csrc").glob("*.hip")) + list((ROOT / "polars_quant_amd" / "csrc").glob("*.h"))):
+        if f.name in host_only:
+            continue
         h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

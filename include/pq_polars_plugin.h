@@ -55,10 +55,13 @@ typedef struct pq_series_export {
 
 uint32_t _polars_plugin_get_version(void);                       /* (major << 16) | minor = 0.1 */
 const char *_polars_plugin_get_last_error_message(void);        /* thread-local, set when a call leaves return_value empty */
-/* One pair of symbols (+ the _over pair) per reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64.
+/* One pair of symbols (+ the _over pair) per reference function of the shape (1..4 numeric columns[, timeperiod]) -> Float64.
  *   _polars_plugin_<f>(inputs, n_inputs, kwargs, kwargs_len, return_value, context)
  *       inputs: `n_inputs` exported Series -- the columns in the reference's order (high, low, close, volume ...), optionally
- *       followed by the period as a literal Series (momentum.rs / volatility.rs: `inputs[k].i64()?.get(0)`);
+ *       followed by the period as a literal Series (momentum.rs / volatility.rs: `inputs[k].i64()?.get(0)`).  A column may be
+ *       of any numeric Arrow type -- int8 .. uint64 (c C s S i I l L), float16 / 32 / 64 (e f g) or Boolean (b): it is cast to
+ *       Float64 on the way in, as every reference function does with `inputs[k].cast(&DataType::Float64)?` (overlap.rs:120,129,
+ *       momentum.rs:12, volume.rs:19-31, pattern.rs:11-17, cycle.rs:11); only a non-numeric column is an error;
  *       kwargs: pickle bytes of {"timeperiod": n} or NULL/0 (overlap.rs:11-28 MaKwargs); return_value: filled on success
  *       (release != NULL), left zeroed on failure with the message in _polars_plugin_get_last_error_message().  A null in the
  *       input of a function that goes through `rechunk().cont_slice()?` in the reference (momentum / cycle family) is such a failure.

@@ -119,20 +119,54 @@ typedef pq_status (*col_fn)(pq_ctx *, const pq_batch *, const double *const *in,
 typedef pq_status (*cols_fn)(pq_ctx *, const pq_batch *, const double *const *in, const double *pv, double *const *out);
 struct PParam { const char *name; bool is_float; double def; };
 struct PlugFn { const char *name; int nin; int nparams; PParam params[8]; bool reject_nulls; bool out_i32; col_fn call;
-                unsigned int_inputs; /* bit k: input k may be an Int64 / Int32 column (it is converted to f64) */ };
+                unsigned int_inputs; /* bit k: input k is an integer-valued column in the reference (MAVP periods, overlap.rs:407-414); documentation only: every numeric column is accepted */ };
 
-// gather the chunks of one exported Float64 Series into a host column + a validity bitmap (bit = 1: valid)
+// every reference function starts with `inputs[k].cast(&DataType::Float64)?` (overlap.rs:120,129, momentum.rs:12, volume.rs:19-31,
+// pattern.rs:11-17, cycle.rs:11): any numeric column is accepted and converted on the host gather with the conversion Polars' cast uses
+// (Rust `as f64`: exact for every integer up to 2^53 and for f32 / f16, round-to-nearest-even for wider 64-bit integers; Boolean ->
+// 0.0 / 1.0).  Arrow formats: c C s S i I l L (int8 .. uint64), e f g (float16 / 32 / 64), b (bit-packed Boolean).
+bool numeric_format(const char *fm) { return fm && fm[0] && !fm[1] && strchr("cCsSiIlLefgb", fm[0]) != nullptr; }
+double half_to_double(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15), ex = (h >> 10) & 31u, man = h & 1023u;
+    double v;
+    if (ex == 0) v = ldexp((double)man, -24);                      // zero / subnormal
+    else if (ex == 31) {                                            // inf / NaN (payload shifted like a hardware conversion)
+        uint64_t b = 0x7FF0000000000000ull | ((uint64_t)man << 42);
+        memcpy(&v, &b, 8);
+    } else v = ldexp((double)(man | 1024u), (int)ex - 25);
+    return sign ? -v : v;
+}
+template <typename T> void widen(const void *buf, int64_t off, int64_t len, double *dst) {
+    const T *p = (const T *)buf + off;
+    for (int64_t i = 0; i < len; i++) dst[i] = (double)p[i];
+}
+// gather the chunks of one exported numeric Series into a host f64 column + a validity bitmap (bit = 1: valid)
 bool gather_f64(const pq_series_export &in, int64_t n, std::vector<double> &host, std::vector<uint8_t> &validity, bool &any_null) {
-    const char fmt = in.field && in.field->format ? in.field->format[0] : 'g'; // 'g' f64, 'l' i64, 'i' i32
+    const char fmt = in.field && in.field->format ? in.field->format[0] : 'g';
     host.resize((size_t)(n > 0 ? n : 1));
     validity.assign((size_t)((n + 7) / 8 + 1), 0xff);
     int64_t pos = 0;
     for (size_t c = 0; c < in.len; c++) {
         const ArrowArray *a = in.arrays[c];
         if (a->n_buffers < 2 || (!a->buffers[1] && a->length)) return false;
-        if (fmt == 'l') for (int64_t i = 0; i < a->length; i++) host[(size_t)(pos + i)] = (double)((const int64_t *)a->buffers[1])[a->offset + i];
-        else if (fmt == 'i') for (int64_t i = 0; i < a->length; i++) host[(size_t)(pos + i)] = (double)((const int32_t *)a->buffers[1])[a->offset + i];
-        else if (a->length) memcpy(host.data() + pos, (const double *)a->buffers[1] + a->offset, (size_t)a->length * 8);
+        double *dst = host.data() + pos;
+        const void *buf = a->buffers[1];
+        switch (a->length ? fmt : 0) {
+        case 0: break;
+        case 'g': memcpy(dst, (const double *)buf + a->offset, (size_t)a->length * 8); break;
+        case 'f': widen<float>(buf, a->offset, a->length, dst); break;
+        case 'e': for (int64_t i = 0; i < a->length; i++) dst[i] = half_to_double(((const uint16_t *)buf)[a->offset + i]); break;
+        case 'l': widen<int64_t>(buf, a->offset, a->length, dst); break;
+        case 'L': widen<uint64_t>(buf, a->offset, a->length, dst); break;
+        case 'i': widen<int32_t>(buf, a->offset, a->length, dst); break;
+        case 'I': widen<uint32_t>(buf, a->offset, a->length, dst); break;
+        case 's': widen<int16_t>(buf, a->offset, a->length, dst); break;
+        case 'S': widen<uint16_t>(buf, a->offset, a->length, dst); break;
+        case 'c': widen<int8_t>(buf, a->offset, a->length, dst); break;
+        case 'C': widen<uint8_t>(buf, a->offset, a->length, dst); break;
+        case 'b': for (int64_t i = 0; i < a->length; i++) { const int64_t bi = a->offset + i; dst[i] = (double)((((const uint8_t *)buf)[bi >> 3] >> (bi & 7)) & 1); } break;
+        default: return false;
+        }
         const uint8_t *vb = (const uint8_t *)a->buffers[0];
         if (vb && a->null_count != 0)
             for (int64_t i = 0; i < a->length; i++) {
@@ -232,6 +266,7 @@ static pq_status over_batch(pq_ctx *ctx, const pq_series_export &key, int64_t n,
     return PQ_OK;
 }
 
+static const char *const k_not_numeric = "plugin: the input column is not numeric (int8 .. uint64, float16 / 32 / 64 and Boolean are cast to Float64 like the reference's inputs[k].cast(&DataType::Float64))";
 bool read_params(const PParam *params, int nparams, int nin, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs,
                  size_t kwargs_len, double (&pv)[8]);
 void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const uint8_t *kwargs, size_t kwargs_len, pq_series_export *ret, bool over = false) {
@@ -240,9 +275,7 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     if (!inputs || (int)n_inputs < f.nin + (over ? 1 : 0) || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
     for (int k = 0; k < f.nin; k++) {
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
-        const char *fm = inputs[k].field->format;
-        const bool int_ok = ((f.int_inputs >> k) & 1) && (!strcmp(fm, "l") || !strcmp(fm, "i"));
-        if (strcmp(fm, "g") != 0 && !int_ok) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+        if (!numeric_format(inputs[k].field->format)) { plugin_fail(k_not_numeric); return; }
     }
     double pv[8];
     if (!read_params(f.params, f.nparams, f.nin + (over ? 1 : 0), inputs, n_inputs, kwargs, kwargs_len, pv)) return;
@@ -253,7 +286,7 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     std::vector<uint8_t> valid[4];
     bool nulls[4] = {false, false, false, false}, any_null = false;
     for (int k = 0; k < f.nin; k++) {
-        if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed Float64 chunk"); return; }
+        if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed input chunk"); return; }
         any_null |= nulls[k];
     }
     // the momentum / cycle families go through rechunk().cont_slice()? in the reference (momentum.rs:12-13): a null is an error there
@@ -374,7 +407,7 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
     if (!inputs || (int)n_inputs < f.nin + (over ? 1 : 0) || !ret) { plugin_fail("plugin: bad arguments (too few input Series)"); return; }
     for (int k = 0; k < f.nin; k++) {
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
-        if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+        if (!numeric_format(inputs[k].field->format)) { plugin_fail(k_not_numeric); return; }
     }
     double pv[8];
     if (!read_params(f.params, f.nparams, f.nin + (over ? 1 : 0), inputs, n_inputs, kwargs, kwargs_len, pv)) return;
@@ -384,7 +417,7 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
     bool nulls[2] = {false, false}, any_null = false;
     for (int k = 0; k < f.nin; k++) {
         if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
-        if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed Float64 chunk"); return; }
+        if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed input chunk"); return; }
         any_null |= nulls[k];
     }
     if (any_null && f.reject_nulls) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
@@ -459,7 +492,7 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
     if (!inputs || n_inputs < 4 || !ret) { plugin_fail("plugin: bad arguments (open, high, low, close expected)"); return; }
     for (int k = 0; k < 4; k++) {
         if (!inputs[k].field || !inputs[k].field->format || (inputs[k].len && !inputs[k].arrays)) { plugin_fail("plugin: bad arguments"); return; }
-        if (strcmp(inputs[k].field->format, "g") != 0) { plugin_fail("plugin: the input must be Float64 (cast before the call)"); return; }
+        if (!numeric_format(inputs[k].field->format)) { plugin_fail(k_not_numeric); return; }
     }
     double pen = 0.3;
     const size_t pi = over ? 5 : 4; // the penetration literal follows the key column of an _over call
@@ -473,7 +506,7 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
     bool any_null = false;
     for (int k = 0; k < 4; k++) {
         if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
-        if (!gather_f64(inputs[k], n, host[k], valid, any_null)) { plugin_fail("plugin: malformed Float64 chunk"); return; }
+        if (!gather_f64(inputs[k], n, host[k], valid, any_null)) { plugin_fail("plugin: malformed input chunk"); return; }
     }
     if (any_null) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
     OutPriv *op = new OutPriv();

@@ -174,14 +174,113 @@ def test_plugin_calls_match_the_oracle(oracle):
     en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
     assert (np.asarray(got.is_null()) == en).all()
     assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all()
-    # (c) output field + error path (a non-Float64 input is refused with a message, return_value stays empty)
+    # (c) output field + error path (a NON-NUMERIC input is refused with a message, return_value stays empty)
     out_field = ArrowSchema()
     L._polars_plugin_field_ema(se0.field, 1, C.byref(out_field), None, 0)
     assert out_field.format == b"g" and out_field.name == b"px"
-    sei, keepi = _export([pa.array([1, 2, 3], type=pa.int64())], "ints")
+    sei, keepi = _export([pa.array(["1", "2", "3"], type=pa.string())], "strs")
     ret = SeriesExport()
     L._polars_plugin_ema(C.byref(sei), 1, None, 0, C.byref(ret), None)
-    assert not ret.release and b"Float64" in L._polars_plugin_get_last_error_message()
+    assert not ret.release and b"not numeric" in L._polars_plugin_get_last_error_message()
+
+
+def _plugin_call(L, name, series, kwargs=None, literals=()):
+    """series: [(pyarrow chunks, name)]; literals: trailing one-row literal arrays -> the imported result array"""
+    ses, keep = [], []
+    for chunks, nm in list(series) + [([lit], "literal") for lit in literals]:
+        se, k = _export(chunks, nm)
+        ses.append(se); keep.append(k)
+    ins = (SeriesExport * len(ses))(*ses)
+    kw = pickle.dumps(kwargs) if kwargs else None
+    ret = SeriesExport()
+    getattr(L, "_polars_plugin_" + name)(ins, len(ses), kw, len(kw) if kw else 0, C.byref(ret), None)
+    assert ret.release, (name, L._polars_plugin_get_last_error_message())
+    return _import(ret)
+
+
+def _same_array(a, b):
+    assert a.type == b.type and len(a) == len(b) and a.null_count == b.null_count
+    na, nb = np.asarray(a.is_null()), np.asarray(b.is_null())
+    assert (na == nb).all()
+    va, vb = a.to_numpy(zero_copy_only=False)[~na], b.to_numpy(zero_copy_only=False)[~nb]
+    if a.type == pa.float64():
+        assert (va.view(np.uint64) == vb.view(np.uint64)).all()
+    else:
+        assert (va == vb).all()
+
+
+@pytest.mark.gpu
+def test_plugin_casts_numeric_columns_like_the_reference(oracle):
+    """Every reference function begins with `inputs[k].cast(&DataType::Float64)?` (overlap.rs:120,129; momentum.rs:12; volume.rs:19-31;
+    pattern.rs:11-17): an Int64 `volume`, a Float32 OHLC frame or an unsigned column must give, bit for bit, what the same values
+    give as Float64 columns -- through the plain and the `_over` symbols, chunked, with nulls where the function accepts them."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    n = 600
+    d = oracle.gen_ohlcv(0x5EED00CA, 1, n, 0)
+    f32 = {c: d[c][0].astype(np.float32) for c in ("open", "high", "low", "close")}
+    as64 = {c: f32[c].astype(np.float64) for c in f32}                     # what a cast of the f32 column yields
+    vol_i = np.round(d["volume"][0]).astype(np.int64)
+    vol_f = vol_i.astype(np.float64)
+    mask = np.zeros(n, bool); mask[[3, 250, 251]] = True
+
+    def chunks(values, typ, msk=None):
+        arr = pa.array(values, type=typ, mask=msk)
+        return [arr.slice(0, 170), arr.slice(170, 0), pa.concat_arrays([arr.slice(0, 2), arr.slice(170)]).slice(2)]
+
+    def pair(name, cols_cast, cols_f64, kwargs=None, literals=()):
+        got = _plugin_call(L, name, cols_cast, kwargs, literals)
+        want = _plugin_call(L, name, cols_f64, kwargs, literals)
+        _same_array(got, want)
+        return got
+
+    # Int64 volume through OBV / AD / MFI (volume.rs:19-31, :70; momentum.rs:286-295)
+    for vt in (pa.int64(), pa.int32(), pa.uint32(), pa.uint64()):
+        pair("obv", [(chunks(as64["close"], pa.float64(), mask), "close"), (chunks(vol_i, vt), "volume")],
+             [(chunks(as64["close"], pa.float64(), mask), "close"), (chunks(vol_f, pa.float64()), "volume")])
+    hlc64 = [(chunks(as64[c], pa.float64()), c) for c in ("high", "low", "close")]
+    r = pair("ad", hlc64 + [(chunks(vol_i, pa.int64()), "volume")], hlc64 + [(chunks(vol_f, pa.float64()), "volume")])
+    (exp,) = oracle.call("ad", as64["high"], as64["low"], as64["close"], vol_f)
+    assert (r.to_numpy(zero_copy_only=False).view(np.uint64) == exp.view(np.uint64)).all()
+    lit = pa.array([10], type=pa.int64())
+    pair("mfi", hlc64 + [(chunks(vol_i, pa.int64()), "volume")], hlc64 + [(chunks(vol_f, pa.float64()), "volume")], literals=(lit,))
+    # Float32 OHLC through ATR (volatility.rs:18-31), one recogniser (pattern.rs:11-17) and a Struct-valued function
+    hlc32 = [(chunks(f32[c], pa.float32(), mask if c == "low" else None), c) for c in ("high", "low", "close")]
+    hlc64n = [(chunks(as64[c], pa.float64(), mask if c == "low" else None), c) for c in ("high", "low", "close")]
+    pair("atr", hlc32, hlc64n, literals=(pa.array([9], type=pa.int64()),))
+    ohlc32 = [(chunks(f32[c], pa.float32()), c) for c in ("open", "high", "low", "close")]
+    ohlc64 = [(chunks(as64[c], pa.float64()), c) for c in ("open", "high", "low", "close")]
+    for cdl in ("cdlengulfing", "cdldoji", "cdlmorningstar"):
+        r = pair(cdl, ohlc32, ohlc64)
+        assert r.type == pa.int32()
+        assert (r.to_numpy() == oracle.pattern(cdl, *[as64[c][None, :] for c in ("open", "high", "low", "close")])[0]).all()
+    got = _plugin_call(L, "bbands", [(chunks(f32["close"], pa.float32(), mask), "close")], {"timeperiod": 10})
+    want = _plugin_call(L, "bbands", [(chunks(as64["close"], pa.float64(), mask), "close")], {"timeperiod": 10})
+    assert got.type == want.type
+    for k in range(3):
+        _same_array(got.field(k), want.field(k))
+    # small integers, unsigned, half precision and Boolean through SMA (overlap.rs:494-500)
+    small = (np.arange(n) * 7919 % 251).astype(np.int64)
+    for typ, vals in ((pa.uint32(), small), (pa.uint8(), small), (pa.int8(), small - 125), (pa.int16(), small * 100 - 12000),
+                      (pa.uint16(), small * 257), (pa.float16(), (small / 8.0).astype(np.float16)), (pa.bool_(), small % 3 == 0)):
+        v64 = np.asarray(vals).astype(np.float64)
+        r = pair("sma", [(chunks(vals, typ, mask), "x")], [(chunks(v64, pa.float64(), mask), "x")], {"timeperiod": 5})
+        xn = v64.copy(); xn[mask] = oracle.NULL
+        (exp,) = oracle.call("sma", xn, timeperiod=5)
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert (np.asarray(r.is_null()) == en).all()
+        assert (r.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all()
+    # 64-bit integers beyond 2^53 round to nearest even, like Rust's `as f64`
+    big = np.array([2 ** 53 + 1, 2 ** 53 + 3, -(2 ** 62) - 1, 2 ** 63 - 1, 5], dtype=np.int64)
+    r = _plugin_call(L, "medprice", [([pa.array(big)], "high"), ([pa.array(big)], "low")])
+    assert (r.to_numpy() == (big.astype(np.float64) + big.astype(np.float64)) / 2.0).all()
+    # the _over twin casts as well (ragged groups: 3 groups of unequal length)
+    key = np.repeat(np.array([3, 1, 2], dtype=np.int64), [250, 100, 250])
+    got = _plugin_call(L, "rsi_over", [([pa.array(f32["close"])], "close"), ([pa.array(key)], "symbol")], literals=(pa.array([14], type=pa.int64()),))
+    want = _plugin_call(L, "rsi_over", [([pa.array(as64["close"])], "close"), ([pa.array(key)], "symbol")], literals=(pa.array([14], type=pa.int64()),))
+    _same_array(got, want)
 
 
 @pytest.mark.gpu
