@@ -34,7 +34,8 @@ COPY_GBS = 4900.0   # a grid-stride 16-byte copy kernel on MI355X, read + writte
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured here: streaming read 6.1, fill 6.6 TB/s
 FUSED_FLOOR_BYTES_PER_ROW = 928   # SURVEY 8(d) second denominator: OHLCV read once (40 B) + every output of the step written once
                                   # (64 + 17 f64 indicator columns, 62 int32 columns, 3 backtest columns = 888 B)
-PMC_FILE = ROOT / "profiles" / "r04_pmc_traffic.json"
+ROUND = "r05"          # evidence under profiles/ is named per round (scripts/collect_profiles.sh writes profiles/<ROUND>_*)
+PMC_FILE = ROOT / "profiles" / f"{ROUND}_pmc_traffic.json"
 
 
 def source_hash() -> str:
@@ -244,7 +245,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (dense layout at 1 GPU, weak scaling at N GPUs)")
     ap.add_argument("--stride", type=int, default=0,
-                    help="row pitch of the device columns in elements (0 = days rounded up to a multiple of 16 = 128 B; = days: dense)")
+                    help="row pitch, in elements, of the INPUT columns the caller hands over (0 = days rounded up to a multiple of 16 = "
+                         "128 B; = days: dense).  The suite owns its outputs and re-houses inputs handed over at a pitch that is not a "
+                         "multiple of 128 B once, at record time (Suite.house); --exact-layout keeps the caller's pitch for everything")
+    ap.add_argument("--exact-layout", action="store_true", help="run on the caller's row pitch exactly (measures a slow layout as it is)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / shard ranges only (gloo on the CPU, no GPU work): what `--gpus N` would run where")
     args = ap.parse_args()
@@ -301,8 +305,8 @@ def main():
                 buf = torch.zeros((n_local, stride), dtype=torch.float64, device=dev)
                 buf[:, :T] = ohlcv[k]
                 ohlcv[k] = buf[:, :T]
-        st = Suite(n_local, T, dev, stride=stride)
-        st.record(ohlcv)   # one-time: turn the step's calls into job grids (not part of the timed region)
+        st = Suite(n_local, T, dev, stride=stride, exact_layout=args.exact_layout)
+        st.record(ohlcv)   # one-time: turn the step's calls into job grids, re-house slow-pitch inputs (not part of the timed region)
         return st, ohlcv, n_local, n_total
 
     # ---- the one exchange of the path (world > 1): per-symbol summary rows to every rank, through the PRODUCT's own collective --
@@ -341,25 +345,45 @@ def main():
         else:
             comm_note = box.get("err", "no answer within 120 s")
 
-    def time_steps(st, ohlcv, n_total, steps, warmup, timing=False):
-        def step():
-            st.run(ohlcv)
-            if world > 1:
+    from polars_quant_amd.distributed import OverlappedGather
+
+    def time_loop(run_slot, local, n_total, steps, warmup, mode, on_timed=None):
+        """`steps` timed steps of run_slot(slot) (which writes the summary rows local[slot]) + the per-step exchange:
+          overlapped  the exchange of step k on the communicator's own stream beside the kernels of step k + 1 (two slots;
+                      pq_gather_summaries_begin / _end, or torch.distributed's async collective if the C-ABI communicator is missing)
+          serial      the exchange on the step's stream behind every step (round 4's form)
+          kernel_only no exchange
+        Every exchange completes inside the timed region (drain before the closing synchronize)."""
+        og = OverlappedGather(n_total, local[0].shape[0], dev, comm=comm, local=local) if (world > 1 and mode == "overlapped") else None
+
+        def step(k):
+            if world == 1 or mode == "kernel_only":
+                run_slot(k & 1)
+            elif og is not None:
+                slot = og.acquire()
+                run_slot(slot)
+                og.begin(slot)
+            else:
+                run_slot(0)
                 if comm is not None:
-                    comm.gather_summaries(st.summary, n_total)
+                    comm.gather_summaries(local[0], n_total)
                 else:
-                    gather_summaries(st.summary, n_total)
-        for _ in range(warmup):
-            step()
+                    gather_summaries(local[0], n_total)
+        for k in range(warmup):
+            step(k)
+        if og is not None:
+            og.drain()
         torch.cuda.synchronize()
-        if timing:
-            st.set_timing(True)
+        if on_timed:
+            on_timed()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for k in range(steps):
+            step(k)
+        if og is not None:
+            og.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -371,14 +395,55 @@ def main():
             el = float(tmax.item())
         return el
 
+    def time_steps(st, ohlcv, n_total, steps, warmup, timing=False, mode="overlapped"):
+        if world > 1 and len(getattr(st, "_summaries", [])) < 2:   # two recordings of the step, one per summary buffer
+            st.record(ohlcv, summaries=[st.summary, torch.empty_like(st.summary)])
+        two = len(st._summaries) == 2
+        return time_loop(lambda slot: st.run(ohlcv, slot=slot if two else 0), st._summaries if two else [st.summary, st.summary], n_total,
+                         steps, warmup, mode, on_timed=(lambda: st.set_timing(True)) if timing else None)
+
+    def backtest_only(ohlcv, n_local, n_total, steps, warmup, stride):
+        """BASELINE config 3 by itself -- the MACD-cross backtest with summary on this rank's shard, DIRECT C-ABI calls (what
+        north_star's `>= 6x at 8 GPUs on the symbol-sharded backtest` is about): ms per step in the three exchange modes."""
+        import ctypes as C
+        from polars_quant_amd._lib import Batch, BtParams, check, lib
+        from polars_quant_amd._spec import BT_DEFAULTS
+        from polars_quant_amd.api import ctx
+        L, h, b, prm = lib(), ctx(dev.index), Batch(n_local, T, stride), BtParams(**BT_DEFAULTS)
+        close = ohlcv["close"]
+        curves = [torch.empty((n_local, stride), dtype=torch.float64, device=dev) for _ in range(3)]
+        local = [torch.empty((n_local, 8), dtype=torch.float64, device=dev) for _ in range(2)]
+
+        def run_slot(slot):
+            check(L.pq_backtest_macd_cross(h, C.byref(b), C.c_void_p(close.data_ptr()), 12, 26, 9, C.byref(prm),
+                                           *[C.c_void_p(t.data_ptr()) for t in curves], C.c_void_p(local[slot].data_ptr())))
+        res = {"symbols_per_gpu": n_local, "symbols_total": n_total, "steps": steps,
+               "what": "pq_backtest_macd_cross (signals + scan + summary, position / cash / equity columns written) on the rank's shard"}
+        for mode in (("overlapped", "serial", "kernel_only") if world > 1 else ("kernel_only",)):
+            el = time_loop(run_slot, local, n_total, steps, warmup, mode)
+            res[mode + "_ms_per_step"] = el / steps * 1e3
+        best = res.get("overlapped_ms_per_step", res["kernel_only_ms_per_step"])
+        res["value"] = n_total * T / (best * 1e-3)
+        res["unit"] = "rows/s"
+        return res
+
     suite, ohlcv, n_local, n_total = build(args.scaling)
-    elapsed = time_steps(suite, ohlcv, n_total, args.steps, args.warmup, timing=True)
+    exchange_modes = None
+    if world > 1:   # the step with the exchange in series and without it, for the record (short runs, outside the headline's timed region)
+        exchange_modes = {m + "_ms_per_step": time_steps(suite, ohlcv, n_total, max(5, args.steps // 2), 2, mode=m) / max(5, args.steps // 2) * 1e3
+                          for m in ("serial", "kernel_only")}
+    elapsed = time_steps(suite, ohlcv, n_total, args.steps, args.warmup, timing=True, mode="overlapped")
+    if exchange_modes is not None:
+        exchange_modes["overlapped_ms_per_step"] = elapsed / args.steps * 1e3
     gather_check = None
     if world > 1 and comm is not None:   # cross-check, outside the timed region: the C-ABI gather against torch.distributed's
         ref = gather_summaries(suite.summary, n_total)
         got = comm.gather_summaries(suite.summary, n_total)
         torch.cuda.synchronize()
         gather_check = bool(torch.equal(got.view(torch.int64), ref.view(torch.int64)))
+    bt_only = None
+    if not args.no_secondary:
+        bt_only = backtest_only(suite._ohlcv, n_local, n_total, max(20, args.steps), 3, suite.stride)
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------------
     # The step's device time is dominated by seq_jobs_kernel<0>: the tiled bodies of all sequential jobs, launched per LDS class, the
@@ -410,7 +475,7 @@ def main():
     # HBM traffic from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command; summary committed by
     # scripts/pmc_summary.py).  Only quoted for the build (source hash) and the configuration it was collected on.
     traffic = step_traffic = traffic_note = None
-    if PMC_FILE.exists() and n_local == N_SYM and T == T_DAYS and stride == (T_DAYS + 15) // 16 * 16:
+    if PMC_FILE.exists() and n_local == N_SYM and T == T_DAYS and suite.stride == (T_DAYS + 15) // 16 * 16:
         pm = json.loads(PMC_FILE.read_text())
         if pm.get("source_hash") == source_hash():
             kernels = pm["kernels"]
@@ -431,16 +496,20 @@ def main():
             "value": rows_total / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "collective": ({"per_step": "one all-gather of the [n_local, 8] summary rows",
-                            "timed": ("pq_gather_summaries (C ABI, csrc/comm.hip: RCCL ncclAllGather on the context's stream)" if comm is not None
-                                      else f"torch.distributed all_gather_into_tensor (the C-ABI communicator could not be built: {comm_note})"),
+            "collective": ({"per_step": "one all-gather of the [n_local, 8] summary rows, double-buffered: the exchange of step k runs on the "
+                                        "communicator's own stream beside the kernels of step k + 1 and completes inside the timed region",
+                            "timed": ("pq_gather_summaries_begin / _end (C ABI, csrc/comm.hip: RCCL ncclAllGather on the communicator's stream)" if comm is not None
+                                      else f"torch.distributed all_gather_into_tensor(async_op=True) (the C-ABI communicator could not be built: {comm_note})"),
+                            "step_ms": exchange_modes,
                             "torch_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
                             "c_abi_equals_torch_gather": gather_check}
                            if world > 1 else None),
+            "backtest_only": bt_only,
             "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
                                    f"recognisers) + fused MACD-cross backtest with summary, {n_total} symbols x {T} days "
                                    f"f64 OHLCV ({n_local} per GPU), inputs resident in HBM",
-                       "symbols_per_gpu": n_local, "symbols_total": n_total, "days": T, "row_pitch_elements": stride,
+                       "symbols_per_gpu": n_local, "symbols_total": n_total, "days": T, "row_pitch_elements": suite.stride,
+                       "input_pitch_elements": stride, "inputs_rehoused_at_record_time": sorted(suite._housed),
                        "parallelism": f"symbol-sharded x{world}",
                        "algorithmic_bytes_per_row": suite.suite_bytes_per_row(),
                        "suite_algorithmic_GBps": suite_gbs,
@@ -471,11 +540,11 @@ def main():
         if args.e2e and world == 1:
             line["config"]["e2e"] = end_to_end(suite, ohlcv, n_local, T, dev)
     # ---- secondary figures, outside the timed region above
-    if world == 1 and stride != T and not args.no_secondary and not args.no_cpu_baseline:
+    if world == 1 and suite.stride != T and not args.no_secondary and not args.no_cpu_baseline:
         # for the record: the same step on the DENSE layout (row pitch = days)
         suite.close()
         dense_in = {k: v.contiguous() for k, v in ohlcv.items()}
-        dense = Suite(n_local, T, dev, stride=T)
+        dense = Suite(n_local, T, dev, stride=T, exact_layout=True)
         dense.record(dense_in)
         el = time_steps(dense, dense_in, n_total, args.steps, args.warmup)
         line["config"]["dense_layout"] = {"row_pitch_elements": T, "ms_per_step": el / args.steps * 1e3}

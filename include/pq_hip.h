@@ -37,7 +37,8 @@ enum {
     PQ_ERR_HIP = 2,     /* a HIP runtime call failed */
     PQ_ERR_NULLS = 3,   /* input has nulls and the reference function rejects them (N-B family) */
     PQ_ERR_NOMEM = 4,
-    PQ_ERR_UNSUPPORTED = 5
+    PQ_ERR_UNSUPPORTED = 5,
+    PQ_WARN_SLOW_LAYOUT = 100 /* pq_layout_check only: not an error -- results are identical, the kernels take their 8-byte / per-lane forms */
 };
 
 typedef struct pq_ctx pq_ctx; /* device + stream + scratch workspace; one per host thread/stream */
@@ -57,6 +58,23 @@ typedef struct {
     int64_t stride;
     const int64_t *offsets; /* NULL: the regular [n_series][stride] layout */
 } pq_batch;
+
+/* ---- layout advice (no reference counterpart: Polars hands over dense Arrow buffers) ----
+ * Every kernel moves [64 series][8 or 16 rows] tiles with 16-byte accesses when the rows of a column are 16-byte aligned
+ * (stride even AND every column base a multiple of 16 B), and is fastest when the row pitch is a multiple of 128 B: every 64 / 128-byte
+ * piece of a tile is then one aligned cache line.  Measured on the full suite at 5 000 x 2 520: pitch 2 528
+ * 3.9 ms per step, dense even pitch 2 520 4.1 ms, ODD pitch 2 521 5.8 ms (the 8-byte forms: every piece straddles two cache lines).
+ *   pq_recommended_stride(len)  the smallest multiple of 16 elements (128 B) >= len: the pitch to allocate [n_series][stride] columns
+ *                               with (pq_memcpy_h2d_pitched places a dense host column there)
+ *   pq_layout_check(b, cols, n) PQ_OK if the n column bases and the batch's stride take the fast forms, PQ_WARN_SLOW_LAYOUT if the
+ *                               call will run the 8-byte forms (odd stride, or a base 8 bytes off) or the per-lane gather forms (a
+ *                               base not even 8-byte aligned); pq_last_error() then says which.  Ragged batches (offsets != NULL)
+ *                               always return PQ_OK: their groups start at arbitrary rows by construction.  Advisory only: every
+ *                               entry point accepts every layout and returns the same values.
+ * The library's own allocations follow the advice: the Polars plugin's device copies of a balanced `_over` panel, loader.DeviceFrame
+ * and polars_quant_amd.Suite (which also re-houses inputs handed over at a slow pitch once, at record time). */
+int64_t pq_recommended_stride(int64_t len);
+pq_status pq_layout_check(const pq_batch *b, const void *const *cols, int32_t n_cols);
 
 /* ---- runtime ---- */
 int32_t pq_abi_version(void);
@@ -315,6 +333,18 @@ pq_status pq_comm_init(pq_ctx *, int32_t rank, int32_t world, const void *id128)
 pq_status pq_comm_destroy(pq_ctx *);
 pq_status pq_shard_range(int64_t n_symbols, int32_t rank, int32_t world, int64_t *lo, int64_t *hi);
 pq_status pq_gather_summaries(pq_ctx *, const double *local, int64_t n_symbols, double *all);
+/* The same exchange OFF the step's critical path (round 5): at 8 GPUs a 625-symbol backtest step is ~50 us and an all-gather tens of
+ * us, so a gather in series behind every step would cost a third of the throughput.
+ *   pq_gather_summaries_begin  marks everything enqueued on the context's stream so far (the step that produced `local`) with an
+ *                              event; the communicator's OWN stream (created by pq_comm_init, highest priority) waits for it and takes
+ *                              the collective.  Returns at once: the context's stream is free for the next step.  slot = 0 / 1.
+ *   pq_gather_summaries_end    the context's stream waits -- on the device, the host does not block -- for that slot's collective:
+ *                              work enqueued afterwards may read `all` and overwrite `local`.  A no-op on an idle slot.
+ * Double-buffer `local` / `all` by slot and call _end(slot) just before the step that rewrites local[slot]: one exchange is then in
+ * flight beside the next step's kernels (polars_quant_amd/distributed.py: OverlappedGather; bench.py --gpus N times it).  No
+ * reference counterpart (single process). */
+pq_status pq_gather_summaries_begin(pq_ctx *, const double *local, int64_t n_symbols, double *all, int32_t slot);
+pq_status pq_gather_summaries_end(pq_ctx *, int32_t slot);
 
 /* ---- the README's `Strategy` signal rules (README.md:862-994; README-only, decision D-11 in
  * oracle/backtest.c): indicator columns -> uint8 buy / sell columns for the backtests above.  Row-parallel.

@@ -99,6 +99,10 @@ def lib() -> C.CDLL:
         L.pq_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.pq_gather_summaries.restype = C.c_int32
         L.pq_gather_summaries.argtypes = [vp, vp, C.c_int64, vp]
+        L.pq_gather_summaries_begin.restype = C.c_int32
+        L.pq_gather_summaries_begin.argtypes = [vp, vp, C.c_int64, vp, C.c_int32]
+        L.pq_gather_summaries_end.restype = C.c_int32
+        L.pq_gather_summaries_end.argtypes = [vp, C.c_int32]
         L.pq_backtest_wave_stats.restype = C.c_int32
         L.pq_backtest_wave_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
         L.pq_wt_stats.restype = C.c_int32
@@ -133,6 +137,10 @@ def lib() -> C.CDLL:
         L.pq_backtest_leveraged.argtypes = [vp, C.POINTER(Batch), vp, vp, vp, vp, C.POINTER(LevParams), vp, vp, vp, C.c_int32] + [vp] * 10
         L.pq_portfolio_metrics.restype = C.c_int32
         L.pq_portfolio_metrics.argtypes = [vp, C.POINTER(Batch), vp, C.c_double, vp, vp]
+        L.pq_recommended_stride.restype = C.c_int64
+        L.pq_recommended_stride.argtypes = [C.c_int64]
+        L.pq_layout_check.restype = C.c_int32
+        L.pq_layout_check.argtypes = [C.POINTER(Batch), C.POINTER(vp), C.c_int32]
         L.pq_ctx_create.argtypes = [C.c_int32, vp, C.POINTER(vp)]
         L.pq_ctx_destroy.argtypes = [vp]
         L.pq_ctx_set_stream.argtypes = [vp, vp]

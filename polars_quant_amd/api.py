@@ -83,10 +83,47 @@ def _to_device(x, dtype=torch.float64):
         raise PqError("inputs must be [T] or [N, T]")
     if not t.is_cuda:
         _require_gpu()
-        t = t.cuda()
+        n, T = t.shape
+        pitch = recommended_stride(T)
+        if n > 1 and pitch != T and dtype == torch.float64:
+            # a host column is uploaded into a device copy this library owns: place it at the 128-byte row pitch straight away
+            # (pq_recommended_stride; one strided H2D copy instead of a dense one -- a dense ODD-T copy would run the 8-byte forms)
+            buf = torch.empty((n, pitch), dtype=dtype, device="cuda")
+            buf[:, :T].copy_(t)
+            t = buf[:, :T]
+        else:
+            t = t.cuda()
+    elif t.dim() == 2 and t.shape[0] > 1 and t.dtype == torch.float64 and t.stride(1) == 1 and (t.stride(0) % 2 or t.data_ptr() % 16):
+        _warn_slow_layout(t)
     if t.stride(1) != 1 and t.shape[1] > 1:
         t = t.contiguous()
     return t, kind, squeeze
+
+
+def recommended_stride(T: int) -> int:
+    """pq_recommended_stride: the row pitch (elements) to allocate [N, T] device columns with -- the smallest multiple of 128 B >= T"""
+    return (int(T) + 15) // 16 * 16
+
+
+class PqLayoutWarning(UserWarning):
+    """A device tensor handed to the library sits on a layout whose rows are only 8-byte aligned (odd row pitch, or a base 8 bytes off a
+    16-byte boundary): every kernel then runs its 8-byte form, about 1.5 x slower (pq_layout_check returns PQ_WARN_SLOW_LAYOUT).  Results
+    are identical.  Allocate [N, recommended_stride(T)] and pass the [:, :T] view, or hand over host data (uploaded pitched), or use
+    Suite / loader.DeviceFrame, which re-house such inputs once."""
+
+
+_warned_layout = False
+
+
+def _warn_slow_layout(t: torch.Tensor) -> None:
+    global _warned_layout
+    if _warned_layout:
+        return
+    _warned_layout = True
+    import warnings
+    warnings.warn(f"polars_quant_amd: device tensor of shape {tuple(t.shape)} has a row pitch of {t.stride(0)} elements / a base that is not "
+                  f"16-byte aligned: the 8-byte kernel forms run (~1.5x slower, same results); use a row pitch of "
+                  f"{recommended_stride(t.shape[1])} (api.recommended_stride) -- warned once per process", PqLayoutWarning, stacklevel=4)
 
 
 def _from_device(t: torch.Tensor, kind: int, squeeze: bool, name: str = ""):
@@ -94,7 +131,7 @@ def _from_device(t: torch.Tensor, kind: int, squeeze: bool, name: str = ""):
         t = t[0]
     if kind == _Kind.TORCH:
         return t
-    a = t.cpu().numpy()
+    a = np.ascontiguousarray(t.cpu().numpy())   # (a pitched device column comes back dense)
     if kind == _Kind.NUMPY:
         return a
     import pyarrow as pa

@@ -79,6 +79,16 @@ pq_status pq_comm_init(pq_ctx *ctx, int32_t rank, int32_t world, const void *id1
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
+    // the side stream of the overlapped exchange: highest priority, so that its (tiny) kernels take the first free wave slots of a chip
+    // that the next step's grids are filling
+    int prio_lo = 0, prio_hi = 0;
+    PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    PQ_HIP_TRY(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, prio_hi));
+    for (int k = 0; k < 2; k++) {
+        PQ_HIP_TRY(hipEventCreateWithFlags(&ctx->comm_ev_in[k], hipEventDisableTiming));
+        PQ_HIP_TRY(hipEventCreateWithFlags(&ctx->comm_ev_done[k], hipEventDisableTiming));
+        ctx->comm_pending[k] = false;
+    }
     return PQ_OK;
 }
 
@@ -86,9 +96,16 @@ pq_status pq_comm_destroy(pq_ctx *ctx) {
     PQ_REQUIRE(ctx, "pq_comm_destroy: null pointer");
     if (!ctx->comm) return PQ_OK;
     PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) PQ_HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
     PQ_NCCL_TRY(g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(ctx->comm)));
     ctx->comm = nullptr;
     ctx->comm_world = 0;
+    for (int k = 0; k < 2; k++) {
+        if (ctx->comm_ev_in[k]) { (void)hipEventDestroy(ctx->comm_ev_in[k]); ctx->comm_ev_in[k] = nullptr; }
+        if (ctx->comm_ev_done[k]) { (void)hipEventDestroy(ctx->comm_ev_done[k]); ctx->comm_ev_done[k] = nullptr; }
+        ctx->comm_pending[k] = false;
+    }
+    if (ctx->comm_stream) { (void)hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
     return PQ_OK;
 }
 
@@ -99,11 +116,44 @@ pq_status pq_shard_range(int64_t n_symbols, int32_t rank, int32_t world, int64_t
     return PQ_OK;
 }
 
+static pq_status gather_on(pq_ctx *ctx, const double *local, int64_t n_symbols, double *all, hipStream_t stream);
 pq_status pq_gather_summaries(pq_ctx *ctx, const double *local, int64_t n_symbols, double *all) {
     PQ_REQUIRE(ctx && all, "pq_gather_summaries: null pointer");
     PQ_REQUIRE(n_symbols >= 0, "pq_gather_summaries: n_symbols < 0");
     PQ_REQUIRE(ctx->comm, "pq_gather_summaries: call pq_comm_init first");
     PQ_REQUIRE(!ctx->rec, "pq_gather_summaries cannot be recorded into a suite (call it after pq_suite_run)");
+    return gather_on(ctx, local, n_symbols, all, ctx->stream);
+}
+// The same exchange OFF the step's critical path.  _begin: everything enqueued on the context's stream so far (the step that produced
+// `local`) is marked with an event, the communicator's own stream waits for it and takes the collective; the call returns at once and
+// the context's stream goes on with the next step.  _end: the context's stream waits (on the device: the host does not block) for that
+// slot's collective, after which `all` may be read and `local` rewritten by work enqueued on the context's stream.  Two slots: a caller
+// that double-buffers `local` / `all` keeps one exchange in flight while the next step computes.
+pq_status pq_gather_summaries_begin(pq_ctx *ctx, const double *local, int64_t n_symbols, double *all, int32_t slot) {
+    PQ_REQUIRE(ctx && all, "pq_gather_summaries_begin: null pointer");
+    PQ_REQUIRE(n_symbols >= 0, "pq_gather_summaries_begin: n_symbols < 0");
+    PQ_REQUIRE(slot == 0 || slot == 1, "pq_gather_summaries_begin: slot must be 0 or 1");
+    PQ_REQUIRE(ctx->comm && ctx->comm_stream, "pq_gather_summaries_begin: call pq_comm_init first");
+    PQ_REQUIRE(!ctx->rec, "pq_gather_summaries_begin cannot be recorded into a suite (call it after pq_suite_run)");
+    PQ_REQUIRE(!ctx->comm_pending[slot], "pq_gather_summaries_begin: this slot has an exchange in flight (call pq_gather_summaries_end first)");
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    PQ_HIP_TRY(hipEventRecord(ctx->comm_ev_in[slot], ctx->stream));
+    PQ_HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev_in[slot], 0));
+    PQ_TRY(gather_on(ctx, local, n_symbols, all, ctx->comm_stream));
+    PQ_HIP_TRY(hipEventRecord(ctx->comm_ev_done[slot], ctx->comm_stream));
+    ctx->comm_pending[slot] = true;
+    return PQ_OK;
+}
+pq_status pq_gather_summaries_end(pq_ctx *ctx, int32_t slot) {
+    PQ_REQUIRE(ctx, "pq_gather_summaries_end: null pointer");
+    PQ_REQUIRE(slot == 0 || slot == 1, "pq_gather_summaries_end: slot must be 0 or 1");
+    if (!ctx->comm_pending[slot]) return PQ_OK;
+    PQ_HIP_TRY(hipSetDevice(ctx->device));
+    PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->comm_ev_done[slot], 0));
+    ctx->comm_pending[slot] = false;
+    return PQ_OK;
+}
+static pq_status gather_on(pq_ctx *ctx, const double *local, int64_t n_symbols, double *all, hipStream_t stream) {
     PQ_HIP_TRY(hipSetDevice(ctx->device));
     const int G = ctx->comm_world;
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(ctx->comm);
@@ -112,11 +162,11 @@ pq_status pq_gather_summaries(pq_ctx *ctx, const double *local, int64_t n_symbol
     PQ_REQUIRE(local || hi == lo, "pq_gather_summaries: null pointer");
     if (n_symbols % G == 0) { // equal shards: one all-gather
         if (n_symbols > 0)
-            PQ_NCCL_TRY(g_rccl.AllGather(local, all, (size_t)(hi - lo) * PQ_SUMMARY_COLS, ncclFloat64, comm, ctx->stream));
+            PQ_NCCL_TRY(g_rccl.AllGather(local, all, (size_t)(hi - lo) * PQ_SUMMARY_COLS, ncclFloat64, comm, stream));
         return PQ_OK;
     }
     // ragged shards: every rank's rows are broadcast into their place, as one group (one launch per peer, all links busy at once)
-    if (hi > lo) PQ_HIP_TRY(hipMemcpyAsync(all + lo * PQ_SUMMARY_COLS, local, (size_t)(hi - lo) * PQ_SUMMARY_COLS * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (hi > lo) PQ_HIP_TRY(hipMemcpyAsync(all + lo * PQ_SUMMARY_COLS, local, (size_t)(hi - lo) * PQ_SUMMARY_COLS * sizeof(double), hipMemcpyDeviceToDevice, stream));
     PQ_NCCL_TRY(g_rccl.GroupStart());
     ncclResult_t bad = ncclSuccess;   // a failing call inside the group must still be followed by GroupEnd (else the communicator stays mid-group)
     for (int r = 0; r < G && bad == ncclSuccess; r++) {
@@ -124,7 +174,7 @@ pq_status pq_gather_summaries(pq_ctx *ctx, const double *local, int64_t n_symbol
         (void)pq_shard_range(n_symbols, r, G, &a, &b);   // (arguments validated above)
         if (b == a) continue;
         double *dst = all + a * PQ_SUMMARY_COLS;
-        bad = g_rccl.Broadcast(dst, dst, (size_t)(b - a) * PQ_SUMMARY_COLS, ncclFloat64, r, comm, ctx->stream);
+        bad = g_rccl.Broadcast(dst, dst, (size_t)(b - a) * PQ_SUMMARY_COLS, ncclFloat64, r, comm, stream);
     }
     const ncclResult_t end = g_rccl.GroupEnd();
     PQ_NCCL_TRY(bad);

@@ -238,10 +238,25 @@ static bool key_refs(const pq_series_export &key, int64_t n, std::vector<KeyRef>
     }
     return (int64_t)out.size() == n;
 }
-// offsets of the contiguous groups of `key` (host), as a ragged batch on the device; *d_off is pq_free'd by the caller
-static pq_status over_batch(pq_ctx *ctx, const pq_series_export &key, int64_t n, pq_batch *b, void **d_off) {
+// How the columns of one call sit on the device.  A plain call: one series of n rows.  An `_over` call: the group offsets come from the
+// key column (host); groups of one common length (a balanced panel) become a REGULAR batch -- the tiled bodies instead of the ragged
+// forms -- and, since the device columns are this library's own copies, they are placed at the 128-byte row pitch
+// (pq_recommended_stride): a panel of ODD length would otherwise run the 8-byte forms of every kernel (1.5x slower).
+// Anything else is a ragged batch over the flat long columns.
+struct Layout {
+    pq_batch b{1, 0, 0, nullptr};
+    int64_t n = 0;         // rows of the long columns
+    int64_t groups = 1, glen = 0, pitch = 0;
+    bool pitched = false;  // device columns are [groups][pitch], host columns stay flat [n]
+    void *d_off = nullptr;
+    size_t dev_elems() const { return pitched ? (size_t)groups * (size_t)pitch : (size_t)n; }
+};
+static pq_status plan_layout(pq_ctx *ctx, const pq_series_export *key, int64_t n, Layout *L) {
+    L->n = n; L->groups = 1; L->glen = n; L->pitch = n; L->pitched = false; L->d_off = nullptr;
+    L->b = pq_batch{1, n, n, nullptr};
+    if (!key) return PQ_OK;
     std::vector<KeyRef> k;
-    if (!key_refs(key, n, k)) { pq_set_error("plugin: the key column of an _over call must be an integer, float, string or dictionary column of the frame's length"); return PQ_ERR_ARG; }
+    if (!key_refs(*key, n, k)) { pq_set_error("plugin: the key column of an _over call must be an integer, float, string or dictionary column of the frame's length"); return PQ_ERR_ARG; }
     std::vector<int64_t> off;
     off.push_back(0);
     int64_t longest = 0;
@@ -250,20 +265,44 @@ static pq_status over_batch(pq_ctx *ctx, const pq_series_export &key, int64_t n,
                           (k[(size_t)i].null || (k[(size_t)i].len == k[(size_t)i - 1].len && !memcmp(k[(size_t)i].p, k[(size_t)i - 1].p, (size_t)k[(size_t)i].len)));
         if (!same) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
     }
-    // groups of one common length (a balanced panel) are a REGULAR batch with stride = len: the tiled bodies instead of the ragged
-    // forms (the per-lane gather body, or a wavefront per group for the functions that have that form)
     bool uniform = off.size() >= 2;
     for (size_t i = 1; uniform && i < off.size(); i++) uniform = off[i] - off[i - 1] == longest;
     if (uniform) {
-        *d_off = nullptr;
-        *b = pq_batch{(int64_t)off.size() - 1, longest, longest, nullptr};
+        L->groups = (int64_t)off.size() - 1; L->glen = longest; L->pitch = pq_recommended_stride(longest); L->pitched = L->pitch != longest;
+        L->b = pq_batch{L->groups, longest, L->pitch, nullptr};
         return PQ_OK;
     }
-    PQ_TRY(pq_malloc(ctx, off.size() * 8, d_off));
-    PQ_TRY(pq_memcpy_h2d(ctx, *d_off, off.data(), off.size() * 8));
+    PQ_TRY(pq_malloc(ctx, off.size() * 8, &L->d_off));
+    PQ_TRY(pq_memcpy_h2d(ctx, L->d_off, off.data(), off.size() * 8));
     PQ_TRY(pq_ctx_sync(ctx)); // `off` is a pageable local
-    *b = pq_batch{(int64_t)off.size() - 1, longest, n, (const int64_t *)*d_off};
+    L->groups = (int64_t)off.size() - 1; L->glen = longest;
+    L->b = pq_batch{L->groups, longest, n, (const int64_t *)L->d_off};
     return PQ_OK;
+}
+// a flat host column [n] of `elem`-byte values -> a fresh device column in the call's layout (and back)
+static pq_status upload_col(pq_ctx *ctx, const Layout &L, const void *host, size_t elem, void **d) {
+    PQ_TRY(pq_malloc(ctx, L.dev_elems() * elem, d));
+    if (L.pitched) return pq_memcpy_h2d_pitched(ctx, *d, (size_t)L.pitch * elem, host, (size_t)L.glen * elem, (size_t)L.glen * elem, (size_t)L.groups);
+    return pq_memcpy_h2d(ctx, *d, host, (size_t)L.n * elem);
+}
+static pq_status download_col(pq_ctx *ctx, const Layout &L, const void *d, size_t elem, void *host) {
+    if (L.pitched) return pq_memcpy_d2h_pitched(ctx, host, (size_t)L.glen * elem, d, (size_t)L.pitch * elem, (size_t)L.glen * elem, (size_t)L.groups);
+    return pq_memcpy_d2h(ctx, host, d, (size_t)L.n * elem);
+}
+// Arrow validity <-> the NULL bit pattern, on the host copies (the plugin owns them; the device entry points pq_nulls_from_arrow /
+// pq_validity_to_arrow do the same for callers whose columns already live on the device)
+static void nulls_into_host(std::vector<double> &host, const std::vector<uint8_t> &validity, int64_t n) {
+    const uint64_t nb = PQ_NULL_BITS;
+    for (int64_t i = 0; i < n; i++)
+        if (!((validity[(size_t)(i >> 3)] >> (i & 7)) & 1)) memcpy(&host[(size_t)i], &nb, 8);
+}
+static int64_t validity_from_host(const std::vector<double> &values, int64_t n, std::vector<uint8_t> &validity) {
+    int64_t nulls = 0;
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t bits; memcpy(&bits, &values[(size_t)i], 8);
+        if (bits == PQ_NULL_BITS) { validity[(size_t)(i >> 3)] &= (uint8_t)~(1u << (i & 7)); nulls++; }
+    }
+    return nulls;
 }
 
 static const char *const k_not_numeric = "plugin: the input column is not numeric (int8 .. uint64, float16 / 32 / 64 and Boolean are cast to Float64 like the reference's inputs[k].cast(&DataType::Float64))";
@@ -298,37 +337,29 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     if (n > 0) {
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
-        void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr, *d_bits = nullptr, *d_cnt = nullptr;
-        const size_t nb = (size_t)((n + 7) / 8);
-        pq_status st = pq_malloc(ctx, (size_t)n * 8, &d_out);
-        if (st == PQ_OK) st = pq_malloc(ctx, nb, &d_bits);
-        if (st == PQ_OK) st = pq_malloc(ctx, 8, &d_cnt);
+        void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
+        Layout lay;
+        pq_status st = plan_layout(ctx, over ? &inputs[f.nin] : nullptr, n, &lay);
+        if (st == PQ_OK) st = pq_malloc(ctx, lay.dev_elems() * 8, &d_out);
         for (int k = 0; k < f.nin && st == PQ_OK; k++) {
-            st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
-            if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
-            if (st == PQ_OK && nulls[k]) {
-                st = pq_memcpy_h2d(ctx, d_bits, valid[k].data(), nb);
-                if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in[k], (const uint8_t *)d_bits, 0, n);
-            }
+            if (nulls[k]) nulls_into_host(host[k], valid[k], n);
+            st = upload_col(ctx, lay, host[k].data(), 8, &d_in[k]);
         }
-        pq_batch b{1, n, n, nullptr};
-        void *d_off = nullptr;
-        if (st == PQ_OK && over) st = over_batch(ctx, inputs[f.nin], n, &b, &d_off);
         const double *cols[4] = {(const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3]};
-        if (st == PQ_OK) st = f.call(ctx, &b, cols, pv, d_out);
+        if (st == PQ_OK) st = f.call(ctx, &lay.b, cols, pv, d_out);
         if (f.out_i32) { // Int32 results of this library are never null on non-null input rows beyond the warm-up: PQ_NULL_I32 marks the rest
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->ivalues.data(), d_out, (size_t)n * 4);
+            if (st == PQ_OK) st = download_col(ctx, lay, d_out, 4, op->ivalues.data());
+            if (st == PQ_OK) st = pq_ctx_sync(ctx);
             if (st == PQ_OK)
                 for (int64_t i = 0; i < n; i++)
                     if (op->ivalues[(size_t)i] == PQ_NULL_I32) { op->validity[(size_t)(i >> 3)] &= (uint8_t)~(1u << (i & 7)); null_count++; }
         } else {
-            if (st == PQ_OK) st = pq_validity_to_arrow(ctx, (const double *)d_out, n, (uint8_t *)d_bits, (int64_t *)d_cnt);
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->values.data(), d_out, (size_t)n * 8);
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->validity.data(), d_bits, nb);
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count, d_cnt, 8);
+            if (st == PQ_OK) st = download_col(ctx, lay, d_out, 8, op->values.data());
+            if (st == PQ_OK) st = pq_ctx_sync(ctx);
+            if (st == PQ_OK) null_count = validity_from_host(op->values, n, op->validity);
         }
         if (st == PQ_OK) st = pq_ctx_sync(ctx);
-        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_bits, d_cnt, d_off}) if (q) (void)pq_free(ctx, q);
+        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, lay.d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail(f.name); return; }
     }
     ArrowArray *arr = new ArrowArray();
@@ -432,33 +463,21 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
     if (n > 0) {
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { drop(); plugin_fail("plugin: no HIP device / context"); return; }
-        void *d_in[2] = {nullptr, nullptr}, *d_out[3] = {nullptr, nullptr, nullptr}, *d_bits = nullptr, *d_cnt = nullptr;
-        const size_t nb = (size_t)((n + 7) / 8);
-        pq_status st = pq_malloc(ctx, nb, &d_bits);
-        if (st == PQ_OK) st = pq_malloc(ctx, 8, &d_cnt);
-        for (int k = 0; k < f.nout && st == PQ_OK; k++) st = pq_malloc(ctx, (size_t)n * 8, &d_out[k]);
+        void *d_in[2] = {nullptr, nullptr}, *d_out[3] = {nullptr, nullptr, nullptr};
+        Layout lay;
+        pq_status st = plan_layout(ctx, over ? &inputs[f.nin] : nullptr, n, &lay);
+        for (int k = 0; k < f.nout && st == PQ_OK; k++) st = pq_malloc(ctx, lay.dev_elems() * 8, &d_out[k]);
         for (int k = 0; k < f.nin && st == PQ_OK; k++) {
-            st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
-            if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
-            if (st == PQ_OK && nulls[k]) {
-                st = pq_memcpy_h2d(ctx, d_bits, valid[k].data(), nb);
-                if (st == PQ_OK) st = pq_nulls_from_arrow(ctx, (double *)d_in[k], (const uint8_t *)d_bits, 0, n);
-            }
+            if (nulls[k]) nulls_into_host(host[k], valid[k], n);
+            st = upload_col(ctx, lay, host[k].data(), 8, &d_in[k]);
         }
-        pq_batch b{1, n, n, nullptr};
-        void *d_off = nullptr;
-        if (st == PQ_OK && over) st = over_batch(ctx, inputs[f.nin], n, &b, &d_off);
         const double *cols[2] = {(const double *)d_in[0], (const double *)d_in[1]};
         double *outs[3] = {(double *)d_out[0], (double *)d_out[1], (double *)d_out[2]};
-        if (st == PQ_OK) st = f.call(ctx, &b, cols, pv, outs);
-        for (int k = 0; k < f.nout && st == PQ_OK; k++) {
-            st = pq_validity_to_arrow(ctx, (const double *)d_out[k], n, (uint8_t *)d_bits, (int64_t *)d_cnt);
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op[k]->values.data(), d_out[k], (size_t)n * 8);
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op[k]->validity.data(), d_bits, nb);
-            if (st == PQ_OK) st = pq_memcpy_d2h(ctx, &null_count[k], d_cnt, 8);
-        }
+        if (st == PQ_OK) st = f.call(ctx, &lay.b, cols, pv, outs);
+        for (int k = 0; k < f.nout && st == PQ_OK; k++) st = download_col(ctx, lay, d_out[k], 8, op[k]->values.data());
         if (st == PQ_OK) st = pq_ctx_sync(ctx);
-        for (void *q : {d_in[0], d_in[1], d_out[0], d_out[1], d_out[2], d_bits, d_cnt, d_off}) if (q) (void)pq_free(ctx, q);
+        for (int k = 0; k < f.nout && st == PQ_OK; k++) null_count[k] = validity_from_host(op[k]->values, n, op[k]->validity);
+        for (void *q : {d_in[0], d_in[1], d_out[0], d_out[1], d_out[2], lay.d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { drop(); plugin_fail(f.name); return; }
     }
     StructPriv *sp = new StructPriv();
@@ -515,18 +534,14 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
         void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
-        pq_status st = pq_malloc(ctx, (size_t)n * 4, &d_out);
-        for (int k = 0; k < 4 && st == PQ_OK; k++) {
-            st = pq_malloc(ctx, (size_t)n * 8, &d_in[k]);
-            if (st == PQ_OK) st = pq_memcpy_h2d(ctx, d_in[k], host[k].data(), (size_t)n * 8);
-        }
-        pq_batch b{1, n, n, nullptr};
-        void *d_off = nullptr;
-        if (st == PQ_OK && over) st = over_batch(ctx, inputs[4], n, &b, &d_off);
-        if (st == PQ_OK) st = pq_cdl(ctx, &b, id, (const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3], pen, (int32_t *)d_out);
-        if (st == PQ_OK) st = pq_memcpy_d2h(ctx, op->ivalues.data(), d_out, (size_t)n * 4);
+        Layout lay;
+        pq_status st = plan_layout(ctx, over ? &inputs[4] : nullptr, n, &lay);
+        if (st == PQ_OK) st = pq_malloc(ctx, lay.dev_elems() * 4, &d_out);
+        for (int k = 0; k < 4 && st == PQ_OK; k++) st = upload_col(ctx, lay, host[k].data(), 8, &d_in[k]);
+        if (st == PQ_OK) st = pq_cdl(ctx, &lay.b, id, (const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3], pen, (int32_t *)d_out);
+        if (st == PQ_OK) st = download_col(ctx, lay, d_out, 4, op->ivalues.data());
         if (st == PQ_OK) st = pq_ctx_sync(ctx);
-        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, d_off}) if (q) (void)pq_free(ctx, q);
+        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, lay.d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail("pq_cdl"); return; }
     }
     ArrowArray *arr = new ArrowArray();

@@ -31,6 +31,11 @@ struct pq_ctx {
     Recorder *rec;   // non-null while a suite is being recorded
     void *comm;      // ncclComm_t of pq_comm_init (comm.hip), or null
     int comm_rank, comm_world;
+    // the communicator's own stream + one event pair per slot: pq_gather_summaries_begin / _end run the exchange of step k beside the
+    // kernels of step k + 1 (comm.hip); created by pq_comm_init, destroyed by pq_comm_destroy
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ev_in[2] = {nullptr, nullptr}, comm_ev_done[2] = {nullptr, nullptr};
+    bool comm_pending[2] = {false, false};
     unsigned *wt_gate = nullptr; // [wt_gate_tiles] flags of the wave-per-symbol kernels' direct launches (ops_wt.h): tiles the gated general path redoes
     size_t wt_gate_tiles = 0;
 };

@@ -31,6 +31,28 @@ pq_status pq_check(pq_ctx *ctx, const pq_batch *b) {
     return PQ_OK;
 }
 
+extern "C" int64_t pq_recommended_stride(int64_t len) { return len <= 0 ? 0 : (len + 15) / 16 * 16; }
+extern "C" pq_status pq_layout_check(const pq_batch *b, const void *const *cols, int32_t n_cols) {
+    if (!b || (n_cols > 0 && !cols) || n_cols < 0) { pq_set_error("pq_layout_check: bad argument"); return PQ_ERR_ARG; }
+    if (b->offsets) return PQ_OK;
+    for (int32_t k = 0; k < n_cols; k++)
+        if (reinterpret_cast<uintptr_t>(cols[k]) % 8) {
+            pq_set_error("slow layout: column %d is not 8-byte aligned: the per-lane gather forms run", (int)k);
+            return PQ_WARN_SLOW_LAYOUT;
+        }
+    if (b->stride % 2) {
+        pq_set_error("slow layout: stride %lld is odd (rows only 8-byte aligned): the 8-byte forms of the tiled kernels run, ~1.5x slower; "
+                     "allocate columns at pq_recommended_stride(len) = %lld", (long long)b->stride, (long long)pq_recommended_stride(b->len));
+        return PQ_WARN_SLOW_LAYOUT;
+    }
+    for (int32_t k = 0; k < n_cols; k++)
+        if (reinterpret_cast<uintptr_t>(cols[k]) % 16) {
+            pq_set_error("slow layout: column %d starts 8 bytes off a 16-byte boundary: the 8-byte forms of the tiled kernels run", (int)k);
+            return PQ_WARN_SLOW_LAYOUT;
+        }
+    return PQ_OK;
+}
+
 pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return PQ_OK;
     // grow-only; earlier launches may still read the old block -> drain the stream before freeing it

@@ -137,6 +137,90 @@ class CabiComm:
             cur.wait_stream(self.stream)
         return out
 
+    def gather_begin(self, local: torch.Tensor, n_symbols: int, out: torch.Tensor, slot: int) -> None:
+        """pq_gather_summaries_begin: the exchange of `local` ([n_local, 8], contiguous, written by work already enqueued on the
+        context's stream) into `out` ([n_symbols, 8]) on the communicator's own stream; returns at once"""
+        C = self._C
+        lo, hi = shard_range(n_symbols, self.rank, self.world)
+        if local.shape[0] != hi - lo or not local.is_contiguous() or not out.is_contiguous() or out.shape[0] != n_symbols:
+            raise ValueError(f"rank {self.rank} of {self.world}: local must be the contiguous [{hi - lo}, 8] shard, out [{n_symbols}, 8]")
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:        # the context lives on another stream than the step: bridge (device-side waits only)
+            self.stream.wait_stream(cur)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.pq_gather_summaries_begin(self.h, C.c_void_p(local.data_ptr()), n_symbols, C.c_void_p(out.data_ptr()), slot))
+
+    def gather_end(self, slot: int) -> None:
+        """pq_gather_summaries_end: the context's stream -- and torch's current stream -- wait (on the device) for that slot's exchange"""
+        with torch.cuda.device(self.device):
+            self._check(self._lib.pq_gather_summaries_end(self.h, slot))
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
+
     def close(self):
         with torch.cuda.device(self.device):
             self._check(self._lib.pq_comm_destroy(self.h))
+
+
+class OverlappedGather:
+    """The per-step exchange taken off the step's critical path: two slots of (`local`, `all`) buffers; the exchange of step k runs
+    beside the kernels of step k + 1 and is waited for only when its slot comes round again (or at `drain`).
+
+        og = OverlappedGather(n_symbols, n_local, device, comm=CabiComm(...))     # GPU: pq_gather_summaries_begin / _end
+        og = OverlappedGather(n_symbols, n_local, "cpu", group=None)              # any torch.distributed backend (tests: gloo)
+        for k in range(steps):
+            slot = og.acquire()          # waits (device-side / handle) for the exchange that last used this slot
+            ... run the step that writes og.local[slot] ...
+            og.begin(slot)               # returns at once
+        og.drain()                       # all[0], all[1] hold the tables of the last two steps
+
+    `all[slot]` may be read after the next acquire() of that slot or after drain()."""
+
+    def __init__(self, n_symbols: int, n_local: int, device, comm: "CabiComm | None" = None, group=None, local=None):
+        self.n, self.comm, self.group = n_symbols, comm, group
+        dev = torch.device(device)
+        self.local = list(local) if local is not None else [torch.zeros((n_local, 8), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.all = [torch.zeros((n_symbols, 8), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._work = [None, None]      # torch.distributed work handles (the non-C-ABI backend)
+        self._next = 0
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = comm.rank if comm is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self._sizes = [shard_range(n_symbols, r, self.world)[1] - shard_range(n_symbols, r, self.world)[0] for r in range(self.world)]
+
+    def acquire(self) -> int:
+        slot = self._next
+        self._next ^= 1
+        self.wait(slot)
+        return slot
+
+    def wait(self, slot: int) -> None:
+        if self.comm is not None:
+            self.comm.gather_end(slot)
+        elif self._work[slot] is not None:
+            for w in self._work[slot]:
+                w.wait()
+            self._work[slot] = None
+
+    def begin(self, slot: int) -> None:
+        if self.comm is not None:
+            self.comm.gather_begin(self.local[slot], self.n, self.all[slot], slot)
+            return
+        if self.world == 1:
+            self.all[slot].copy_(self.local[slot])
+            return
+        if len(set(self._sizes)) == 1:
+            self._work[slot] = [dist.all_gather_into_tensor(self.all[slot], self.local[slot], group=self.group, async_op=True)]
+        else:   # ragged shards: every rank's rows are broadcast into their place
+            lo, hi = shard_range(self.n, self.rank, self.world)
+            self.all[slot][lo:hi].copy_(self.local[slot])
+            self._work[slot] = []
+            for r in range(self.world):
+                a, b = shard_range(self.n, r, self.world)
+                if b > a:
+                    self._work[slot].append(dist.broadcast(self.all[slot][a:b], src=dist.get_global_rank(self.group, r) if self.group else r,
+                                                           group=self.group, async_op=True))
+
+    def drain(self) -> None:
+        self.wait(0)
+        self.wait(1)

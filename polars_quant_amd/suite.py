@@ -27,12 +27,22 @@ def algorithmic_bytes_per_row() -> dict:
 
 
 class Suite:
-    def __init__(self, n_series: int, T: int, device="cuda", stride: int | None = None):
-        """stride (elements between consecutive series, >= T): rows whose byte pitch is a multiple of 128 B keep every
-        64/128-byte tile segment inside one cache line; default = T (dense)"""
+    def __init__(self, n_series: int, T: int, device="cuda", stride: int | None = None, exact_layout: bool = False):
+        """The suite OWNS its output columns and allocates them at a row pitch that is a multiple of 128 B (pq_recommended_stride:
+        every 64 / 128-byte tile piece is then one aligned cache line): `stride` if it is such a multiple, else the smallest one
+        >= T.  Inputs handed to record() at another pitch or at a base that is not 16-byte aligned -- a dense odd-T tensor would run
+        the 8-byte forms of every kernel, 1.5 x slower -- are re-housed ONCE at that pitch (record() / refresh_inputs()).
+        exact_layout=True keeps the caller's layout exactly (stride = `stride` or T, inputs used in place): what the tests of the
+        8-byte forms and bench.py --exact-layout measure."""
         self.n, self.T = n_series, T
-        self.stride = T if stride is None else int(stride)
+        self.exact_layout = bool(exact_layout)
+        rec = (T + 15) // 16 * 16
+        if self.exact_layout:
+            self.stride = T if stride is None else int(stride)
+        else:
+            self.stride = int(stride) if (stride and int(stride) % 16 == 0 and int(stride) >= T) else rec
         assert self.stride >= T
+        self._housed = {}
         self.dev = torch.device(device)
         self.batch = Batch(n_series, T, self.stride)
         f64 = lambda: torch.empty((n_series, self.stride), dtype=torch.float64, device=self.dev)[:, :T]
@@ -57,8 +67,17 @@ class Suite:
     def _col(self, ohlcv, c):
         return self.periods if c == "periods" else ohlcv[COLMAP.get(c, c)]
 
+    def _on_layout(self, ohlcv: dict) -> None:
+        """run_one() reads the columns with the suite's batch descriptor: refuse a column at another pitch instead of reading it wrongly
+        (record() / run_eager() re-house such columns themselves; direct callers of run_one() pass them through house() first)"""
+        for k, t in ohlcv.items():
+            if self.n > 1 and t.stride(0) != self.stride:
+                raise ValueError(f"input column `{k}` has a row pitch of {t.stride(0)} elements, the suite's is {self.stride}: "
+                                 f"pass the columns through Suite.house() (or build the suite with exact_layout=True)")
+
     def run_one(self, name: str, ohlcv: dict) -> None:
         L, h, b = lib(), ctx(self.dev.index), self.batch
+        self._on_layout(ohlcv)
         if name == "cdl_all":
             check(L.pq_cdl_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("open", "high", "low", "close")],
                                self._pens, self._pat_ptrs))
@@ -137,26 +156,66 @@ class Suite:
 
     def run_eager(self, ohlcv: dict) -> None:
         """one step as ~90 separate launches (one per C-ABI call), enqueued on the current stream"""
+        ohlcv = self._house(ohlcv)
         with torch.cuda.device(self.dev):
             for name in self.tasks():
                 self.run_one(name, ohlcv)
 
-    def record(self, ohlcv: dict, tasks=None) -> None:
-        """record the step once (pq_suite_begin/end): the sequential jobs of all functions become one grid per phase"""
+    def _house(self, ohlcv: dict) -> dict:
+        """the input columns on the suite's layout: a column already at the suite's pitch (and 16-byte aligned) is used in place,
+        any other is copied into a suite-owned pitched buffer -- once; refresh_inputs() repeats the copy after the caller changed it"""
+        if self.exact_layout:
+            return ohlcv
+        out = {}
+        for k, t in ohlcv.items():
+            ok = (t.dim() == 2 and tuple(t.shape) == (self.n, self.T) and t.dtype == torch.float64 and t.device == self.dev and
+                  (self.T <= 1 or t.stride(1) == 1) and (self.n <= 1 or t.stride(0) == self.stride) and t.data_ptr() % 16 == 0)
+            if ok:
+                out[k] = t
+                continue
+            buf = self._housed.get(k)
+            if buf is None:
+                buf = self._housed[k] = torch.zeros((self.n, self.stride), dtype=torch.float64, device=self.dev)
+            buf[:, :self.T].copy_(t)
+            out[k] = buf[:, :self.T]
+        return out
+
+    house = _house
+
+    def refresh_inputs(self, ohlcv: dict) -> None:
+        """after the caller changed input columns that record() had to re-house: copy them again (same buffers, no re-recording)"""
+        self._house(ohlcv)
+
+    def record(self, ohlcv: dict, tasks=None, summaries=None) -> None:
+        """record the step once (pq_suite_begin/end): the sequential jobs of all functions become one grid per phase.
+        summaries = [t0, t1] ([n, 8] f64 each): the step is recorded TWICE, the backtest of recording k writing its summary rows into
+        summaries[k] (every other output column is shared) -- run(slot=k) then replays recording k, so that a multi-GPU caller can
+        keep the exchange of one table in flight while the next step fills the other (distributed.OverlappedGather)."""
         self.close()
         L, h = lib(), ctx(self.dev.index)
+        ohlcv = self._house(ohlcv)
         self._ohlcv = ohlcv  # keep the inputs alive: the suite holds raw device pointers
-        with torch.cuda.device(self.dev):
-            check(L.pq_suite_begin(h, C.byref(self.batch)))
-            try:
-                for name in (tasks or self.tasks(fused=True)):
-                    self.run_one(name, ohlcv)
-            except Exception:
-                L.pq_suite_abort(h)
-                raise
-            out = C.c_void_p()
-            check(L.pq_suite_end(h, C.byref(out)))
-        self._suite = out
+        handles, keep = [], self.summary
+        try:
+            for summ in (summaries or [self.summary]):
+                assert summ.shape == (self.n, 8) and summ.dtype == torch.float64 and summ.is_contiguous()
+                self.summary = summ
+                with torch.cuda.device(self.dev):
+                    check(L.pq_suite_begin(h, C.byref(self.batch)))
+                    try:
+                        for name in (tasks or self.tasks(fused=True)):
+                            self.run_one(name, ohlcv)
+                    except Exception:
+                        L.pq_suite_abort(h)
+                        raise
+                    out = C.c_void_p()
+                    check(L.pq_suite_end(h, C.byref(out)))
+                handles.append(out)
+        finally:
+            self.summary = summaries[0] if summaries else keep
+        self._summaries = list(summaries) if summaries else [self.summary]
+        self._suites = handles
+        self._suite = handles[0]
 
     # ---- staged form: the step split by the input columns a task needs, so that a stage starts as soon as ITS columns have
     # arrived from the host (loader.DeviceFrame.upload records one event per column on the copy stream)
@@ -178,6 +237,7 @@ class Suite:
         """one recorded suite per prefix of STAGE_ORDER that completes some task's inputs -> [(columns needed, n tasks)]"""
         self.close()
         L, h = lib(), ctx(self.dev.index)
+        ohlcv = self._house(ohlcv)
         self._ohlcv = ohlcv
         stages, have, left = [], set(), list(self.tasks(fused=True))
         for col in self.STAGE_ORDER:
@@ -244,17 +304,19 @@ class Suite:
         check(lib().pq_suite_span_stats(self._suite, variant, C.byref(ms), C.byref(by)))
         return ms.value, by.value
 
-    def run(self, ohlcv: dict | None = None) -> None:
-        """one step: every indicator + all 61 patterns + the MACD-cross backtest, enqueued on the current stream"""
+    def run(self, ohlcv: dict | None = None, slot: int = 0) -> None:
+        """one step: every indicator + all 61 patterns + the MACD-cross backtest, enqueued on the current stream
+        (slot: which of the recordings of record(summaries=[...]) to replay)"""
         if getattr(self, "_suite", None) is None:
             self.record(ohlcv)
         with torch.cuda.device(self.dev):
-            check(lib().pq_suite_run(ctx(self.dev.index), self._suite))
+            check(lib().pq_suite_run(ctx(self.dev.index), self._suites[slot]))
 
     def close(self):
-        if getattr(self, "_suite", None) is not None:
-            check(lib().pq_suite_destroy(ctx(self.dev.index), self._suite))
-            self._suite = None
+        for hnd in getattr(self, "_suites", []) or []:
+            check(lib().pq_suite_destroy(ctx(self.dev.index), hnd))
+        self._suites = []
+        self._suite = None
         for _col, handle, _n in getattr(self, "_stages", []):
             check(lib().pq_suite_destroy(ctx(self.dev.index), handle))
         self._stages = []

@@ -55,7 +55,7 @@ from polars_quant_amd._lib import Batch, LevParams, check, lib
 from polars_quant_amd._spec import LEV_DEFAULTS
 from polars_quant_amd.suite import Suite
 g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
-st = Suite(N, T, "cuda")
+st = Suite(N, T, "cuda", exact_layout=True)   # dense columns shared with the direct leveraged call
 L, h = lib(), api.ctx(0)
 cash, sv, tv = (torch.empty((N, T), dtype=torch.float64, device="cuda") for _ in range(3))
 cnt = torch.zeros(N, dtype=torch.int32, device="cuda")
@@ -72,7 +72,7 @@ def timed(with_lev):
                                       *([None] * 8), vp(summ)))
     out = C.c_void_p()
     check(L.pq_suite_end(h, C.byref(out)))
-    st._suite = out
+    st._suite = out; st._suites = [out]; st._summaries = [st.summary]
     for _ in range(3): st.run()
     torch.cuda.synchronize()
     e0.record()

@@ -241,3 +241,137 @@ def test_c_abi_communicator_and_summary_gather_single_rank(L):
     comm = CabiComm("cuda:0", 0, 1)          # and it can be created again after the destroy
     assert torch.equal(comm.gather_summaries(s[:5], 5), s[:5])
     comm.close()
+
+
+def test_overlapped_gather_equals_the_serial_one_over_consecutive_steps(L, oracle):
+    """pq_gather_summaries_begin / _end (the exchange of step k on the communicator's own stream beside the kernels of step k + 1,
+    two slots): five consecutive steps with CHANGING inputs; every gathered table equals the table the serial pq_gather_summaries
+    returns for that step, and the oracle's summary rows."""
+    import polars_quant_amd as pq
+    from polars_quant_amd._lib import Batch, BtParams, check
+    from polars_quant_amd._spec import BT_DEFAULTS
+    from polars_quant_amd.api import ctx
+    from polars_quant_amd.distributed import CabiComm, OverlappedGather
+    n, T = 96, 640
+    data = [oracle.gen_ohlcv(0x5EED0F00 + k, n, T, 0)["close"] for k in range(5)]
+    dev = torch.device("cuda:0")
+    closes = [torch.from_numpy(c).to(dev) for c in data]
+    comm = CabiComm(dev, 0, 1)
+    h, b, prm = ctx(0), Batch(n, T, T), BtParams(**BT_DEFAULTS)
+    og = OverlappedGather(n, n, dev, comm=comm)
+    curves = [torch.empty((n, T), dtype=torch.float64, device=dev) for _ in range(3)]
+
+    def run(k, summ):
+        check(L.pq_backtest_macd_cross(h, C.byref(b), C.c_void_p(closes[k].data_ptr()), 12, 26, 9, C.byref(prm),
+                                       *[C.c_void_p(t.data_ptr()) for t in curves], C.c_void_p(summ.data_ptr())))
+    got = []
+    held = {}
+    for k in range(5):
+        slot = og.acquire()                       # waits for the exchange that used this slot two steps ago
+        if slot in held:
+            got.append((held[slot], og.all[slot].clone()))
+        run(k, og.local[slot])
+        og.begin(slot)
+        held[slot] = k
+        with pytest.raises(pq.PqError):           # a slot with an exchange in flight cannot be begun again
+            comm.gather_begin(og.local[slot], n, og.all[slot], slot)
+    og.drain()
+    for slot, k in held.items():
+        got.append((k, og.all[slot].clone()))
+    torch.cuda.synchronize()
+    assert sorted(k for k, _ in got) == [0, 1, 2, 3, 4]
+    for k, table in got:
+        serial_local = torch.empty((n, 8), dtype=torch.float64, device=dev)
+        run(k, serial_local)
+        serial = comm.gather_summaries(serial_local, n)
+        torch.cuda.synchronize()
+        assert torch.equal(table.view(torch.int64), serial.view(torch.int64)), k
+        buy, sell = oracle.macd_cross_signals(data[k])
+        _, _, _, exp = oracle.backtest(data[k], buy, sell)
+        np.testing.assert_allclose(table.cpu().numpy(), exp.reshape(n, 8), rtol=1e-12, atol=1e-13)
+    comm.close()
+
+
+def test_suite_recorded_twice_fills_either_summary_buffer(L, oracle):
+    """Suite.record(summaries=[a, b]): run(slot=k) writes the backtest's summary rows into buffer k and nothing else differs"""
+    from polars_quant_amd.suite import Suite
+    n, T = 70, 256
+    d = oracle.gen_ohlcv(0x5EED0F10, n, T, 0)
+    g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    st = Suite(n, T, "cuda")
+    a, b = torch.zeros((n, 8), dtype=torch.float64, device="cuda"), torch.zeros((n, 8), dtype=torch.float64, device="cuda")
+    st.record(g, summaries=[a, b])
+    st.run(g, slot=1)
+    torch.cuda.synchronize()
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) > 0.0
+    st.run(g, slot=0)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    buy, sell = oracle.macd_cross_signals(d["close"])
+    _, _, _, exp = oracle.backtest(d["close"], buy, sell)
+    np.testing.assert_allclose(a.cpu().numpy(), exp.reshape(n, 8), rtol=1e-12, atol=1e-13)
+    st.close()
+
+
+def test_layout_advice_and_no_silent_slow_layout(L, oracle):
+    """pq_recommended_stride / pq_layout_check (include/pq_hip.h), and the Python layer's side of it: a Suite re-houses inputs handed
+    over at an odd pitch once (then runs the aligned job kernel, not the 8-byte form), host inputs are uploaded pitched, and a device
+    tensor at a slow pitch draws a PqLayoutWarning instead of silence."""
+    import warnings
+    from polars_quant_amd import api
+    from polars_quant_amd._lib import Batch
+    from polars_quant_amd.suite import Suite
+    assert [L.pq_recommended_stride(n) for n in (0, 1, 16, 17, 2520, 2521, 2528)] == [0, 16, 16, 32, 2528, 2528, 2528]
+    buf = torch.zeros(4 * 2528 + 2, dtype=torch.float64, device="cuda")
+    vp = C.c_void_p
+    cols = lambda *ptrs: (vp * len(ptrs))(*ptrs)
+    assert L.pq_layout_check(C.byref(Batch(4, 2520, 2528)), cols(buf.data_ptr()), 1) == 0
+    assert L.pq_layout_check(C.byref(Batch(4, 2520, 2520)), cols(buf.data_ptr()), 1) == 0             # dense even pitch: the 16-byte forms
+    assert L.pq_layout_check(C.byref(Batch(4, 2521, 2521)), cols(buf.data_ptr()), 1) == 100           # PQ_WARN_SLOW_LAYOUT
+    assert b"2528" in L.pq_last_error()
+    assert L.pq_layout_check(C.byref(Batch(4, 2520, 2528)), cols(buf.data_ptr(), buf.data_ptr() + 8), 2) == 100
+    assert L.pq_layout_check(C.byref(Batch(4, 2520, 2528)), cols(buf.data_ptr() + 4), 1) == 100
+    assert L.pq_layout_check(None, None, 0) == 1
+    # Suite: inputs on a dense ODD pitch -> re-housed once -> the aligned job kernel; results = the oracle's
+    n, T = 70, 301
+    d = oracle.gen_ohlcv(0x5EED0F20, n, T, 0)
+    g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    st = Suite(n, T, "cuda")
+    assert st.stride == 304
+    st.record(g, ["sma", "ema_all", "dm_system_all", "cdl_all", "backtest_macd_cross"])
+    assert sorted(st._housed) == ["close", "high", "low", "open", "volume"]
+    kernels = {gs["kernel"] for gs in st.grid_stats()}
+    assert "seq_jobs_kernel<3>" not in kernels and "seq_jobs_kernel<2>" not in kernels and "seq_jobs_kernel<0>" in kernels, kernels
+    st.run(); torch.cuda.synchronize()
+    (exp,) = oracle.call("sma", d["close"], timeperiod=30)
+    assert (bits(st.out["sma"][0].cpu().numpy()) == bits(exp)).all()
+    (exp,) = oracle.call("adx", d["high"], d["low"], d["close"], timeperiod=14)
+    assert (bits(st.out["adx"][0].cpu().numpy()) == bits(exp)).all()
+    g["close"].mul_(2.0)                                        # the caller changes a re-housed column ...
+    st.refresh_inputs(g)                                        # ... and says so
+    st.run(); torch.cuda.synchronize()
+    (exp,) = oracle.call("sma", d["close"] * 2.0, timeperiod=30)
+    assert (bits(st.out["sma"][0].cpu().numpy()) == bits(exp)).all()
+    pitched = st.house(g)
+    assert all(t.stride(0) == 304 for t in pitched.values())
+    with pytest.raises(ValueError):
+        st.run_one("sma", g)                                    # a column at another pitch is refused, not misread
+    st.close()
+    # exact_layout=True keeps the caller's odd pitch (the 8-byte form), as bench.py --exact-layout does
+    st = Suite(n, T, "cuda", exact_layout=True)
+    st.record({k: torch.from_numpy(v).cuda() for k, v in d.items()}, ["sma", "ema_all"])
+    assert "seq_jobs_kernel<3>" in {gs["kernel"] for gs in st.grid_stats()}
+    st.close()
+    # api.call: host data is uploaded pitched (no warning); a dense odd-pitch DEVICE tensor warns once; both give the oracle's values
+    api._warned_layout = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        (got,) = api.call("ema", d["close"], timeperiod=10)
+    (exp,) = oracle.call("ema", d["close"], timeperiod=10)
+    assert got.flags["C_CONTIGUOUS"] and (bits(got) == bits(exp)).all()
+    with pytest.warns(api.PqLayoutWarning):
+        (got,) = api.call("ema", torch.from_numpy(d["close"]).cuda(), timeperiod=10)
+    assert (bits(got.cpu().numpy()) == bits(exp)).all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                          # once per process
+        api.call("ema", torch.from_numpy(d["close"]).cuda(), timeperiod=10)

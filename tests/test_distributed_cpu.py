@@ -159,3 +159,50 @@ def test_shard_range_of_the_c_abi_matches_python():
             lo, hi = C.c_int64(), C.c_int64()
             assert L.pq_shard_range(n, r, g, C.byref(lo), C.byref(hi)) == 0
             assert (lo.value, hi.value) == shard_range(n, r, g)
+
+
+def _worker_overlapped(rank, world, n_sym, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from polars_quant_amd.distributed import OverlappedGather, shard_range
+    lo, hi = shard_range(n_sym, rank, world)
+    og = OverlappedGather(n_sym, hi - lo, "cpu")
+    tables, held = {}, {}
+    for k in range(6):
+        slot = og.acquire()                                   # the exchange that used this slot two steps ago has completed
+        if slot in held:
+            tables[held[slot]] = og.all[slot].clone()
+        # "the step": this rank's rows of step k (symbol s, column c -> 1000 k + 8 s + c), written into the slot's local buffer
+        s_idx = torch.arange(lo, hi, dtype=torch.float64)[:, None]
+        og.local[slot].copy_(1000.0 * k + 8.0 * s_idx + torch.arange(8, dtype=torch.float64)[None, :])
+        og.begin(slot)                                        # returns with the collective in flight
+        held[slot] = k
+    og.drain()
+    for slot, k in held.items():
+        tables[k] = og.all[slot].clone()
+    if rank == 1:
+        q.put({k: v.numpy() for k, v in tables.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_sym", [10, 7])      # even split (one all-gather) and ragged split (grouped broadcasts)
+def test_two_rank_overlapped_double_buffered_gather(n_sym):
+    """distributed.OverlappedGather over gloo, world 2: six steps, two slots, the exchange of step k in flight while step k + 1 fills
+    the other slot; every step's table arrives complete, in symbol order, and belongs to ITS step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + n_sym
+    procs = [ctx.Process(target=_worker_overlapped, args=(r, 2, n_sym, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(got) == [0, 1, 2, 3, 4, 5]
+    for k, table in got.items():
+        exp = 1000.0 * k + 8.0 * np.arange(n_sym)[:, None] + np.arange(8)[None, :]
+        assert table.shape == (n_sym, 8) and (table == exp).all(), k

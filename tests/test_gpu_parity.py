@@ -618,7 +618,7 @@ def _check_suite_replay(pq, oracle, data, stride):
             buf = torch.full((N_SYM, stride), 1e300, dtype=torch.float64, device="cuda")
             buf[:, :T] = torch.from_numpy(data[k]).cuda()
             g[k] = buf[:, :T]
-    st = Suite(N_SYM, T, "cuda", stride=stride)
+    st = Suite(N_SYM, T, "cuda", stride=stride, exact_layout=True)   # the caller's layout as it is (the 8-byte forms at an odd pitch)
     pitch = T if stride is None else stride
     st.record(g)
     info = st.info()
