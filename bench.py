@@ -419,22 +419,30 @@ def main():
                                            *[C.c_void_p(t.data_ptr()) for t in curves], C.c_void_p(local[slot].data_ptr())))
         res = {"symbols_per_gpu": n_local, "symbols_total": n_total, "steps": steps,
                "what": "pq_backtest_macd_cross (signals + scan + summary, position / cash / equity columns written) on the rank's shard"}
-        for mode in (("overlapped", "serial", "kernel_only") if world > 1 else ("kernel_only",)):
-            el = time_loop(run_slot, local, n_total, steps, warmup, mode)
-            res[mode + "_ms_per_step"] = el / steps * 1e3
-        best = res.get("overlapped_ms_per_step", res["kernel_only_ms_per_step"])
+        for m in (("overlapped", "serial", "kernel_only") if world > 1 else ("kernel_only",)):
+            el = time_loop(run_slot, local, n_total, steps, warmup, m)
+            res[m + "_ms_per_step"] = el / steps * 1e3
+        best = min(res["overlapped_ms_per_step"], res["serial_ms_per_step"]) if world > 1 else res["kernel_only_ms_per_step"]
+        if world > 1:
+            res["chosen"] = "serial" if res["serial_ms_per_step"] <= res["overlapped_ms_per_step"] else "overlapped"
         res["value"] = n_total * T / (best * 1e-3)
         res["unit"] = "rows/s"
         return res
 
     suite, ohlcv, n_local, n_total = build(args.scaling)
-    exchange_modes = None
-    if world > 1:   # the step with the exchange in series and without it, for the record (short runs, outside the headline's timed region)
-        exchange_modes = {m + "_ms_per_step": time_steps(suite, ohlcv, n_total, max(5, args.steps // 2), 2, mode=m) / max(5, args.steps // 2) * 1e3
-                          for m in ("serial", "kernel_only")}
-    elapsed = time_steps(suite, ohlcv, n_total, args.steps, args.warmup, timing=True, mode="overlapped")
-    if exchange_modes is not None:
-        exchange_modes["overlapped_ms_per_step"] = elapsed / args.steps * 1e3
+    exchange_modes, mode = None, "kernel_only"
+    if world > 1:
+        # The exchange can run in series behind every step (one more small kernel on the step's stream) or double-buffered on the
+        # communicator's own stream beside the next step.  Which one is cheaper is a property of the runtime and of the step's length
+        # -- a cross-stream dependency costs tens of microseconds on this runtime (scripts/bench_gather.py: a 51 us backtest step
+        # becomes 53 us with the gather in series and 136 us with it overlapped, world of one) -- so both are timed in short runs
+        # outside the headline's timed region (max over ranks, so every rank picks the same) and the faster one is used.
+        short = max(5, args.steps // 2)
+        exchange_modes = {m + "_ms_per_step": time_steps(suite, ohlcv, n_total, short, 2, mode=m) / short * 1e3
+                          for m in ("serial", "overlapped", "kernel_only")}
+        mode = "serial" if exchange_modes["serial_ms_per_step"] <= exchange_modes["overlapped_ms_per_step"] else "overlapped"
+        exchange_modes["chosen"] = mode
+    elapsed = time_steps(suite, ohlcv, n_total, args.steps, args.warmup, timing=True, mode=mode)
     gather_check = None
     if world > 1 and comm is not None:   # cross-check, outside the timed region: the C-ABI gather against torch.distributed's
         ref = gather_summaries(suite.summary, n_total)
@@ -496,10 +504,12 @@ def main():
             "value": rows_total / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "collective": ({"per_step": "one all-gather of the [n_local, 8] summary rows, double-buffered: the exchange of step k runs on the "
-                                        "communicator's own stream beside the kernels of step k + 1 and completes inside the timed region",
-                            "timed": ("pq_gather_summaries_begin / _end (C ABI, csrc/comm.hip: RCCL ncclAllGather on the communicator's stream)" if comm is not None
-                                      else f"torch.distributed all_gather_into_tensor(async_op=True) (the C-ABI communicator could not be built: {comm_note})"),
+            "collective": ({"per_step": "one all-gather of the [n_local, 8] summary rows per step, completed inside the timed region; `step_ms.chosen` = "
+                                        "the faster of: in series on the step's stream / double-buffered on the communicator's own stream beside "
+                                        "the next step (both timed in short runs before the headline run)",
+                            "timed": (("pq_gather_summaries" if mode == "serial" else "pq_gather_summaries_begin / _end") + " (C ABI, csrc/comm.hip: RCCL ncclAllGather)"
+                                      if comm is not None
+                                      else f"torch.distributed all_gather_into_tensor (the C-ABI communicator could not be built: {comm_note})"),
                             "step_ms": exchange_modes,
                             "torch_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
                             "c_abi_equals_torch_gather": gather_check}

@@ -149,7 +149,14 @@ pq_status pq_gather_summaries_end(pq_ctx *ctx, int32_t slot) {
     PQ_REQUIRE(slot == 0 || slot == 1, "pq_gather_summaries_end: slot must be 0 or 1");
     if (!ctx->comm_pending[slot]) return PQ_OK;
     PQ_HIP_TRY(hipSetDevice(ctx->device));
-    PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->comm_ev_done[slot], 0));
+    // steady state: the exchange of two steps ago completed long ago -- a host-side query then saves the cross-stream wait (a barrier
+    // packet on the step's queue costs tens of microseconds on this runtime, scripts/bench_gather.py)
+    const hipError_t q = hipEventQuery(ctx->comm_ev_done[slot]);
+    if (q != hipSuccess) {
+        if (q != hipErrorNotReady) PQ_HIP_TRY(q);
+        (void)hipGetLastError(); // hipErrorNotReady is sticky in hipGetLastError
+        PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->comm_ev_done[slot], 0));
+    }
     ctx->comm_pending[slot] = false;
     return PQ_OK;
 }

@@ -464,9 +464,26 @@ __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
 // body these batches ran before (255 VGPRs, 92 of them spilled, one L1 tag lookup per lane and 8 bytes) and 3.9 ms at the 16-byte
 // aligned pitch 2 528.  (A form with 16-byte accesses on the 8-byte aligned addresses -- legal in the queue's unaligned access mode --
 // was built and measured the same 7.7 ms: the cost of an odd pitch is that every 64-byte piece straddles two cache lines.)
-template <class Op, bool UNAL = false>
+// MJ (multi-job workgroups, suite_mj.hip): the compute wave of this job is one of several in a workgroup that share ONE storer wave.
+// There is no storer branch here and no workgroup barrier: the hand-off is a pair of counters in LDS (MjCtl) -- `ready` = tiles this
+// wave has finished, `taken` = tiles the storer has pulled out of LDS -- so every compute wave runs at its own pace.
+struct MjCtl { unsigned ready, taken, pad0, pad1; };
+typedef __attribute__((address_space(3))) unsigned pq_lds_u32;
+__device__ __forceinline__ unsigned mj_peek(const unsigned *p) { // an LDS word another wave writes: a fresh ds_read every time
+    asm volatile("" ::: "memory");
+    const unsigned v = *(volatile const pq_lds_u32 *)p;
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void mj_post(unsigned *p, unsigned v) { // after the caller's lds_fence(): data first, then the counter
+    asm volatile("" ::: "memory");
+    *(volatile pq_lds_u32 *)p = v;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+constexpr unsigned MJ_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gives up (a protocol error must end the grid, not hang the GPU)
+template <class Op, bool UNAL = false, bool MJ = false>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
-                                            int64_t tile_s0, unsigned char *lds) {
+                                            int64_t tile_s0, unsigned char *lds, MjCtl *ctl = nullptr, unsigned *mj_err = nullptr) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
     constexpr int TB = SeqTile<Op>::TILE_BYTES;
     constexpr int CPL = UNAL ? K : K / 2; // lanes per series segment: 16-byte chunks (UNAL: 8-byte elements)
@@ -475,7 +492,8 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     constexpr int EB = UNAL ? 8 : 16;
     constexpr bool MASKED = SeqTile<Op>::DIRECT; // per-lane stores by wave 0 (row-masked outputs)
     static_assert(NTap<Op>::value == 0 || HasRings<Op>::value, "an op with lag taps needs a ring variant for the LDS body");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_assert(!MJ || (!UNAL && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value), "multi-job workgroups: aligned, tile-output ops without an epilogue");
+    const int lane = threadIdx.x & 63, wave = MJ ? 0 : (int)(threadIdx.x >> 6);
     const int64_t T = d.len, nt = T / K;
     const int csym = lane / CPL, cchunk = lane % CPL;
     // Global addresses of the cooperative tile accesses: a wave-uniform 64-bit base (column + first series of the tile + first row of
@@ -528,12 +546,23 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     // hand-off of a finished out tile to the storer wave.  (Measured alternative: one-wave workgroups in which the compute
     // wave pulls the tile back and issues the stores itself, with the next tile's loads issued before them -- 8.2 vs 5.5 ms
     // per suite step: the wave's own stores hold up its vmcnt waits whatever the order.)
+    unsigned mj_done = 0; // MJ: tiles handed over so far
     auto hand_off = [&](int64_t) {
         if constexpr (MASKED) return;
+        if constexpr (MJ) { // this wave's LDS writes are complete (lds_fence above): publish the tile, wait until the storer has pulled it
+            mj_done++;
+            mj_post(&ctl->ready, mj_done);
+            unsigned spins = 0;
+            while (mj_peek(&ctl->taken) != mj_done) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > MJ_SPIN_LIMIT) { if (lane == 0 && mj_err) atomicExch(mj_err, 1u); break; }
+            }
+            return;
+        }
         __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
         __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
     };
-    if (wave == 1) { // ---------------------------------------------------------------- storer
+    if (!MJ && wave == 1) { // ---------------------------------------------------------------- storer
         if constexpr (!MASKED) {
             // Tunable: the storer can keep ACC consecutive out tiles in registers and issue their stores back to back (ACC * K * 8
             // contiguous bytes per series within a few cycles).  In a pure tile copy 64-byte pieces scattered over 64 series run
