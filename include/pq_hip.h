@@ -318,6 +318,14 @@ pq_status pq_backtest_wave_stats(pq_ctx *, int64_t *out3, int32_t reset);
  * behind.  out4 (host): [0] symbols computed that way since the last reset, [1] chunks that failed the bit test, [2] chunk re-runs,
  * [3] symbols handed to the gated general path.  Synchronises the context's stream. */
 pq_status pq_wt_stats(pq_ctx *, int64_t *out4, int32_t reset);
+/* Ragged batches whose groups are of similar length (n_series x pq_recommended_stride(longest) <= 1.5 x total rows, >= 16 groups,
+ * >= 16 384 rows) do not run the per-lane gather forms of the sequential kernels: every function here is causal in time, so the groups
+ * are re-housed as the rows of a regular padded batch (one streaming copy per input column), the tiled kernel of the same function
+ * walks it -- told every group's own length, so short groups see the reference's short-series rules -- and the groups' rows of every
+ * output are copied back (csrc/pq_dev.h launch_seq, csrc/runtime.hip rg_pack / rg_unpack).  Bit-identical to the gather forms, 2-10 x
+ * faster on `.over("symbol")`-shaped batches (profiles/r05_bench_ragged.json).  *calls: launches that took this path on the context
+ * since the last reset.  PQ_NO_RG_PACK=1 in the environment keeps the gather forms (A/B runs and tests). */
+pq_status pq_ragged_rehouse_stats(pq_ctx *, int64_t *calls, int32_t reset);
 
 /* ---- multi-GPU: symbols are split statically over the ranks -- rank r of G owns [floor(N r / G), floor(N (r + 1) / G)),
  * a contiguous byte range of every symbol-major column -- and every rank runs the calls above on its own shard with no

@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
         L.pq_backtest_wave_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
         L.pq_wt_stats.restype = C.c_int32
         L.pq_wt_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
+        L.pq_ragged_rehouse_stats.restype = C.c_int32
+        L.pq_ragged_rehouse_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
         L.pq_macd_cross_signals.restype = C.c_int32
         L.pq_macd_cross_signals.argtypes = [vp, C.POINTER(Batch), vp, C.c_int64, C.c_int64, C.c_int64, vp, vp]
         L.pq_cross_signals.restype = C.c_int32

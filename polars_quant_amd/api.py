@@ -382,6 +382,15 @@ def backtest_wave_stats(reset: bool = False, device=None):
     return tuple(int(v) for v in out)
 
 
+def ragged_rehouse_stats(reset: bool = False, device=None) -> int:
+    """launches on a ragged batch that took the re-housed tiled path (pq_ragged_rehouse_stats) since the last reset"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = C.c_int64(0)
+    with torch.cuda.device(dev):
+        check(lib().pq_ragged_rehouse_stats(ctx(dev.index), C.byref(out), 1 if reset else 0))
+    return int(out.value)
+
+
 def wt_stats(reset: bool = False, device=None):
     """(symbols computed by the wave-per-symbol indicator kernels, speculative chunks that failed the bit test, chunk re-runs,
     symbols handed to the gated lane-per-symbol path) since the last reset -- pq_wt_stats (csrc/wt_dev.h).  Synchronises."""

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/pq_hip.h"
 #include "experiments.h"
@@ -36,6 +37,9 @@ struct pq_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ev_in[2] = {nullptr, nullptr}, comm_ev_done[2] = {nullptr, nullptr};
     bool comm_pending[2] = {false, false};
+    void *rg_ws = nullptr;       // workspace of the ragged -> regular re-housing (rg_reserve): packed input / output columns + the per-series lengths
+    size_t rg_ws_bytes = 0;
+    int64_t rg_calls = 0;        // launches that took the re-housed path (pq_ragged_rehouse_stats)
     unsigned *wt_gate = nullptr; // [wt_gate_tiles] flags of the wave-per-symbol kernels' direct launches (ops_wt.h): tiles the gated general path redoes
     size_t wt_gate_tiles = 0;
 };
@@ -86,6 +90,7 @@ __device__ __forceinline__ bool pq_isskip(double x) {
 struct Dims {
     int64_t n, len, stride;
     const int64_t *offs; // ragged batch: series s = rows [offs[s], offs[s + 1]) of the long column (len = the longest); else null
+    const int64_t *lens = nullptr; // a re-housed ragged batch (rg_pack): the series' own row counts (<= len); the tiled body hands them to the op
 };
 static inline Dims dims_of(const pq_batch *b) { return Dims{b->n_series, b->len, b->stride, b->offsets}; }
 __device__ __forceinline__ int64_t dims_base(const Dims &d, int64_t s) { return d.offs ? d.offs[s] : s * d.stride; }
@@ -480,8 +485,11 @@ __device__ __forceinline__ void mj_post(unsigned *p, unsigned v) { // after the 
     *(volatile pq_lds_u32 *)p = v;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-constexpr unsigned MJ_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gives up (a protocol error must end the grid, not hang the GPU)
-template <class Op, bool UNAL = false, bool MJ = false>
+constexpr unsigned MJ_SPIN_LIMIT = 1u << 22; // polls before a waiting wave gives up (a protocol error must end the grid, not hang the GPU)
+// LENS: the batch is a re-housed ragged one (launch_seq, rg_pack): every series is walked over d.len rows of its padded row, but the op
+// is told the series' OWN length (init / init_lds read r.len for their short-series rules); rows beyond it are computed on padding
+// and never leave the padded columns.
+template <class Op, bool UNAL = false, bool MJ = false, bool LENS = false>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
                                             int64_t tile_s0, unsigned char *lds, MjCtl *ctl = nullptr, unsigned *mj_err = nullptr) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
@@ -555,7 +563,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
             unsigned spins = 0;
             while (mj_peek(&ctl->taken) != mj_done) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > MJ_SPIN_LIMIT) { if (lane == 0 && mj_err) atomicExch(mj_err, 1u); break; }
+                if (++spins > MJ_SPIN_LIMIT) { if (lane == 0 && mj_err) atomicExch(mj_err, 1u); __builtin_amdgcn_endpgm(); } // (ends this wave)
             }
             return;
         }
@@ -687,7 +695,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     const bool live = s < d.n;
     const int64_t srow = live ? s : d.n - 1; // dead lanes shadow the last series (never stored)
     Row<NIN> r;
-    r.len = d.len;
+    if constexpr (LENS) r.len = d.lens[srow]; else r.len = d.len;
 #pragma unroll
     for (int k = 0; k < NIN; k++) r.in[k] = inp[k] + srow * d.stride;
     if constexpr (HasRings<Op>::value) {
@@ -840,7 +848,7 @@ static inline int seq_cols_tiling(const pq_batch *b, const double *const *in, do
     return 1;
 }
 
-template <class Op, bool LDS, bool UNAL = false>
+template <class Op, bool LDS, bool UNAL = false, bool LENS = false>
 #ifndef PQ_SEQ_MIN_WAVES
 #define PQ_SEQ_MIN_WAVES 1 // analysis builds: 3 = compile every stand-alone op kernel under the light job kernel's register cap
 #endif
@@ -856,7 +864,7 @@ PQ_HOOK_SEQ_KERNEL_ATTR __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_B
     }
     if constexpr (LDS) {
         extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
-        run_seq_lds<Op, UNAL>(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
+        run_seq_lds<Op, UNAL, false, LENS>(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
     } else {
         const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
         if (s >= d.n) return;
@@ -877,6 +885,7 @@ struct SeqTraits { // what the scheduler needs to know about a recorded job
     double summary_bytes_per_series; // extra algorithmic bytes per series (the backtest's summary row)
     const void *extra_reads[4];      // columns read outside the tile path (signal / benchmark columns): ordering hazards only
     bool unal = false;               // the tiled body in its 8-byte form (rows not 16-byte aligned)
+    int tile_k = 0;                  // SeqTile<Op>::K
 };
 template <class Op, class = void>
 struct HasExtraReads { static constexpr bool value = false; };
@@ -911,10 +920,33 @@ template <class Op, class = void>
 struct IsLdsOnly { static constexpr bool value = false; };
 template <class Op>
 struct IsLdsOnly<Op, decltype((void)Op::LDS_ONLY)> { static constexpr bool value = Op::LDS_ONLY; };
+// ---- ragged batches through the tiled bodies (round 5) -------------------------------------------------------------------------------
+// The groups of `.over("symbol")` start at arbitrary rows of the long columns, which the tiled body cannot address; the per-lane gather
+// body can, at one L1 tag lookup per lane and 8 bytes (and, recorded, 255 registers with 92 spilled).  Every function of this library
+// is CAUSAL in time -- row t of a series depends on rows <= t of that series only -- so a ragged batch whose groups are of similar
+// length is re-housed instead: rg_pack copies every group into a row of a regular [n][pitch] batch (pitch = pq_recommended_stride of
+// the longest group, zero padding behind the group's rows), the tiled kernel of the SAME op walks it -- told every series' own length
+// (Dims::lens), so its short-series rules see what the reference sees -- and rg_unpack copies the group's rows of every output back.
+// Two streaming copies per column at the chip's copy rate against a walk at L1 rate; results bit-identical to the gather body
+// (tests/test_ragged_gpu.py runs both).  Taken when the padded batch is at most 1.5 x the rows of the ragged one.
+template <class Op>
+struct IsPackable { static constexpr bool value = !IsMasked<Op>::value && !HasFinish<Op>::value && NDer<Op>::value == 0; };
+static inline bool rg_worth(const pq_batch *b) {
+    if (!b->offsets || b->n_series < 16 || b->stride < 16384 || b->len <= 0) return false;
+    const int64_t pitch = pq_recommended_stride(b->len);
+    return pitch < (1 << 22) && (double)b->n_series * (double)pitch <= 1.5 * (double)b->stride;
+}
+pq_status rg_reserve(pq_ctx *ctx, size_t bytes);
+// src: n_cols long columns of the ragged batch b -> dst: n_cols regular columns [n_series][pitch]; lens: [n_series] (device) receives the group lengths
+pq_status rg_pack(pq_ctx *ctx, const pq_batch *b, int64_t pitch, const double *const *src, double *const *dst, int n_cols, int64_t *lens);
+pq_status rg_unpack(pq_ctx *ctx, const pq_batch *b, int64_t pitch, const double *const *src, double *const *dst, int n_cols);
+
 // can this op instance run in the LDS body on these columns?  (fused ops have no gather body: callers check first)
 template <class Op>
 static inline bool seq_can_lds(const pq_batch *b, const Op &op, const InCols<Op::NIN> &in, const OutCols<Op::NOUT> &out) {
-    return seq_lds_bytes(op) <= SEQ_LDS_LIMIT && seq_cols_tiling<Op::NIN, Op::NOUT>(b, in.p, out.p) >= 0;
+    if (seq_lds_bytes(op) > SEQ_LDS_LIMIT) return false;
+    if (b->offsets && IsPackable<Op>::value && rg_worth(b) && !getenv("PQ_NO_RG_PACK")) return true; // (launch_seq re-houses the batch)
+    return seq_cols_tiling<Op::NIN, Op::NOUT>(b, in.p, out.p) >= 0;
 }
 template <class Op, class = void>
 struct HasSeqId { static constexpr bool value = false; };
@@ -926,6 +958,28 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
                                    const OutCols<Op::NOUT> &out) {
     if (b->n_series == 0 || b->len == 0) return PQ_OK;
     size_t lds = seq_lds_bytes(op);
+    if constexpr (IsPackable<Op>::value) {
+        if (b->offsets && !ctx->rec && lds <= SEQ_LDS_LIMIT && rg_worth(b) && !getenv("PQ_NO_RG_PACK")) { // ragged -> regular, tiled kernel, back
+            constexpr int NIN = Op::NIN, NOUT = Op::NOUT;
+            const int64_t pitch = pq_recommended_stride(b->len);
+            const size_t col = (size_t)b->n_series * (size_t)pitch * sizeof(double);
+            PQ_TRY(rg_reserve(ctx, (NIN + NOUT) * col + (size_t)b->n_series * sizeof(int64_t)));
+            double *cols[NIN + NOUT];
+            for (int k = 0; k < NIN + NOUT; k++) cols[k] = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(ctx->rg_ws) + (size_t)k * col);
+            int64_t *lens = reinterpret_cast<int64_t *>(reinterpret_cast<unsigned char *>(ctx->rg_ws) + (size_t)(NIN + NOUT) * col);
+            PQ_TRY(rg_pack(ctx, b, pitch, in.p, cols, NIN, lens));
+            ctx->rg_calls++;
+            InCols<NIN> pin;
+            OutCols<NOUT> pout;
+            for (int k = 0; k < NIN; k++) pin.p[k] = cols[k];
+            for (int k = 0; k < NOUT; k++) pout.p[k] = cols[NIN + k];
+            Dims pd{b->n_series, b->len, pitch, nullptr, lens};
+            dim3 grid((unsigned)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
+            hipLaunchKernelGGL((seq_kernel<Op, true, false, true>), grid, dim3(SEQ_LDS_BLOCK), lds, ctx->stream, op, pin, pout, pd, (unsigned *)nullptr);
+            PQ_HIP_TRY(hipGetLastError());
+            return rg_unpack(ctx, b, pitch, pout.p, out.p, NOUT);
+        }
+    }
     const int tiling = seq_cols_tiling<Op::NIN, Op::NOUT>(b, in.p, out.p);
     bool use_lds = lds <= SEQ_LDS_LIMIT && tiling >= 0;
     if (IsLdsOnly<Op>::value && !use_lds) {
@@ -944,6 +998,7 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
             SeqTraits tr{Op::SEQ_ID, (int)((double)OpCost<Op>::get(op) * (double)b->len * 1e-3), IsHeavy<Op>::value, IsMasked<Op>::value,
                          use_lds ? lds : 0, (size_t)SeqTile<Op>::BYTES, AlgCols<Op>::value, HasFinish<Op>::value ? 64.0 : 0.0, {}};
             tr.unal = use_lds && tiling == 1;
+            tr.tile_k = SeqTile<Op>::K;
             if constexpr (HasExtraReads<Op>::value) op.extra_reads(tr.extra_reads);
             return rec_add_seq(ctx, b, tr, &op, sizeof(Op), in.p, Op::NIN, out.p, Op::NOUT, extra);
         } else {

@@ -53,6 +53,65 @@ extern "C" pq_status pq_layout_check(const pq_batch *b, const void *const *cols,
     return PQ_OK;
 }
 
+// ---- ragged -> regular re-housing (pq_dev.h: launch_seq) ---------------------------------------------------------------------------
+pq_status rg_reserve(pq_ctx *ctx, size_t bytes) {
+    if (ctx->rg_ws_bytes >= bytes) return PQ_OK;
+    PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); // grow-only; earlier launches may still read the old block
+    if (ctx->rg_ws) PQ_HIP_TRY(hipFree(ctx->rg_ws));
+    ctx->rg_ws = nullptr;
+    ctx->rg_ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->rg_ws, bytes);
+    if (e != hipSuccess) { pq_set_error("ragged workspace hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return PQ_ERR_NOMEM; }
+    ctx->rg_ws_bytes = bytes;
+    return PQ_OK;
+}
+struct RgCols { const double *src[8]; double *dst[8]; int n; };
+// one thread per (series, row of the padded pitch); consecutive threads = consecutive rows: both sides coalesced
+__global__ __launch_bounds__(256) void rg_pack_kernel(RgCols c, const int64_t *offs, int64_t s_base, int64_t pitch, int64_t *lens) {
+    const int64_t s = s_base + blockIdx.y, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pitch) return;
+    const int64_t base = offs[s], len = offs[s + 1] - base;
+    if (lens && t == 0) lens[s] = len;
+    for (int k = 0; k < c.n; k++) c.dst[k][s * pitch + t] = t < len ? c.src[k][base + t] : 0.0;
+}
+__global__ __launch_bounds__(256) void rg_unpack_kernel(RgCols c, const int64_t *offs, int64_t s_base, int64_t pitch) {
+    const int64_t s = s_base + blockIdx.y, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t base = offs[s], len = offs[s + 1] - base;
+    if (t >= len) return;
+    for (int k = 0; k < c.n; k++) c.dst[k][base + t] = c.src[k][s * pitch + t];
+}
+pq_status rg_pack(pq_ctx *ctx, const pq_batch *b, int64_t pitch, const double *const *src, double *const *dst, int n_cols, int64_t *lens) {
+    if (n_cols > 8) { pq_set_error("internal: rg_pack takes at most 8 columns"); return PQ_ERR_UNSUPPORTED; }
+    RgCols c{};
+    c.n = n_cols;
+    for (int k = 0; k < n_cols; k++) { c.src[k] = src[k]; c.dst[k] = dst[k]; }
+    for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) { // grid.y is limited to 65535
+        const int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
+        hipLaunchKernelGGL(rg_pack_kernel, dim3((unsigned)((pitch + 255) / 256), (unsigned)ns), dim3(256), 0, ctx->stream, c, b->offsets, s0, pitch, lens);
+    }
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+pq_status rg_unpack(pq_ctx *ctx, const pq_batch *b, int64_t pitch, const double *const *src, double *const *dst, int n_cols) {
+    if (n_cols > 8) { pq_set_error("internal: rg_unpack takes at most 8 columns"); return PQ_ERR_UNSUPPORTED; }
+    RgCols c{};
+    c.n = n_cols;
+    for (int k = 0; k < n_cols; k++) { c.src[k] = src[k]; c.dst[k] = dst[k]; }
+    for (int64_t s0 = 0; s0 < b->n_series; s0 += 65535) {
+        const int64_t ns = b->n_series - s0 < 65535 ? b->n_series - s0 : 65535;
+        hipLaunchKernelGGL(rg_unpack_kernel, dim3((unsigned)((b->len + 255) / 256), (unsigned)ns), dim3(256), 0, ctx->stream, c, b->offsets, s0, pitch);
+    }
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
+
+extern "C" pq_status pq_ragged_rehouse_stats(pq_ctx *ctx, int64_t *calls, int32_t reset) {
+    if (!ctx || !calls) { pq_set_error("pq_ragged_rehouse_stats: null pointer"); return PQ_ERR_ARG; }
+    *calls = ctx->rg_calls;
+    if (reset) ctx->rg_calls = 0;
+    return PQ_OK;
+}
+
 pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return PQ_OK;
     // grow-only; earlier launches may still read the old block -> drain the stream before freeing it
@@ -140,6 +199,7 @@ pq_status pq_ctx_destroy(pq_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->wt_gate) (void)hipFree(ctx->wt_gate);
+    if (ctx->rg_ws) (void)hipFree(ctx->rg_ws);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PQ_OK;

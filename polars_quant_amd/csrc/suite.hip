@@ -8,29 +8,13 @@
 // blockIdx.x = 64-symbol tile), ROW launches replay as recorded.  pq_suite_run() replays with no host work
 // besides the launches.  Composite functions (MAVP = one job per candidate period) use the same machinery
 // internally through SuiteScope.
-#include "ops_backtest.h"
-#include "ops_fused.h"
+#include "suite_jobs.h"
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <map>
 #include <set>
 #include <vector>
-
-struct SeqJob { // device-visible
-    int kind, nin, nout, cost; // cost: estimated solo duration in microseconds (SeqTraits)
-    int heavy, masked;
-    int cls;                   // CLS_*: the grid the job runs in (suite_finalize)
-    int prio;                  // s_setprio of the job's waves: by its cost relative to the longest job of the phase (suite_finalize)
-    int unal;                  // rows only 8-byte aligned: the grid of its class runs the 8-byte form of the tiled body (seq_jobs_kernel<3>)
-    double summary_bytes;
-    int alg_cols;                  // f64 column transfers credited (per reference call)
-    unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
-    const double *in[6];
-    double *out[8];
-    alignas(8) unsigned char op[1024];
-};
-static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
 
 struct GridStat { // one SEQ grid launch site: algorithmic bytes + optional HIP-event timing
     double alg_bytes = 0;
@@ -60,6 +44,9 @@ static const int k_variant[NCLS] = {0, 0, 1, 2};                                
 // "thin" = six workgroups fit a CU's LDS; the LONG grid places half a workgroup less per CU at t = 0 than LDS admits of its widest
 // job.  Both follow from the device's LDS size and the recorded jobs (at 5 000 x 2 520 on MI355X: 26 KB and 3.5, the values round
 // 2 had tuned as literals).
+// PQ_MJ=1: multi-job workgroups for the light tiled jobs (A/B switch while the form is being measured); PQ_MJ_WIDTH=1..MJ_NC: compute waves used
+static bool mj_enabled() { const char *e = getenv("PQ_MJ"); return e && atoi(e) > 0; }
+static int mj_width() { const char *e = getenv("PQ_MJ_WIDTH"); const int w = e ? atoi(e) : MJ_NC; return w < 1 ? 1 : (w > MJ_NC ? MJ_NC : w); }
 static unsigned thin_lds_max(const hipDeviceProp_t &prop) { return (unsigned)(prop.maxSharedMemoryPerMultiProcessor / 6 / 1024 * 1024); }
 struct Phase {
     GridStat gs[NCLS];
@@ -77,6 +64,12 @@ struct Phase {
     unsigned wg_tiles = 0;
     int first[NCLS + 1] = {}; // job index range of each class
     unsigned lds[NCLS] = {};
+    // multi-job workgroups (suite_mj.hip): when n_mj > 0 the jobs of class LONG run as n_mj groups of up to MJ_NC jobs in ONE grid of
+    // (MJ_NC + 1)-wave workgroups instead of one two-wave workgroup per job and tile
+    MjGroup *d_mj = nullptr;
+    int n_mj = 0;
+    unsigned mj_lds = 0;
+    unsigned *d_mj_err = nullptr;
 };
 struct Recorder {
     pq_batch b;
@@ -93,32 +86,6 @@ struct pq_suite {
     Recorder rec;
 };
 
-// every recordable SEQ op: X(Type).  Kernel variants: the light job kernel is capped at 192 VGPRs (PQ_NV0 below; every op of the list
-// fits without scratch); an op marked HEAVY (none at present: STOCH and the Hilbert pipeline were slimmed in round 3) and the lane-form
-// backtest scan run in a second kernel with the full 256.
-#define SEQ_OPS_LIGHT(X)                                                                                             \
-    X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
-    X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
-    X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
-    X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
-    X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
-    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
-    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(HtAll6Op) X(BtMacdOp) X(LevOp)                                     \
-    X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
-#if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
-#undef SEQ_OPS_LIGHT
-#define SEQ_OPS_LIGHT(X) PQ_ANALYZE_LIGHT
-#endif
-#define SEQ_OPS_HEAVY(X) // (none since the Hilbert pipeline keeps its delay lines in LDS rings; the class and its kernel remain for ops marked HEAVY)
-// V = 0: LDS bodies of the light ops (2 waves/SIMD, capped at 192 VGPRs: PQ_NV0 below), 1: LDS bodies of the heavy ops, 2: gather
-// bodies of every op + the backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
-#ifndef PQ_LB0
-// waves per SIMD the light kernel is compiled for: 2.  At 3 (168 VGPRs, round 2) the three widest jobs (EMA x 4, the volume family, the
-// DM system) spilled 359 registers / 272 B of scratch per lane, and LDS holds a CU to four of the LONG grid's workgroups = 2 waves /
-// SIMD anyway.  The actual cap is PQ_NV0 (192).  Table: profiles/r03_kernel_resources.txt, csrc/suite.resources.txt (every build)
-#define PQ_LB0 2
-#endif
 template <int V>
 __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];
@@ -185,13 +152,6 @@ template <int V> // 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 
 __global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<V>(jobs, d, dbg, wg);
 }
-// Register cap of the light kernel: 192 VGPRs (`amdgpu_num_vgpr` counts register PAIRS on gfx950: 96).  Two job waves then leave 128
-// of a SIMD's 512 registers free, which is what one wave of the pattern kernel (118) or of the wave-per-symbol backtest (122) needs:
-// at the uncapped 199 (200 allocated) neither fits beside two job waves and the pattern kernel -- the last chain of a step to finish --
-// only advances where a job workgroup has retired.  A/B in one session: 4.60 -> 4.53 ms per step.  PQ_NV0=0: no cap.
-#ifndef PQ_NV0
-#define PQ_NV0 96
-#endif
 #if PQ_NV0 > 0
 template <>
 __global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_LDS_BLOCK, PQ_LB0) void seq_jobs_kernel<0>(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
@@ -245,6 +205,7 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
     j.kind = tr.kind; j.nin = nin; j.nout = nout; j.cost = tr.cost; j.heavy = tr.heavy; j.masked = tr.masked;
     j.lds_bytes = (unsigned)tr.lds_bytes; j.tile_bytes = (unsigned)tr.tile_bytes;
     j.unal = tr.unal ? 1 : 0;
+    j.tile_k = tr.tile_k;
     j.alg_cols = tr.alg_cols > 0 ? tr.alg_cols : nin + nout;
     j.summary_bytes = tr.summary_bytes_per_series;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
@@ -395,10 +356,19 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // the longest jobs are the critical path of a step: their waves win the issue arbitration against shorter jobs on the same
         // SIMD.  Relative to the longest job of the phase (>= 0.8 / 0.58 / 0.4 of it), not to absolute microseconds.
         for (SeqJob &j : p.seq) j.prio = j.cost >= 0.8 * cmax ? 3 : j.cost >= 0.58 * cmax ? 2 : j.cost >= 0.4 * cmax ? 1 : 0;
+        // multi-job workgroups (PQ_MJ=1; suite_jobs.h): every tiled light job whose op the storer of such a workgroup can serve goes to
+        // class LONG, which then runs as ONE grid of (MJ_NC + 1)-wave workgroups; the others (row-masked outputs, epilogues) to SHORT
+        bool mj = mj_enabled() && !r.b.offsets;
+        auto mj_job = [&](const SeqJob &j) {
+            return !j.heavy && !j.masked && j.lds_bytes > 0 && !j.unal && j.summary_bytes == 0.0 && mj_kind_supported(j.kind) &&
+                   j.lds_bytes + MJ_CTL_BYTES <= prop.maxSharedMemoryPerMultiProcessor / 2;
+        };
+        for (const SeqJob &j : p.seq) if (!j.heavy && j.lds_bytes > 0 && j.unal) mj = false; // (the 8-byte form has no multi-job kernel)
         for (SeqJob &j : p.seq) {
             const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
             if (j.heavy && (j.lds_bytes > 0 || bt)) j.cls = CLS_HEAVY;
             else if (j.lds_bytes == 0) j.cls = CLS_GATHER;
+            else if (mj) j.cls = mj_job(j) ? CLS_LONG : CLS_SHORT;
             else if (j.lds_bytes > THIN_LDS_MAX) j.cls = CLS_LONG;
             else if (long_wgs + tiles <= long_budget) { j.cls = CLS_LONG; long_wgs += tiles; }
             else j.cls = CLS_SHORT;
@@ -455,6 +425,44 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         for (int c = 0; c < NCLS; c++) { p.first[c + 1] += p.first[c]; p.gs[c].lds = p.lds[c]; }
+        if (mj && p.first[CLS_LONG + 1] > p.first[CLS_LONG]) {
+            // Groups: the jobs in order of decreasing cost (the order of the class), each into the first group that has a free compute
+            // wave and LDS left -- neighbours in cost share a workgroup, whose resources are held until its longest job ends.
+            const unsigned budget = (unsigned)(prop.maxSharedMemoryPerMultiProcessor / 2) - 1024u;
+            std::vector<MjGroup> groups;
+            std::vector<unsigned> used;
+            for (int jx = p.first[CLS_LONG]; jx < p.first[CLS_LONG + 1]; jx++) {
+                const unsigned need = (p.seq[jx].lds_bytes + 15u) & ~15u;
+                size_t gi = 0;
+                for (; gi < groups.size(); gi++)
+                    if (groups[gi].njobs < mj_width() && used[gi] + need <= budget) break;
+                if (gi == groups.size()) {
+                    MjGroup g;
+                    memset(&g, 0, sizeof g);
+                    groups.push_back(g);
+                    used.push_back(MJ_CTL_BYTES);
+                }
+                MjGroup &g = groups[gi];
+                g.job[g.njobs] = jx - p.first[CLS_LONG];
+                g.lds_off[g.njobs] = used[gi];
+                g.njobs++;
+                used[gi] += need;
+            }
+            p.n_mj = (int)groups.size();
+            p.mj_lds = 0;
+            for (unsigned u : used) p.mj_lds = std::max(p.mj_lds, u);
+            p.gs[CLS_LONG].lds = p.mj_lds;
+            PQ_HIP_TRY(hipMalloc((void **)&p.d_mj, sizeof(MjGroup) * groups.size()));
+            PQ_HIP_TRY(hipMemcpy(p.d_mj, groups.data(), sizeof(MjGroup) * groups.size(), hipMemcpyHostToDevice));
+            PQ_HIP_TRY(hipMalloc((void **)&p.d_mj_err, sizeof(unsigned)));
+            PQ_HIP_TRY(hipMemset(p.d_mj_err, 0, sizeof(unsigned)));
+            if (getenv("PQ_SUITE_DEBUG"))
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    fprintf(stderr, "[pq suite] mj group %zu: lds %u, jobs", gi, used[gi]);
+                    for (int k = 0; k < groups[gi].njobs; k++) fprintf(stderr, " %d(kind %d)", groups[gi].job[k], p.seq[p.first[CLS_LONG] + groups[gi].job[k]].kind);
+                    fprintf(stderr, "\n");
+                }
+        }
         if (getenv("PQ_SUITE_DEBUG"))
             for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d class=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost, j.cls);
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
@@ -520,6 +528,11 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             if (nj <= 0) return PQ_OK;
             PQ_HIP_TRY(timed(p.gs[c], st, true));
             unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
+            if (c == CLS_LONG && p.n_mj > 0) {
+                PQ_TRY(mj_launch(ctx, st, p.d_seq + p.first[c], p.d_mj, p.n_mj, tiles, p.mj_lds, d, p.d_mj_err, dbg));
+                PQ_HIP_TRY(timed(p.gs[c], st, false));
+                return PQ_OK;
+            }
             const dim3 grid(tiles, (unsigned)nj);
             int v = k_variant[c];
             if (v == 0) // one job with 8-byte rows: the whole grid runs the 8-byte form (it handles aligned columns as well)
@@ -631,6 +644,13 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
             if (p.d_rows[pos]) { (void)hipFree(p.d_rows[pos]); p.d_rows[pos] = nullptr; p.n_rows[pos] = 0; }
         if (p.d_dbg) (void)hipFree(p.d_dbg);
         if (p.d_wg) (void)hipFree(p.d_wg);
+        if (p.d_mj) { (void)hipFree(p.d_mj); p.d_mj = nullptr; p.n_mj = 0; }
+        if (p.d_mj_err) {
+            unsigned e = 0; // (the stream was drained above) a hand-off that timed out ended its waves instead of hanging the GPU: say so
+            if (hipMemcpy(&e, p.d_mj_err, sizeof e, hipMemcpyDeviceToHost) == hipSuccess && e)
+                fprintf(stderr, "[pq] ERROR: a multi-job workgroup's hand-off timed out (code %u): the columns of this suite are incomplete\n", e);
+            (void)hipFree(p.d_mj_err); p.d_mj_err = nullptr;
+        }
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
         for (hipEvent_t e : p.gs_row.ev) (void)hipEventDestroy(e);
         p.gs_row.ev.clear(); p.gs_row.runs = 0;
@@ -794,6 +814,7 @@ pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
             if ((c < NCLS ? p.gs[c] : p.gs_row).n_jobs == 0) continue;
             if (idx++ != k) continue;
             *variant = c < NCLS ? k_variant[c] : 3; // 3 = the chain of ROW launches
+            if (c == CLS_LONG && p.n_mj > 0) { *variant = 5; return PQ_OK; } // 5 = seq_mj_kernel (multi-job workgroups)
             if (c < NCLS && k_variant[c] == 0)
                 for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) *variant = 4; // 4 = seq_jobs_kernel<3>: the 8-byte form of the tiled body
             return PQ_OK;

@@ -1,0 +1,78 @@
+// suite_jobs.h -- what the job-grid translation units share (suite.hip: recording, scheduling, the classic two-wave job kernels;
+// suite_mj.hip: the multi-job workgroups): the device-visible job record, the list of recordable ops, the register cap.
+#pragma once
+#include "ops_backtest.h"
+#include "ops_fused.h"
+
+struct SeqJob { // device-visible
+    int kind, nin, nout, cost; // cost: estimated solo duration in microseconds (SeqTraits)
+    int heavy, masked;
+    int cls;                   // CLS_*: the grid the job runs in (suite_finalize)
+    int prio;                  // s_setprio of the job's waves: by its cost relative to the longest job of the phase (suite_finalize)
+    int unal;                  // rows only 8-byte aligned: the grid of its class runs the 8-byte form of the tiled body (seq_jobs_kernel<3>)
+    double summary_bytes;
+    int alg_cols;                  // f64 column transfers credited (per reference call)
+    unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
+    int tile_k;                     // rows per tile of the tiled body (SeqTile<Op>::K)
+    const double *in[6];
+    double *out[8];
+    alignas(8) unsigned char op[1024];
+};
+static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
+
+// every recordable SEQ op: X(Type).  Kernel variants: the light job kernel is capped at 192 VGPRs (PQ_NV0 below; every op of the list
+// fits without scratch); an op marked HEAVY (none at present: STOCH and the Hilbert pipeline were slimmed in round 3) and the lane-form
+// backtest scan run in a second kernel with the full 256.
+#define SEQ_OPS_LIGHT(X)                                                                                             \
+    X(SmaOp) X(EmaOp) X(BbandsOp) X(DemaOp) X(TemaOp) X(T3Op) X(WmaOp) X(KamaOp) X(MidpointOp) X(MidpriceOp) X(SarextOp) \
+    X(MavpPickOp) X(MavpSelOp<SmaOp>) X(MavpSelOp<EmaOp>) X(MavpSelOp<WmaOp>) X(MavpSelOp<DemaOp>) X(MavpSelOp<TemaOp>)  \
+    X(MavpSelOp<T3Op>) X(MavpSelOp<KamaOp>)                                                                          \
+    X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
+    X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
+    X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
+    X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(HtAll6Op) X(BtMacdOp) X(LevOp)                                     \
+    X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
+#if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
+#undef SEQ_OPS_LIGHT
+#define SEQ_OPS_LIGHT(X) PQ_ANALYZE_LIGHT
+#endif
+#define SEQ_OPS_HEAVY(X) // (none since the Hilbert pipeline keeps its delay lines in LDS rings; the class and its kernel remain for ops marked HEAVY)
+// V = 0: LDS bodies of the light ops (2 waves/SIMD, capped at 192 VGPRs: PQ_NV0 below), 1: LDS bodies of the heavy ops, 2: gather
+// bodies of every op + the backtest scan (one wave per workgroup; the fallback for very long windows / unaligned columns).
+#ifndef PQ_LB0
+// waves per SIMD the light kernel is compiled for: 2.  At 3 (168 VGPRs, round 2) the three widest jobs (EMA x 4, the volume family, the
+// DM system) spilled 359 registers / 272 B of scratch per lane, and LDS holds a CU to four of the LONG grid's workgroups = 2 waves /
+// SIMD anyway.  The actual cap is PQ_NV0 (192).  Table: profiles/r03_kernel_resources.txt, csrc/suite.resources.txt (every build)
+#define PQ_LB0 2
+#endif
+// Register cap of the light kernel: 192 VGPRs (`amdgpu_num_vgpr` counts register PAIRS on gfx950: 96).  Two job waves then leave 128
+// of a SIMD's 512 registers free, which is what one wave of the pattern kernel (118) or of the wave-per-symbol backtest (122) needs:
+// at the uncapped 199 (200 allocated) neither fits beside two job waves and the pattern kernel -- the last chain of a step to finish --
+// only advances where a job workgroup has retired.  A/B in one session: 4.60 -> 4.53 ms per step.  PQ_NV0=0: no cap.
+#ifndef PQ_NV0
+#define PQ_NV0 96
+#endif
+
+// ---- multi-job workgroups (suite_mj.hip) -------------------------------------------------------------------------------------------
+// A workgroup of MJ_NC + 1 wavefronts takes up to MJ_NC different jobs through the SAME 64-symbol tile: MJ_NC compute waves (each loads
+// its own input tiles and walks its op exactly as in the two-wave form) and ONE storer wave that drains the finished out tiles of all of
+// them.  Why: in the two-wave form every job owns a storer, all 192 registers of it; a CU holds four jobs = four compute waves (one per
+// SIMD) and four storers.  The wide cheap jobs (MACD pair, EMA x 4, the DM system) keep their storer busy and their compute wave idle,
+// the narrow expensive ones (MAMA, the Hilbert pipeline, KAMA) the other way round, and neither can lend the other its idle wave:
+// measured at HEAD, a step without arithmetic takes 3.45 ms, without input loads 3.52, without either 2.78, with both 3.95
+// (profiles/r05_ab_noload_nocompute.txt) -- the parts add up instead of overlapping.  With one storer per three jobs a CU holds SIX
+// compute waves (two workgroups of 4 x 192 registers), and a storer is busy whenever ANY of its three jobs has a tile ready.
+// Hand-off: per compute wave a pair of counters in LDS (MjCtl, pq_dev.h), no workgroup barrier after the first.
+constexpr int MJ_NC = 3;
+struct MjGroup {
+    int njobs;
+    int job[MJ_NC];           // indices into the phase's job array
+    unsigned lds_off[MJ_NC];  // byte offset of the job's LDS region (tiles, then rings) inside the workgroup's allocation
+};
+constexpr unsigned MJ_CTL_BYTES = 256; // MjCtl[MJ_NC] at the start of the allocation
+template <class Op>
+struct MjOk { static constexpr bool value = !IsMasked<Op>::value && !HasFinish<Op>::value && !IsHeavy<Op>::value && NDer<Op>::value <= 3; };
+bool mj_kind_supported(int kind);
+pq_status mj_launch(pq_ctx *ctx, hipStream_t st, const SeqJob *d_jobs, const MjGroup *d_groups, int n_groups, unsigned tiles, unsigned lds_bytes,
+                    Dims d, unsigned *d_err, unsigned long long *dbg);

@@ -79,6 +79,59 @@ def test_every_function_on_ragged_groups(pq, oracle, groups, name):
             check(f"{name}.{oname}{{group {s} len {hi - lo}}}", g[lo:hi], np.asarray(e).reshape(-1), name not in TRANSCENDENTAL, d["close"][lo:hi])
 
 
+@pytest.fixture(scope="module")
+def panel(oracle):
+    """What `.over("symbol")` usually sees: a few hundred groups of SIMILAR length (a panel with listing gaps), a handful of very
+    short ones among them (shorter than every warm-up: all-null there, as in the reference) -- the shape the re-housed tiled path
+    takes (n_series x pitch <= 1.5 x total rows)."""
+    rng = np.random.default_rng(22)
+    lens = np.r_[256, 255, 1, 0, 5, 31, 32, 33, 64, 129, 200, 254, rng.integers(170, 257, size=300), 2, 256].astype(np.int64)
+    off = np.r_[0, np.cumsum(lens)]
+    d = oracle.gen_ohlcv(SEED + 20, 1, int(off[-1]), 0)
+    d = {k: np.ascontiguousarray(v[0]) for k, v in d.items()}
+    d["real"] = d["close"]
+    d["periods"] = rng.integers(0, 40, size=off[-1]).astype(np.float64)
+    assert len(lens) * 256 <= 1.5 * off[-1] and off[-1] >= 16384
+    return d, off, lens
+
+
+@pytest.mark.parametrize("name", ALL_FUNCS)
+def test_every_function_on_a_panel_of_similar_groups_rehoused(pq, oracle, panel, name, monkeypatch):
+    """The re-housed path (ragged -> regular padded batch -> the tiled kernel, told each group's own length -> back): every group equals
+    the oracle run on it ALONE, and the whole column equals, bit for bit, what the per-lane gather forms write (PQ_NO_RG_PACK=1)."""
+    from polars_quant_amd import api
+    d, off, lens = panel
+    cols = pq.SPEC[name][0]
+    ins = [torch.from_numpy(d[c]).cuda() for c in cols]
+    api.ragged_rehouse_stats(reset=True)
+    api.wt_stats(reset=True)
+    got = [g.cpu().numpy() for g in api.call(name, *ins, offsets=off)]
+    rehoused, by_wave = api.ragged_rehouse_stats(), api.wt_stats()[0]
+    seq = pq.SPEC[name][3] is not None and name not in ROW_FUNCS
+    if seq:
+        assert rehoused >= 1 or by_wave > 0, f"{name}: neither the re-housed tiled path nor a wave-per-group form ran"
+    monkeypatch.setenv("PQ_NO_RG_PACK", "1")
+    ref = [g.cpu().numpy() for g in api.call(name, *ins, offsets=off)]
+    monkeypatch.delenv("PQ_NO_RG_PACK")
+    for (oname, _), g, r in zip(pq.SPEC[name][2], got, ref):
+        if name in TRANSCENDENTAL:
+            continue
+        same_ = (bits(g) == bits(r)) | ((g != g) & (r != r)) if g.dtype == np.float64 else (g == r)
+        assert same_.all(), f"{name}.{oname}: re-housed and gather forms differ at rows {np.argwhere(~same_)[:3].ravel().tolist()}"
+    for s in range(len(lens)):
+        lo, hi = off[s], off[s + 1]
+        if hi == lo:
+            continue
+        exp = oracle.call(name, *[d[c][lo:hi] for c in cols])
+        for (oname, _), g, e in zip(pq.SPEC[name][2], got, exp):
+            check(f"{name}.{oname}{{panel group {s} len {hi - lo}}}", g[lo:hi], np.asarray(e).reshape(-1), name not in TRANSCENDENTAL, d["close"][lo:hi])
+
+
+# the functions that are row-parallel kernels (a pure function of a bounded window): ragged batches are native to them
+ROW_FUNCS = {"mom", "roc", "rocp", "rocr", "rocr100", "ht_trendline", "ht_trendmode", "trange", "bop", "avgprice", "medprice", "typprice", "wclprice",
+             "aroon", "aroonosc", "willr", "midprice"}
+
+
 def test_patterns_and_parameters_on_ragged_groups(pq, oracle, groups):
     from polars_quant_amd import api
     d, off, lens = groups
