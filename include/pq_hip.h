@@ -41,7 +41,9 @@ enum {
     PQ_WARN_SLOW_LAYOUT = 100 /* pq_layout_check only: not an error -- results are identical, the kernels take their 8-byte / per-lane forms */
 };
 
-typedef struct pq_ctx pq_ctx; /* device + stream + scratch workspace; one per host thread/stream */
+typedef struct pq_ctx pq_ctx; /* device + stream + scratch workspace; one per host thread/stream.  A pq_ctx is NOT re-entrant: calls grow its
+                               * workspaces on demand, so two host threads must not use one context concurrently (create one each: contexts
+                               * are cheap; the Polars plugin symbols keep one per calling thread) */
 
 /* n_series series of `len` rows; consecutive series start `stride` elements apart (stride >= len).
  * RAGGED batches (offsets != NULL): what the reference sees under `.over("symbol")` -- one plugin call per group of whatever

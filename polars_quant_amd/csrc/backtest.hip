@@ -62,8 +62,7 @@ static bool bt_wave(pq_ctx *ctx, const pq_batch *b, bool macd, const BtArgs &g, 
         // (four per CU by registers): 1 250 symbols 103 against 96 us, where the one-wave form still fits a single round (six per CU by
         // LDS).  PQ_BT_WAVES=1 / 4: A/B runs and tests.
         const char *e = getenv("PQ_BT_WAVES");
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+        const int cus = ctx->cus > 0 ? ctx->cus : 256;
         w.waves = e ? atoi(e) : ((b->n_series > (int64_t)cus * 4 && b->n_series <= (int64_t)cus * 5) ? 1 : 4);
         // recorded into a suite the kernel runs in the tail of a step beside the job grids, where the waiting helper waves cost the
         // other kernels wave slots and registers: 4.02 against 3.85 ms per step -- one wave per symbol there

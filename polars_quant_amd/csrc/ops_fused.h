@@ -266,6 +266,7 @@ struct FastkCore {
 
 template <int MODE> // 0 STOCH -> (slowk, slowd); 1 STOCHF -> (fastk, fastd)     momentum.py:178-195
 struct StochOp {
+    static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 3, NOUT = 2; // high, low, close
     static constexpr int SEQ_ID = 74 + MODE;
@@ -303,6 +304,7 @@ struct StochOp {
 // STOCH and STOCHF of the same fastk_period in one walk: the rolling-extrema core (the expensive part) is evaluated once;
 // slowk/slowd and fastd keep their own moving averages, so every column is bit-identical to the single function's.
 struct StochAllOp {
+    static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 3, NOUT = 4; // -> slowk, slowd, fastk, fastd
     static constexpr int ALG_COLS = 5 + 5;  // stoch, stochf
@@ -335,6 +337,7 @@ struct StochAllOp {
 };
 
 struct StochRsiOp {
+    static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
     static constexpr bool LDS_ONLY = true; // momentum.py:197-205
     static constexpr int NIN = 1, NOUT = 2;
     static constexpr int SEQ_ID = 76;
@@ -523,6 +526,7 @@ struct DmAllOp {
 // for its storer wave's queue position in the write path (11 600 of 27 300 cycles per 8-row tile, PQ_PROFILE_WAVES); with three
 // output columns and one atan less per row it is no longer the step's critical path.
 struct HtAllOp {
+    static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
     static constexpr int NIN = 1, NOUT = 3; // dcperiod, inphase, quadrature
     static constexpr int ALG_COLS = 2 + 3;  // ht_dcperiod, ht_phasor (ht_dcphase and ht_sine are credited to HtPhaseSineOp's launch)
     static constexpr int SEQ_ID = 79;

@@ -106,6 +106,7 @@ struct AdOp {
     }
 };
 struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
+    static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
     static constexpr int NIN = 2, NOUT = 1; // close, volume
     static constexpr int SEQ_ID = 44;
     static constexpr int COST_NS = 120;
@@ -141,6 +142,7 @@ struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
 #define PQ_RAD2DEG (180.0 / PQ_PI)
 template <int MODE>
 struct HtOp {
+    static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
     static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
     static constexpr int SEQ_ID = 45 + MODE;
     static constexpr int COST_NS = 880;

@@ -99,7 +99,10 @@ pq_status pq_midprice(pq_ctx *ctx, const pq_batch *b, const double *high, const 
     // 1.04 ms for the lane-per-symbol job and 0.35 ms for the wave-per-symbol form).  Inside a recorded suite it stays a sequential
     // job: the fused ROW grid is the tail of a step there and one more job in it costs more than the job it replaces (4.03 against
     // 3.88 ms per step, A/B in one session; PQ_MIDPRICE_ROW=1 records the ROW form anyway).  PQ_MIDPRICE_SEQ=1: never the ROW form.
-    if ((!ctx->rec || getenv("PQ_MIDPRICE_ROW")) && !getenv("PQ_MIDPRICE_SEQ")) { MidpriceRowOp rop{}; rop.p = p; return launch_row(ctx, b, rop, IN2(high, low), OutColsT<MidpriceRowOp, double>{{out}}); }
+    // The ROW form rescans the last p valid values per row (walking further back over NULLs): O(p) per row -- taken up to p = 64 (0.1 ms
+    // at p = 14; beyond that the O(1)-amortised wave-per-symbol / lane-per-symbol forms below win, and a column of long NULL runs cannot
+    // turn the call quadratic)
+    if (p <= 64 && (!ctx->rec || getenv("PQ_MIDPRICE_ROW")) && !getenv("PQ_MIDPRICE_SEQ")) { MidpriceRowOp rop{}; rop.p = p; return launch_row(ctx, b, rop, IN2(high, low), OutColsT<MidpriceRowOp, double>{{out}}); }
     { pq_status st; if (wt_midprice(ctx, b, high, low, p, out, &st)) return st; }
     MidpriceOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN2(high, low), OUT1(out));
@@ -126,24 +129,20 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
     PQ_TRY(pq_check(ctx, b)); PQ_REQUIRE(real && periods && out, "pq_mavp: null pointer");
     if (minp > maxp || minp < 0)
         return launch_row(ctx, b, FillNullOp{}, InCols<0>{}, OutColsT<FillNullOp, double>{{out}});
-    // otherwise one masked-select job per candidate period; recorded into a (possibly temporary) suite so that all
-    // of them run as ONE grid
-    SuiteScope scope(ctx, b);
-    PQ_TRY(scope.status);
     const double *r0 = real; // the select jobs map nulls to 0.0 themselves (overlap.rs:416-424)
-    rec_set_shared_out(ctx, true); // the jobs write disjoint rows of `out`
-    pq_status st = PQ_OK;
-    bool blocked = false;
     const bool sma_core = matype != 1 && matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8;
     if (sma_core && maxp - minp < 32 && maxp < (1 << 30)) { // every candidate in ONE job: an ordinary (unmasked) output column
         MavpSma32Op op{}; op.lo = (int)minp; op.hi = (int)maxp; op.minp = (int)minp; op.maxp = (int)maxp;
         InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
-        if (seq_can_lds(b, op, in, o1)) {
-            rec_set_shared_out(ctx, false);
-            PQ_TRY(launch_seq(ctx, b, op, in, o1));
-            return scope.finish();
-        }
+        if (seq_can_lds(ctx, b, op, in, o1)) return launch_seq(ctx, b, op, in, o1); // (one job: a plain launch, or one recorded job)
     }
+    // otherwise one masked-select job per candidate period; recorded into a (possibly temporary) suite so that all
+    // of them run as ONE grid
+    SuiteScope scope(ctx, b);
+    PQ_TRY(scope.status);
+    rec_set_shared_out(ctx, true); // the jobs write disjoint rows of `out`
+    pq_status st = PQ_OK;
+    bool blocked = false;
     if (matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8 && maxp < (1 << 30)) {
         // SMA: sixteen candidate periods per job (states in registers); EMA: eight (states in LDS).  Two passes: decide
         // first whether EVERY block fits the tiled body -- nothing may be recorded before that is known, or the rows of `out`
@@ -156,11 +155,11 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
                 int64_t hi = lo + per_job - 1 < maxp ? lo + per_job - 1 : maxp;
                 if (matype != 1) {
                     MavpSma16Op op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
-                    if (pass == 0) blocked = seq_can_lds(b, op, in, o1);
+                    if (pass == 0) blocked = seq_can_lds(ctx, b, op, in, o1);
                     else st = launch_seq(ctx, b, op, in, o1);
                 } else {
                     MavpBlockOp<1> op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
-                    if (pass == 0) blocked = seq_can_lds(b, op, in, o1);
+                    if (pass == 0) blocked = seq_can_lds(ctx, b, op, in, o1);
                     else st = launch_seq(ctx, b, op, in, o1);
                 }
             }

@@ -40,6 +40,7 @@ struct pq_ctx {
     void *rg_ws = nullptr;       // workspace of the ragged -> regular re-housing (rg_reserve): packed input / output columns + the per-series lengths
     size_t rg_ws_bytes = 0;
     int64_t rg_calls = 0;        // launches that took the re-housed path (pq_ragged_rehouse_stats)
+    int cus = 0;                 // compute units of the device (read once at pq_ctx_create)
     unsigned *wt_gate = nullptr; // [wt_gate_tiles] flags of the wave-per-symbol kernels' direct launches (ops_wt.h): tiles the gated general path redoes
     size_t wt_gate_tiles = 0;
 };
@@ -929,8 +930,12 @@ struct IsLdsOnly<Op, decltype((void)Op::LDS_ONLY)> { static constexpr bool value
 // (Dims::lens), so its short-series rules see what the reference sees -- and rg_unpack copies the group's rows of every output back.
 // Two streaming copies per column at the chip's copy rate against a walk at L1 rate; results bit-identical to the gather body
 // (tests/test_ragged_gpu.py runs both).  Taken when the padded batch is at most 1.5 x the rows of the ragged one.
+template <class Op, class = void>
+struct RgGather { static constexpr bool value = false; }; // Op::RG_GATHER: compute-bound walks (SAR, STOCH, the Hilbert pipeline, OBV) are faster per-lane when called alone
 template <class Op>
-struct IsPackable { static constexpr bool value = !IsMasked<Op>::value && !HasFinish<Op>::value && NDer<Op>::value == 0; };
+struct RgGather<Op, decltype((void)Op::RG_GATHER)> { static constexpr bool value = Op::RG_GATHER; };
+template <class Op>
+struct IsPackable { static constexpr bool value = !IsMasked<Op>::value && !HasFinish<Op>::value && NDer<Op>::value == 0 && !RgGather<Op>::value; };
 static inline bool rg_worth(const pq_batch *b) {
     if (!b->offsets || b->n_series < 16 || b->stride < 16384 || b->len <= 0) return false;
     const int64_t pitch = pq_recommended_stride(b->len);
@@ -943,9 +948,9 @@ pq_status rg_unpack(pq_ctx *ctx, const pq_batch *b, int64_t pitch, const double 
 
 // can this op instance run in the LDS body on these columns?  (fused ops have no gather body: callers check first)
 template <class Op>
-static inline bool seq_can_lds(const pq_batch *b, const Op &op, const InCols<Op::NIN> &in, const OutCols<Op::NOUT> &out) {
+static inline bool seq_can_lds(const pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in, const OutCols<Op::NOUT> &out) {
     if (seq_lds_bytes(op) > SEQ_LDS_LIMIT) return false;
-    if (b->offsets && IsPackable<Op>::value && rg_worth(b) && !getenv("PQ_NO_RG_PACK")) return true; // (launch_seq re-houses the batch)
+    if (b->offsets && !ctx->rec && IsPackable<Op>::value && rg_worth(b) && !getenv("PQ_NO_RG_PACK")) return true; // (launch_seq re-houses the batch)
     return seq_cols_tiling<Op::NIN, Op::NOUT>(b, in.p, out.p) >= 0;
 }
 template <class Op, class = void>
@@ -982,6 +987,10 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     }
     const int tiling = seq_cols_tiling<Op::NIN, Op::NOUT>(b, in.p, out.p);
     bool use_lds = lds <= SEQ_LDS_LIMIT && tiling >= 0;
+    // (the 8-byte form of the tiled body exists for the light job kernel only -- seq_jobs_kernel<3> -- so a recorded HEAVY op on 8-byte
+    //  rows takes the gather class; no op is marked HEAVY at present)
+    if (IsHeavy<Op>::value && tiling == 1 && ctx->rec && !IsLdsOnly<Op>::value) use_lds = false;
+    static_assert(!(IsHeavy<Op>::value && IsLdsOnly<Op>::value), "a HEAVY op needs a gather body: it is what 8-byte-aligned rows run when recorded");
     if (IsLdsOnly<Op>::value && !use_lds) {
         pq_set_error("internal: fused op launched without checking seq_can_lds");
         return PQ_ERR_UNSUPPORTED;

@@ -183,6 +183,7 @@ pq_status pq_ctx_create(int32_t device, void *hip_stream, pq_ctx **out) {
     c->comm = nullptr;
     c->comm_rank = 0;
     c->comm_world = 0;
+    if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0) c->cus = 256;
     c->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
     c->own_stream = false;
     hipError_t e = hipMalloc((void **)&c->d_flag, 64 * sizeof(int64_t)); // [0] reduction scalar, [4..6] wave-backtest statistics (+ [8..23] profiling builds), [24..27] wave-per-symbol indicators (+ [32..63] profiling builds)

@@ -1,7 +1,10 @@
 // wt_api.h -- host entry points of the wave-per-symbol forms (wt.hip).  Each returns true when it has handled the call (launched,
 // or recorded into the suite being recorded; *st = the status) and false when the batch / parameters are outside the form's scope
-// (ragged or unaligned batch, len outside [1 024, 4 096], period out of range, PQ_NO_WT set): the caller then takes its usual path.
-// Output pointers may be null (that output is not computed).
+// (a regular batch whose rows are not 16-byte aligned or whose len is outside [1 024, 4 096], a ragged batch whose groups average fewer
+// than 1 024 rows or whose longest exceeds 4 096, a period out of range, PQ_NO_WT set): the caller then takes its usual path.  RAGGED
+// batches are inside the scope -- any 8-byte group start; wt_all() enables every form for them, the per-lane gather body of the same
+// function runs gated behind for groups with a NULL / NaN -- see wt_try (wt.hip).  Output pointers may be null (that output is not
+// computed).  wt_try grows ctx->wt_gate on demand: like every entry point, these must not run on one pq_ctx from two host threads at once.
 #pragma once
 #include "pq_dev.h"
 

@@ -50,8 +50,33 @@ for n in (5000, 2500, 1250, 625):
     bu = bu.contiguous(); se = se.contiguous()
     dense = close.contiguous()
     out["vectorized_ms"][n] = t_event(lambda: api.backtest_vectorized(dense, bu, se))
+# HIP-graph replay of the shard step: the same call captured once on a side stream and replayed -- what a host that
+# repeats a fixed step (a parameter sweep over the same columns) can do; launch-to-launch time of `reps` replays
+out["macd_cross_graph_replay_ms"] = {}
+for n in (5000, 625):
+    try:
+        buf = torch.zeros((n, PITCH), dtype=torch.float64, device="cuda")
+        buf[:, :T] = torch.from_numpy(full["close"][:n].copy()).cuda()
+        b = api.Batch(n, T, PITCH)
+        pos, cash, eq = (torch.empty((n, PITCH), dtype=torch.float64, device="cuda") for _ in range(3))
+        summ = torch.empty((n, 8), dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            hs = ctx(0)          # the context of the capture stream exists before the capture (its creation allocates)
+            call = lambda: check(lib().pq_backtest_macd_cross(hs, C.byref(b), vp(buf), 12, 26, 9, C.byref(prm), vp(pos), vp(cash), vp(eq), vp(summ)))
+            for _ in range(3): call()
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                call()
+            out["macd_cross_graph_replay_ms"][n] = t_event(g.replay, reps=50)
+    except Exception as e:  # noqa: BLE001
+        out["macd_cross_graph_replay_ms"][n] = f"capture failed: {e}"
 t = out["macd_cross_ms"]
 out["projected_speedup"] = {f"{g}gpu": t[5000] / t[5000 // g] for g in (2, 4, 8)}
+gr = out["macd_cross_graph_replay_ms"]
+if all(isinstance(gr.get(n), float) for n in (5000, 625)):
+    out["projected_speedup_graph_replay_8gpu"] = gr[5000] / gr[625]
 out["rows_per_s_5000"] = 5000 * T / (t[5000] * 1e-3)
 out["alg_GBps_5000"] = 5000 * T * 32 / (t[5000] * 1e-3) / 1e9
 print(json.dumps(out, indent=1))

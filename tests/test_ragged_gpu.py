@@ -107,7 +107,7 @@ def test_every_function_on_a_panel_of_similar_groups_rehoused(pq, oracle, panel,
     api.wt_stats(reset=True)
     got = [g.cpu().numpy() for g in api.call(name, *ins, offsets=off)]
     rehoused, by_wave = api.ragged_rehouse_stats(), api.wt_stats()[0]
-    seq = pq.SPEC[name][3] is not None and name not in ROW_FUNCS
+    seq = name not in ROW_FUNCS and name not in GATHER_FUNCS
     if seq:
         assert rehoused >= 1 or by_wave > 0, f"{name}: neither the re-housed tiled path nor a wave-per-group form ran"
     monkeypatch.setenv("PQ_NO_RG_PACK", "1")
@@ -130,6 +130,10 @@ def test_every_function_on_a_panel_of_similar_groups_rehoused(pq, oracle, panel,
 # the functions that are row-parallel kernels (a pure function of a bounded window): ragged batches are native to them
 ROW_FUNCS = {"mom", "roc", "rocp", "rocr", "rocr100", "ht_trendline", "ht_trendmode", "trange", "bop", "avgprice", "medprice", "typprice", "wclprice",
              "aroon", "aroonosc", "willr", "midprice"}
+
+
+# compute-bound walks whose per-lane form, called alone, beats re-housing + the tiled body (Op::RG_GATHER, profiles/r05_bench_ragged.json)
+GATHER_FUNCS = {"sar", "sarext", "stoch", "stochf", "stochrsi", "obv", "mama", "ht_dcperiod", "ht_dcphase", "ht_phasor", "ht_sine"}
 
 
 def test_patterns_and_parameters_on_ragged_groups(pq, oracle, groups):
