@@ -170,6 +170,8 @@ pq_status pq_macd_pair(pq_ctx *, const pq_batch *, const double *real, int64_t f
 /* Wilder's directional system over (high, low, close): DX, +DI, -DI, ADX, ADXR and ATR, NATR of one timeperiod as one job */
 pq_status pq_dm_system_all(pq_ctx *, const pq_batch *, const double *high, const double *low, const double *close, int64_t timeperiod,
                            double *dx, double *plus_di, double *minus_di, double *adx, double *adxr, double *atr, double *natr);
+/* SMA(timeperiod) and MA(timeperiod, matype 0) are the same walk (overlap.rs:857-869: `ma` dispatches to calc_sma): one job, both columns */
+pq_status pq_sma_ma(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *sma, double *ma);
 /* the two up/down-move oscillators of one timeperiod as one job */
 pq_status pq_cmo_rsi(pq_ctx *, const pq_batch *, const double *real, int64_t timeperiod, double *cmo, double *rsi);
 /* the volume family over (high, low, close, volume): MFI + AD + ADOSC + OBV as one job (4 in / 4 out: MFI's own LDS need) */

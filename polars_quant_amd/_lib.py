@@ -72,7 +72,7 @@ def lib() -> C.CDLL:
                          ("pq_apo_ppo", [vp, C.c_int64, C.c_int64, C.c_int64, vp, vp]),
                          ("pq_stoch_all", [vp, vp, vp] + [C.c_int64] * 7 + [vp] * 4),
                          ("pq_sar_pair", [vp, vp] + [C.c_double] * 10 + [vp, vp]),
-                         ("pq_dm_system_all", [vp, vp, vp, C.c_int64] + [vp] * 7), ("pq_cmo_rsi", [vp, C.c_int64, vp, vp]),
+                         ("pq_dm_system_all", [vp, vp, vp, C.c_int64] + [vp] * 7), ("pq_cmo_rsi", [vp, C.c_int64, vp, vp]), ("pq_sma_ma", [vp, C.c_int64, vp, vp]),
                          ("pq_volume_all", [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp])):
             getattr(L, nm).restype = C.c_int32
             getattr(L, nm).argtypes = [vp, C.POINTER(Batch)] + args

@@ -214,6 +214,14 @@ pq_status pq_dm_system_all(pq_ctx *ctx, const pq_batch *b, const double *h, cons
     PQ_TRY(pq_dmi_all(ctx, b, h, l, c, p, dx, plus_di, minus_di, adx, adxr));
     return pq_atr_all(ctx, b, h, l, c, p, atr, natr);
 }
+pq_status pq_sma_ma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *sma, double *ma) {
+    CHK("pq_sma_ma", real && sma && ma);
+    SmaDupOp op{}; op.a.p = p;
+    InCols<1> in{{real}}; OutCols<2> o{{sma, ma}};
+    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    PQ_TRY(pq_sma(ctx, b, real, p, sma));
+    return pq_ma(ctx, b, real, p, 0, ma);
+}
 pq_status pq_cmo_rsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t p, double *cmo, double *rsi) {
     CHK("pq_cmo_rsi", real && cmo && rsi);
     {   // RSI's Wilder averages contract (wave-per-symbol form); CMO's rolling sums do not: it stays a lane-per-symbol job

@@ -162,6 +162,35 @@ struct TrimaOp {
     __device__ void step_fast(int64_t, const double (&x)[1], double (&y)[1]) { y[0] = b.fast_ring(wb, a.fast_ring(wa, x[0])); }
 };
 
+// SMA(p) and MA(p, matype 0) of one input are the same walk (overlap.rs:857-869: `ma` dispatches to calc_sma, :871-937): one job, the
+// value written to both columns -- the common-subexpression form of two calls a query makes with the wrapper defaults
+// (python/polars_quant/talib/overlap.py: SMA(timeperiod=30), MA(timeperiod=30, matype=0)).
+struct SmaDupOp {
+    static constexpr bool LDS_ONLY = true;
+    static constexpr int NIN = 1, NOUT = 2;
+    static constexpr int SEQ_ID = 88;
+    static constexpr int ALG_COLS = 4; // the two calls it replaces
+    static constexpr int COST_NS = 130;
+    SmaOp a;
+    __host__ __device__ int64_t ring_slots() const { return a.ring_slots(); }
+    __device__ void init(const Row<1> &) {}
+    __device__ void init_lds(const Row<1> &r, RingAlloc &ra) { a.init_lds(r, ra); }
+    __device__ void step(const Row<1> &, int64_t, const double (&)[1], double (&y)[2]) { y[0] = y[1] = pq_null(); }
+    __device__ void step_lds(int64_t t, const double (&x)[1], double (&y)[2]) { double v[1]; a.step_lds(t, x, v); y[0] = y[1] = v[0]; }
+    static constexpr bool HAS_FAST = true;
+    __device__ bool steady(int64_t t0) const { return a.steady(t0); }
+    __device__ void step_fast(int64_t t, const double (&x)[1], double (&y)[2]) { double v[1]; a.step_fast(t, x, v); y[0] = y[1] = v[0]; }
+    static constexpr bool FAST_BATCH = true;
+    static constexpr int FAST_UNROLL = 8;
+    template <int N>
+    __device__ void steps_fast(int64_t t, const double (&x)[N][1], double (&y)[N][2]) {
+        double v[N][1];
+        a.template steps_fast<N>(t, x, v);
+#pragma unroll
+        for (int u = 0; u < N; u++) y[u][0] = y[u][1] = v[u][0];
+    }
+};
+
 template <int MODE> // 0 APO, 1 PPO (decision D-6)
 struct MaDiffOp {
     static constexpr bool LDS_ONLY = true;

@@ -490,7 +490,9 @@ constexpr unsigned MJ_SPIN_LIMIT = 1u << 22; // polls before a waiting wave give
 // LENS: the batch is a re-housed ragged one (launch_seq, rg_pack): every series is walked over d.len rows of its padded row, but the op
 // is told the series' OWN length (init / init_lds read r.len for their short-series rules); rows beyond it are computed on padding
 // and never leave the padded columns.
-template <class Op, bool UNAL = false, bool MJ = false, bool LENS = false>
+// NS: storer waves of the workgroup (1: the two-wave form; 2: seq_jobs_kernel<4>, suite.hip -- a job with many output columns is paced
+// by its store stream, so its columns are dealt out to two storers: storer s takes the columns s, s + 2, ...).
+template <class Op, bool UNAL = false, bool MJ = false, bool LENS = false, int NS = 1>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
                                             int64_t tile_s0, unsigned char *lds, MjCtl *ctl = nullptr, unsigned *mj_err = nullptr) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
@@ -571,7 +573,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
         __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
     };
-    if (!MJ && wave == 1) { // ---------------------------------------------------------------- storer
+    if (!MJ && wave >= 1) { // ---------------------------------------------------------------- storer(s)
+        const int si = NS > 1 ? __builtin_amdgcn_readfirstlane(wave - 1) : 0; // which storer: its columns are si, si + NS, ...
+        constexpr int NOS = (NOUT + NS - 1) / NS;                             // columns per storer (at most)
         if constexpr (!MASKED) {
             // Tunable: the storer can keep ACC consecutive out tiles in registers and issue their stores back to back (ACC * K * 8
             // contiguous bytes per series within a few cycles).  In a pure tile copy 64-byte pieces scattered over 64 series run
@@ -591,9 +595,10 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 // step at pitch 2528 (against 64-byte pieces at the dense pitch 2520; -4 % of it from the pitch alone, which also
                 // aligns the 16-row tiles of the 1-in/1-out ops).  No extra LDS, the register count of two held tiles; columns
                 // beyond the register cap go out per tile as before.
+                // (this storer's j-th column is column kk = j * NS + si of the job; with one storer kk = j)
                 constexpr int CAP = IsHeavy<Op>::value ? 208 : PQ_PAIR_CAP;
-                constexpr int W0 = (CAP - NOUT * NI * 4) / (NI * 4);
-                constexpr int W = W0 < 0 ? 0 : (W0 > NOUT ? NOUT : W0), R = NOUT - W;
+                constexpr int W0 = (CAP - NOS * NI * 4) / (NI * 4);
+                constexpr int W = W0 < 0 ? 0 : (W0 > NOS ? NOS : W0), R = NOS - W;
                 const int half = (lane >> 2) & 1, sub = lane >> 3;
                 const unsigned char *pr_row = lds + sub * ROWB + (lane & 3) * 16;
                 for (int64_t it = 0; it < nt; it += 2) {
@@ -606,40 +611,52 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             lds_fence();
                             if (half == a) {
 #pragma unroll
-                                for (int k = 0; k < W; k++)
+                                for (int k = 0; k < W; k++) {
+                                    const int kk = k * NS + si;
+                                    if (NS > 1 && kk >= NOUT) continue;
 #pragma unroll
                                     for (int i = 0; i < 8; i++) {
-                                        const double *q = reinterpret_cast<const double *>(pr_row + i * 8 * ROWB + k * TB);
+                                        const double *q = reinterpret_cast<const double *>(pr_row + i * 8 * ROWB + kk * TB);
                                         w[k][i] = make_double2(q[0], q[1]);
                                     }
+                                }
                             }
 #pragma unroll
-                            for (int k = 0; k < R; k++)
+                            for (int k = 0; k < R; k++) {
+                                const int kk = (W + k) * NS + si;
+                                if (NS > 1 && kk >= NOUT) continue;
 #pragma unroll
                                 for (int i = 0; i < NI; i++) {
-                                    const double *q = reinterpret_cast<const double *>(co_row(i) + (W + k) * TB);
+                                    const double *q = reinterpret_cast<const double *>(co_row(i) + kk * TB);
                                     v[k][i] = make_double2(q[0], q[1]);
                                 }
+                            }
                             lds_fence();
                             __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
                             const int64_t t0 = (it + a) * K;
 #pragma unroll
-                            for (int k = 0; k < R; k++)
+                            for (int k = 0; k < R; k++) {
+                                const int kk = (W + k) * NS + si;
+                                if (NS > 1 && kk >= NOUT) continue;
 #pragma unroll
                                 for (int i = 0; i < NI; i++)
-                                    if (live_i(i)) nt_store2(at_w(outp[W + k], i, t0), v[k][i]);
+                                    if (live_i(i)) nt_store2(at_w(outp[kk], i, t0), v[k][i]);
+                            }
                         }
                     }
                     const bool mine = it + 1 < nt || half == 0; // an odd tile count leaves the last tile alone
                     const unsigned pair_part = (unsigned)sub * stride_b + (unsigned)(lane & 7) * 16u; // series sub + 8 i, rows 2 (lane & 7) ..
 #pragma unroll
-                    for (int k = 0; k < W; k++)
+                    for (int k = 0; k < W; k++) {
+                        const int kk = k * NS + si;
+                        if (NS > 1 && kk >= NOUT) continue;
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
-                            unsigned char *const pb = reinterpret_cast<unsigned char *>(outp[k] + tile_base + it * K); // wave-uniform
+                            unsigned char *const pb = reinterpret_cast<unsigned char *>(outp[kk] + tile_base + it * K); // wave-uniform
                             if (mine && (unsigned)(i * 8 + sub) <= rel_max)
                                 nt_store2(reinterpret_cast<double *>(pb + (pair_part + (unsigned)(i * 8) * stride_b)), w[k][i]);
                         }
+                    }
                 }
             } else {
             // (an op with derived columns takes this per-tile form: the 64-bit constants of derive() -- ~80 registers for an atan -- leave
@@ -652,14 +669,17 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     if (it + a < nt) {
                         __builtin_amdgcn_s_barrier(); // A: out tile `it + a` is complete
                         lds_fence();
+                        if (NS == 1 || si == 0) { // (this per-tile form is not split over storers: a second one only keeps the barriers company)
 #pragma unroll
                         for (int k = 0; k < NOUT; k++)
 #pragma unroll
                             for (int i = 0; i < NI; i++) v[a][k][i] = l_get(i, k * TB);
+                        }
                         lds_fence();
                         __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
                     }
                 }
+                if (NS > 1 && si != 0) continue;
                 const int64_t t0 = it * K;
 #pragma unroll
                 for (int k = 0; k < NOUT; k++)

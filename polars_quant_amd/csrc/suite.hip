@@ -44,8 +44,35 @@ static const int k_variant[NCLS] = {0, 0, 1, 2};                                
 // "thin" = six workgroups fit a CU's LDS; the LONG grid places half a workgroup less per CU at t = 0 than LDS admits of its widest
 // job.  Both follow from the device's LDS size and the recorded jobs (at 5 000 x 2 520 on MI355X: 26 KB and 3.5, the values round
 // 2 had tuned as literals).
-// PQ_MJ=1: multi-job workgroups for the light tiled jobs (A/B switch while the form is being measured); PQ_MJ_WIDTH=1..MJ_NC: compute waves used
+// A/B builds (scripts/ab_build.sh mj "-DPQ_EXPERIMENTS -DPQ_EXP_MJ" all): PQ_MJ=1 runs the light tiled jobs in multi-job workgroups (measured
+// slower, EXPERIMENTS.md round 5); PQ_MJ_WIDTH=1..MJ_NC: compute waves used
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_MJ)
 static bool mj_enabled() { const char *e = getenv("PQ_MJ"); return e && atoi(e) > 0; }
+#else
+static bool mj_enabled() { return false; } // (the product build carries no seq_mj_kernel: suite_mj.hip compiles to two stubs)
+#endif
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_WIDE)
+static int wide_min_nout() { const char *e = getenv("PQ_WIDE"); return e ? atoi(e) : 0; }
+#else
+static int wide_min_nout() { return 0; } // (the product build has no seq_jobs_kernel<4>)
+#endif
+static bool wide_kind_listed(int kind) { // PQ_WIDE_KINDS=94,90: these job kinds as well (A/B runs; PQ_WIDE=99 then selects by the list alone)
+    const char *e = getenv("PQ_WIDE_KINDS");
+    while (e && *e) {
+        if (atoi(e) == kind) return true;
+        e = strchr(e, ',');
+        if (e) e++;
+    }
+    return false;
+}
+static bool wide_kind_ok(int kind) { // pair-mode ops only: 8-row tiles, no derived columns (what run_seq_lds<..., NS = 2> deals out to two storers)
+    switch (kind) {
+#define X(OP) case OP::SEQ_ID: return SeqTile<OP>::K == 8 && NDer<OP>::value == 0 && !IsMasked<OP>::value && !HasFinish<OP>::value && !IsHeavy<OP>::value;
+        SEQ_OPS_LIGHT(X)
+#undef X
+    default: return false;
+    }
+}
 static int mj_width() { const char *e = getenv("PQ_MJ_WIDTH"); const int w = e ? atoi(e) : MJ_NC; return w < 1 ? 1 : (w > MJ_NC ? MJ_NC : w); }
 static unsigned thin_lds_max(const hipDeviceProp_t &prop) { return (unsigned)(prop.maxSharedMemoryPerMultiProcessor / 6 / 1024 * 1024); }
 struct Phase {
@@ -70,6 +97,7 @@ struct Phase {
     int n_mj = 0;
     unsigned mj_lds = 0;
     unsigned *d_mj_err = nullptr;
+    bool wide = false; // class HEAVY holds light jobs with many output columns and runs seq_jobs_kernel<4> (two storers per workgroup)
 };
 struct Recorder {
     pq_batch b;
@@ -108,6 +136,7 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
         OP op;                                                                                                       \
         __builtin_memcpy(&op, job.op, sizeof(OP));                                                                   \
         if constexpr (V == 2) run_seq(op, job.in, job.out, d, s);                                                    \
+        else if constexpr (V == 4) run_seq_lds<OP, false, false, false, 2>(op, job.in, job.out, d, s0, jobs_lds);    \
         else                                                                                                         \
             run_seq_lds<OP, V == 3>(op, job.in, job.out, d, s0, jobs_lds); \
     } break;
@@ -148,8 +177,11 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
-template <int V> // 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 3: light ops, tiled, rows only 8-byte aligned (UNAL)
-__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+// 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 3: light ops, tiled, rows only 8-byte aligned (UNAL);
+// 4: light ops, tiled, THREE waves per workgroup: one compute wave and two storers (PQ_WIDE: jobs with many output columns)
+constexpr int SEQ_WIDE_BLOCK = 192;
+template <int V>
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : V == 4 ? SEQ_WIDE_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<V>(jobs, d, dbg, wg);
 }
 #if PQ_NV0 > 0
@@ -157,6 +189,12 @@ template <>
 __global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_LDS_BLOCK, PQ_LB0) void seq_jobs_kernel<0>(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<0>(jobs, d, dbg, wg);
 }
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_WIDE) // A/B builds only (EXPERIMENTS.md, round 5): a second storer wave for the jobs with many output columns
+template <>
+__global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_WIDE_BLOCK, PQ_LB0) void seq_jobs_kernel<4>(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+    seq_jobs_body<4>(jobs, d, dbg, wg);
+}
+#endif
 #endif
 
 static int phase_for(Recorder &r, const void *const *reads, int nr, void *const *writes, int nw) {
@@ -364,10 +402,20 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
                    j.lds_bytes + MJ_CTL_BYTES <= prop.maxSharedMemoryPerMultiProcessor / 2;
         };
         for (const SeqJob &j : p.seq) if (!j.heavy && j.lds_bytes > 0 && j.unal) mj = false; // (the 8-byte form has no multi-job kernel)
+        // PQ_WIDE=<n>: light tiled jobs with at least n output columns get a SECOND storer wave (three-wave workgroups, seq_jobs_kernel<4>) on
+        // the chain of the register-heavy class, which no op uses at present -- off if the phase has a job of that class or 8-byte rows
+        int wide_min = wide_min_nout();
+        for (const SeqJob &j : p.seq) {
+            const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1;
+            if ((j.heavy && (j.lds_bytes > 0 || bt)) || (!j.heavy && j.lds_bytes > 0 && j.unal)) wide_min = 0;
+        }
+        if (mj || r.b.offsets) wide_min = 0;
+        p.wide = false;
         for (SeqJob &j : p.seq) {
             const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
             if (j.heavy && (j.lds_bytes > 0 || bt)) j.cls = CLS_HEAVY;
             else if (j.lds_bytes == 0) j.cls = CLS_GATHER;
+            else if (wide_min > 0 && (j.nout >= wide_min || wide_kind_listed(j.kind)) && !j.masked && j.summary_bytes == 0.0 && wide_kind_ok(j.kind)) { j.cls = CLS_HEAVY; p.wide = true; }
             else if (mj) j.cls = mj_job(j) ? CLS_LONG : CLS_SHORT;
             else if (j.lds_bytes > THIN_LDS_MAX) j.cls = CLS_LONG;
             else if (long_wgs + tiles <= long_budget) { j.cls = CLS_LONG; long_wgs += tiles; }
@@ -537,6 +585,10 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             int v = k_variant[c];
             if (v == 0) // one job with 8-byte rows: the whole grid runs the 8-byte form (it handles aligned columns as well)
                 for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) v = 3;
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_WIDE)
+            if (c == CLS_HEAVY && p.wide) hipLaunchKernelGGL(seq_jobs_kernel<4>, grid, dim3(SEQ_WIDE_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
+            else
+#endif
             if (v == 3) hipLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             else if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
             else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
@@ -815,6 +867,7 @@ pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
             if (idx++ != k) continue;
             *variant = c < NCLS ? k_variant[c] : 3; // 3 = the chain of ROW launches
             if (c == CLS_LONG && p.n_mj > 0) { *variant = 5; return PQ_OK; } // 5 = seq_mj_kernel (multi-job workgroups)
+            if (c == CLS_HEAVY && p.wide) { *variant = 6; return PQ_OK; }    // 6 = seq_jobs_kernel<4> (two storers per workgroup)
             if (c < NCLS && k_variant[c] == 0)
                 for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) *variant = 4; // 4 = seq_jobs_kernel<3>: the 8-byte form of the tiled body
             return PQ_OK;

@@ -32,7 +32,7 @@ static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
     X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(HtAll6Op) X(BtMacdOp) X(LevOp)                                     \
-    X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp)
+    X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp) X(SmaDupOp)
 #if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
 #undef SEQ_OPS_LIGHT
 #define SEQ_OPS_LIGHT(X) PQ_ANALYZE_LIGHT

@@ -5,6 +5,9 @@
 // NOUT x [64 series][K rows] doubles at a fixed pitch, whatever produced it (the one exception: the Hilbert job's derived columns).
 #include "suite_jobs.h"
 
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_MJ)
+
+
 #ifndef PQ_MJ_NO_DERIVE
 #define PQ_MJ_NO_DERIVE 0
 #endif
@@ -167,3 +170,13 @@ pq_status mj_launch(pq_ctx *ctx, hipStream_t st, const SeqJob *d_jobs, const MjG
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
 }
+
+#else
+// MEASURED AND NOT TAKEN (EXPERIMENTS.md, round 5: 5.68 against 4.17 ms per step, columns bit-identical): the product build carries neither
+// the kernel nor its op instantiations; `scripts/ab_build.sh mj "-DPQ_EXPERIMENTS -DPQ_EXP_MJ" all` builds the variant, PQ_MJ=1 selects it.
+bool mj_kind_supported(int) { return false; }
+pq_status mj_launch(pq_ctx *, hipStream_t, const SeqJob *, const MjGroup *, int, unsigned, unsigned, Dims, unsigned *, unsigned long long *) {
+    pq_set_error("multi-job workgroups are not part of this build (PQ_EXP_MJ)");
+    return PQ_ERR_UNSUPPORTED;
+}
+#endif

@@ -88,7 +88,8 @@ class Suite:
             o = self.out
             check(L.pq_dmi_all(h, C.byref(b), *[C.c_void_p(ohlcv[k].data_ptr()) for k in ("high", "low", "close")], 14,
                                *[C.c_void_p(o[n][0].data_ptr()) for n in ("dx", "plus_di", "minus_di", "adx", "adxr")]))
-        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all", "sar_pair", "volume_all", "dm_system_all", "cmo_rsi"):
+        elif name in ("ema_all", "atr_all", "dm_pair", "ad_all", "macd_pair", "apo_ppo", "stoch_all", "sar_pair", "volume_all", "dm_system_all", "cmo_rsi",
+                      "sma_ma"):
             # multi-output forms: the listed functions share their inputs and (default) parameters -> one job
             o, P = self.out, lambda k: C.c_void_p(ohlcv[k].data_ptr())
             O = lambda n, i=0: C.c_void_p(o[n][i].data_ptr())
@@ -105,6 +106,8 @@ class Suite:
                                          O("adxr"), O("atr"), O("natr")))
             elif name == "cmo_rsi":
                 check(L.pq_cmo_rsi(h, C.byref(b), P("close"), 14, O("cmo"), O("rsi")))
+            elif name == "sma_ma":    # SMA(30) and MA(30, matype 0): the same walk (overlap.rs:857-869), one job, the value written twice
+                check(L.pq_sma_ma(h, C.byref(b), P("close"), 30, O("sma"), O("ma")))
             elif name == "volume_all":
                 check(L.pq_volume_all(h, C.byref(b), P("high"), P("low"), P("close"), P("volume"), 14, 3, 10, O("mfi"), O("ad"), O("adosc"),
                                       O("obv")))
@@ -138,7 +141,7 @@ class Suite:
              "aroon_all": ("aroon", "aroonosc"), "ema_all": ("ema", "dema", "tema", "trix"), 
              "dm_pair": ("plus_dm", "minus_dm"), "apo_ppo": ("apo", "ppo"),
              "sar_pair": ("sar", "sarext"), "volume_all": ("mfi", "ad", "adosc", "obv"),
-             "stoch_all": ("stoch", "stochf"), "macd_pair": ("macd", "macdfix")}
+             "stoch_all": ("stoch", "stochf"), "macd_pair": ("macd", "macdfix"), "sma_ma": ("sma", "ma")}
     # pq_macd_pair (six output tiles, 27.6 KB) and pq_stoch_all (192 VGPRs since the moving-average cores were slimmed: it now runs in
     # the light job kernel) joined the list in round 3: time-neutral within the noise of a session (4.34 against 4.35 ms per step), two
     # jobs and four column reads fewer.  PQ_SUITE_UNFUSE=name,... keeps the listed ones as separate calls for A/B runs.
@@ -294,7 +297,8 @@ class Suite:
             check(lib().pq_suite_grid_variant(self._suite, k, C.byref(var)))
             out.append({"avg_ms": ms.value, "alg_bytes": by.value, "n_jobs": nj.value, "lds_bytes": lds.value, "runs": runs.value,
                         "kernel": f"seq_jobs_kernel<{var.value}>" if var.value < 3 else ("seq_jobs_kernel<3>" if var.value == 4 else
-                                                                                          "seq_mj_kernel" if var.value == 5 else "row_chain")})
+                                                                                          "seq_mj_kernel" if var.value == 5 else
+                                                                                          "seq_jobs_kernel<4>" if var.value == 6 else "row_chain")})
             k += 1
         return out
 

@@ -622,15 +622,17 @@ def _check_suite_replay(pq, oracle, data, stride):
     pitch = T if stride is None else stride
     st.record(g)
     info = st.info()
-    # tiled path: the multi-output forms make ~25 single-phase jobs (the gather path -- ragged batches, windows whose rings exceed
+    # tiled path: the multi-output forms make ~24 single-phase jobs (the gather path -- ragged batches, windows whose rings exceed
     # 64 KB -- would run every composite as a chain through scratch)
-    assert info["seq_jobs"] >= 25 and info["phases"] >= 1, info
+    assert info["seq_jobs"] >= 24 and info["phases"] >= 1, info
     kernels = {gs["kernel"] for gs in st.grid_stats()}
     # an even row pitch must run the tiled bodies bench.py times; an odd one (rows only 8-byte aligned) their 8-byte form
     # seq_jobs_kernel<3> -- until round 4 it fell to the per-lane gather bodies seq_jobs_kernel<2>, 2.6 x slower at full size.
     # (no job of the suite needs the register-heavy kernel seq_jobs_kernel<1> since the Hilbert pipeline keeps its delay lines in LDS)
     import os
     aligned = "seq_mj_kernel" if os.environ.get("PQ_MJ", "0") not in ("", "0") else "seq_jobs_kernel<0>"   # (PQ_MJ=1: multi-job workgroups, suite_mj.hip)
+    if os.environ.get("PQ_WIDE", "0") not in ("", "0") and pitch % 2 == 0:
+        assert "seq_jobs_kernel<4>" in kernels, kernels      # (PQ_WIDE=n: the jobs with >= n output columns get a second storer wave)
     assert "seq_jobs_kernel<2>" not in kernels and (aligned if pitch % 2 == 0 else "seq_jobs_kernel<3>") in kernels, kernels
     for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
         t.fill_(-7)                      # poison: every row must be produced by the replay
@@ -804,6 +806,9 @@ def test_fused_multi_output_calls(pq, oracle, data):
                                        for n in ("dx", "plus_di", "minus_di", "adx", "adxr", "atr", "natr")]))
     o = mk(2); check(lib().pq_cmo_rsi(api.ctx(0), C.byref(b), P("close"), 14, *V(o)))
     cases.append(("cmo_rsi", o, [oracle.call(n, data["close"], timeperiod=14)[0] for n in ("cmo", "rsi")]))
+    for p_ in (30, 7):
+        o = mk(2); check(lib().pq_sma_ma(api.ctx(0), C.byref(b), P("close"), p_, *V(o)))
+        cases.append((f"sma_ma({p_})", o, [oracle.call("sma", data["close"], timeperiod=p_)[0], oracle.call("ma", data["close"], timeperiod=p_, matype=0)[0]]))
     o = mk(4); check(lib().pq_volume_all(api.ctx(0), C.byref(b), P("high"), P("low"), P("close"), P("volume"), 14, 3, 10, *V(o)))
     hlcv = [data[k] for k in ("high", "low", "close", "volume")]
     cases.append(("volume_all", o, [oracle.call("mfi", *hlcv, timeperiod=14)[0], oracle.call("ad", *hlcv)[0],
