@@ -573,7 +573,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
         __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
     };
-    if (!MJ && wave >= 1) { // ---------------------------------------------------------------- storer(s)
+    // (`wave == 1` for the two-wave form, literally: with `wave >= 1` the compute branch learns that its wave index is 0 and the register
+    //  allocation of the light job kernel shifts by two spilled registers under its 192 cap)
+    if (!MJ && (NS == 1 ? wave == 1 : wave >= 1)) { // -------------------------------------------- storer(s)
         const int si = NS > 1 ? __builtin_amdgcn_readfirstlane(wave - 1) : 0; // which storer: its columns are si, si + NS, ...
         constexpr int NOS = (NOUT + NS - 1) / NS;                             // columns per storer (at most)
         if constexpr (!MASKED) {
