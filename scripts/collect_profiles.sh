@@ -35,11 +35,25 @@ if [ -f "$R/ab/libpq_wtprof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_wtprof
 # 4c. per-job accounting of the compute wave inside a step (a PQ_PROFILE_WAVES build made on the CPU box: scripts/ab_build.sh prof
 #     "-DPQ_EXPERIMENTS -DPQ_PROFILE_WAVES" suite)
 if [ -f "$R/ab/libpq_prof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_prof.so PQ_SUITE_DEBUG=1 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>&1 | grep "pq prof" | tail -40 > "$OUT/wave_profile.txt" ); fi
+# 4d. round 5: ragged batches (re-housed tiled path / wave forms against the gather forms), the exchange modes at a world of one
+( cd "$R" && timeout -k 10 300 python3 scripts/bench_ragged.py > "$OUT/bench_ragged.json" 2>> "$OUT/bench.err" )
+( cd "$R" && timeout -k 10 200 python3 scripts/bench_gather.py 2>> "$OUT/bench.err" | sed -n '/^{/,$p' > "$OUT/bench_gather.json" )
 cp "$R/polars_quant_amd/csrc/suite.resources.txt" "$OUT/kernel_resources.txt" 2>/dev/null || true
 # 5. rocprofv3 kernel stats of the config-3 backtest alone
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bt" -- python3 $R/scripts/bench_backtest.py > /dev/null 2> "$OUT/trace_bt.err"
 f=$(find "$OUT/trace_bt" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/backtest_kernel_stats.csv"; rm -rf "$OUT/trace_bt"
+# 6. instruction-side counters of the step (SQ passes; kernels serialised by the profiler), VALU-busy per SIMD derived in pmc_sq.py
+cd /tmp
+i=0
+for p in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
+  i=$((i+1))
+  timeout -k 10 250 rocprofv3 --kernel-trace --pmc $p --output-format csv -d "$OUT/sq_$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/sq_$i.log" 2>&1 || true
+done
+( cd "$R" && python scripts/pmc_sq.py "$OUT/sq_1" "$OUT/sq_2" "$OUT/sq_3" > "$OUT/sq_counters.txt" 2>> "$OUT/bench.err" )
+rm -rf "$OUT/sq_1" "$OUT/sq_2" "$OUT/sq_3" "$OUT"/sq_*.log
 ls -la "$OUT"
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/wg.log"
 ls -la "$OUT"; tail -1 "$OUT/bench.json" | cut -c1-400
