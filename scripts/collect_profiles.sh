@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary"   # (the step's own kernels only)
 # 1. kernel trace + stats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
