@@ -281,9 +281,18 @@ def sweep_patterns(seed: int, iters: int, log=print) -> int:
 # ---- ragged batches (what the Polars plugin's `_over` entry points launch): one long column, groups of any length
 def _ragged_case(rng, name, log) -> int:
     cols, pspec, outs, fam = SPEC[name]
-    big = rng.random() < 0.35   # groups averaging >= 1024 rows take the one-symbol-per-wavefront forms where one exists
-    ng = int(rng.integers(1, 12 if big else 60))
-    lens = rng.integers(600, 3000, size=ng) if big else rng.choice([0, 1, 2, 7, 31, 32, 33, 64, 65, 100, 255, 256, 300], size=ng)
+    shape = rng.random()
+    big = shape < 0.3           # groups averaging >= 1024 rows take the one-symbol-per-wavefront forms where one exists
+    panel = shape >= 0.7        # many groups of similar length (>= 16 groups, >= 16 384 rows): re-housed as a regular batch, tiled kernels (round 5)
+    if panel:
+        L = int(rng.choice([40, 100, 257, 600]))
+        ng = int(np.ceil(18000 / (0.9 * L))) + int(rng.integers(0, 12))
+        lens = rng.integers(int(0.8 * L), L + 1, size=ng)
+        for _ in range(int(rng.integers(0, 4))):   # a few groups shorter than every warm-up
+            lens[int(rng.integers(0, ng))] = int(rng.choice([0, 1, 2, 7, 31]))
+    else:
+        ng = int(rng.integers(1, 12 if big else 60))
+        lens = rng.integers(600, 3000, size=ng) if big else rng.choice([0, 1, 2, 7, 31, 32, 33, 64, 65, 100, 255, 256, 300], size=ng)
     lens = np.asarray(lens, dtype=np.int64)
     if big and rng.random() < 0.5:
         lens[int(rng.integers(0, ng))] = int(rng.choice([0, 1, 5, 64]))

@@ -375,3 +375,35 @@ def test_layout_advice_and_no_silent_slow_layout(L, oracle):
     with warnings.catch_warnings():
         warnings.simplefilter("error")                          # once per process
         api.call("ema", torch.from_numpy(d["close"]).cuda(), timeperiod=10)
+
+
+def test_baseline_config_1_one_symbol_252_days_sma_and_ema_20(L, oracle):
+    """BASELINE config 1, literally: 1 symbol x 252 days of f64 close, SMA(20) + EMA(20) -- through the C ABI on a host Arrow buffer (what
+    the Rust stub of INTEGRATION.md does) and through the Polars plugin symbols (what `pq.SMA(pl.col("close"), 20)` resolves to), both
+    bit for bit the oracle's."""
+    import pickle
+    from polars_quant_amd._lib import Batch
+    close = np.ascontiguousarray(oracle.gen_ohlcv(0x5EED0C01, 1, 252, 0)["close"][0])
+    arr = pa.array(close)
+    ctx = C.c_void_p()
+    _ck(L, L.pq_ctx_create(0, None, C.byref(ctx)))
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    _ck(L, L.pq_malloc(ctx, 252 * 8, C.byref(d_in))); _ck(L, L.pq_malloc(ctx, 252 * 8, C.byref(d_out)))
+    _ck(L, L.pq_memcpy_h2d(ctx, d_in, C.c_void_p(arr.buffers()[1].address), 252 * 8))
+    b = Batch(1, 252, 252)
+    for name in ("sma", "ema"):
+        _ck(L, getattr(L, "pq_" + name)(ctx, C.byref(b), d_in, 20, d_out))
+        got = np.empty(252)
+        _ck(L, L.pq_memcpy_d2h(ctx, got.ctypes.data_as(C.c_void_p), d_out, 252 * 8))
+        (exp,) = oracle.call(name, close, timeperiod=20)
+        assert (bits(got) == bits(exp)).all(), name
+        assert (bits(got[:19]) == NULLB).all() and np.isfinite(got[19:]).all()
+    _ck(L, L.pq_free(ctx, d_in)); _ck(L, L.pq_free(ctx, d_out)); _ck(L, L.pq_ctx_destroy(ctx))
+    import test_polars_plugin as tp
+    PL = tp._lib()
+    for name in ("sma", "ema"):
+        got = tp._plugin_call(PL, name, [([arr], "close")], {"timeperiod": 20})
+        (exp,) = oracle.call(name, close, timeperiod=20)
+        en = bits(exp) == NULLB
+        assert (np.asarray(got.is_null()) == en).all()
+        assert (bits(got.to_numpy(zero_copy_only=False)[~en]) == bits(exp[~en])).all()
