@@ -705,3 +705,25 @@ def test_batched_over_balanced_panel(oracle, n_groups, glen):
         en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
         assert len(got) == n and (np.asarray(got.is_null()) == en).all(), name
         assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all(), name
+    # nulls inside a pitched panel (the validity bitmap is applied on the host copy, rows between the groups are padding), Int32 output
+    mask = np.zeros(n, bool); mask[::37] = True
+    ses, keep = [], []
+    se, k = _export([pa.array(d["real"], mask=mask)], "real"); ses.append(se); keep.append(k)
+    se, k = _export([pa.array(sym)], "symbol"); ses.append(se); keep.append(k)
+    se, k = _export([pa.array([4], type=pa.int64())], "literal"); ses.append(se); keep.append(k)
+    ins = (SeriesExport * 3)(*ses)
+    ret = SeriesExport(); L._polars_plugin_sma_over(ins, 3, None, 0, C.byref(ret), None)
+    got = _import(ret)
+    xn = d["real"].copy(); xn[mask] = oracle.NULL
+    exp = np.concatenate([np.asarray(oracle.call("sma", xn[g * glen:(g + 1) * glen], timeperiod=4)[0]).reshape(-1) for g in range(n_groups)])
+    en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+    assert (np.asarray(got.is_null()) == en).all() and (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all()
+    ses, keep = [], []
+    for c in ("open", "high", "low", "close"):
+        se, k = _export([pa.array(d[c])], c); ses.append(se); keep.append(k)
+    se, k = _export([pa.array(sym)], "symbol"); ses.append(se); keep.append(k)
+    ins = (SeriesExport * 5)(*ses)
+    ret = SeriesExport(); L._polars_plugin_cdlengulfing_over(ins, 5, None, 0, C.byref(ret), None)
+    got = _import(ret)
+    exp = np.concatenate([oracle.pattern("cdlengulfing", *[d[c][g * glen:(g + 1) * glen] for c in ("open", "high", "low", "close")]).reshape(-1) for g in range(n_groups)])
+    assert got.type == pa.int32() and (got.to_numpy() == exp).all()
