@@ -248,6 +248,8 @@ def main():
                     help="row pitch, in elements, of the INPUT columns the caller hands over (0 = days rounded up to a multiple of 16 = "
                          "128 B; = days: dense).  The suite owns its outputs and re-houses inputs handed over at a pitch that is not a "
                          "multiple of 128 B once, at record time (Suite.house); --exact-layout keeps the caller's pitch for everything")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="run the N-GPU code path (communicator, exchange modes, backtest_only modes, weak-scaling secondary) with a world of one")
     ap.add_argument("--exact-layout", action="store_true", help="run on the caller's row pitch exactly (measures a slow layout as it is)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / shard ranges only (gloo on the CPU, no GPU work): what `--gpus N` would run where")
@@ -267,8 +269,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # --rehearse-exchange: the code path of an N-GPU run -- process group, the C-ABI communicator built on a helper thread, the exchange
+    # modes, the backtest_only figures, the weak-scaling secondary -- on ONE GPU with a world of one (a one-GPU box cannot run N > 1)
+    multi = world > 1 or args.rehearse_exchange
+    if args.rehearse_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -314,23 +324,28 @@ def main():
     # communicator is built on a helper thread with a deadline; if it cannot be built, the step falls back to torch.distributed's
     # all_gather and the line says so (collective.timed).
     comm, comm_note, th = None, None, None
-    if world > 1:
+    if multi:
         import threading
         box = {}
+        # (the suite's three side streams come into being with its first replay: that replay happens HERE, before the communicator and
+        #  its stream(s) exist -- the runtime hands out its four hardware queues in creation order, and a step whose chains share a queue
+        #  takes 5.0 instead of 3.9 ms)
+        suite0, ohlcv0, _nl0, _nt0 = build(args.scaling)
+        suite0.run(ohlcv0)
+        torch.cuda.synchronize()
 
         def mk_comm():
-            # on a side stream, with one trial gather: a communicator that cannot be built -- or whose first collective never returns --
-            # then hangs THAT stream and this thread, not the stream the step runs on
+            # The communicator lives on the context of the stream the steps run on (its in-series gather is then one more kernel on that
+            # stream: +1.3 us at a world of one; bound to another stream every gather would pay two cross-stream dependencies, ~30 us).
+            # The TRIAL exchange runs on the communicator's own stream and is waited for on the host from this helper thread: a
+            # communicator that cannot be built -- or whose first collective never returns -- hangs this thread, not the steps' stream.
             try:
                 torch.cuda.set_device(dev)   # (the current device is per thread)
                 from polars_quant_amd.distributed import CabiComm
-                side = torch.cuda.Stream(dev)
-                with torch.cuda.stream(side):
-                    c = CabiComm(dev, rank, world)
-                    trial = c.gather_summaries(torch.full((1, 8), float(rank), dtype=torch.float64, device=dev), world)
-                    side.synchronize()
-                    if not torch.equal(trial[:, 0].cpu(), torch.arange(world, dtype=torch.float64)):
-                        raise RuntimeError("trial gather returned the wrong rows")
+                c = CabiComm(dev, rank, world)
+                trial = c.trial()
+                if not torch.equal(trial[:, 0].cpu(), torch.arange(world, dtype=torch.float64)):
+                    raise RuntimeError("trial gather returned the wrong rows")
                 box["comm"] = c
             except Exception as e:  # noqa: BLE001
                 box["err"] = str(e)
@@ -354,10 +369,10 @@ def main():
           serial      the exchange on the step's stream behind every step (round 4's form)
           kernel_only no exchange
         Every exchange completes inside the timed region (drain before the closing synchronize)."""
-        og = OverlappedGather(n_total, local[0].shape[0], dev, comm=comm, local=local) if (world > 1 and mode == "overlapped") else None
+        og = OverlappedGather(n_total, local[0].shape[0], dev, comm=comm, local=local) if (multi and mode == "overlapped") else None
 
         def step(k):
-            if world == 1 or mode == "kernel_only":
+            if not multi or mode == "kernel_only":
                 run_slot(k & 1)
             elif og is not None:
                 slot = og.acquire()
@@ -376,7 +391,7 @@ def main():
         torch.cuda.synchronize()
         if on_timed:
             on_timed()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -385,18 +400,18 @@ def main():
         if og is not None:
             og.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         return el
 
     def time_steps(st, ohlcv, n_total, steps, warmup, timing=False, mode="overlapped"):
-        if world > 1 and len(getattr(st, "_summaries", [])) < 2:   # two recordings of the step, one per summary buffer
+        if multi and len(getattr(st, "_summaries", [])) < 2:   # two recordings of the step, one per summary buffer
             st.record(ohlcv, summaries=[st.summary, torch.empty_like(st.summary)])
         two = len(st._summaries) == 2
         return time_loop(lambda slot: st.run(ohlcv, slot=slot if two else 0), st._summaries if two else [st.summary, st.summary], n_total,
@@ -419,19 +434,46 @@ def main():
                                            *[C.c_void_p(t.data_ptr()) for t in curves], C.c_void_p(local[slot].data_ptr())))
         res = {"symbols_per_gpu": n_local, "symbols_total": n_total, "steps": steps,
                "what": "pq_backtest_macd_cross (signals + scan + summary, position / cash / equity columns written) on the rank's shard"}
-        for m in (("overlapped", "serial", "kernel_only") if world > 1 else ("kernel_only",)):
+        for m in (("overlapped", "serial", "kernel_only") if multi else ("kernel_only",)):
             el = time_loop(run_slot, local, n_total, steps, warmup, m)
             res[m + "_ms_per_step"] = el / steps * 1e3
-        best = min(res["overlapped_ms_per_step"], res["serial_ms_per_step"]) if world > 1 else res["kernel_only_ms_per_step"]
-        if world > 1:
+        best = min(res["overlapped_ms_per_step"], res["serial_ms_per_step"]) if multi else res["kernel_only_ms_per_step"]
+        if multi:
             res["chosen"] = "serial" if res["serial_ms_per_step"] <= res["overlapped_ms_per_step"] else "overlapped"
+        # For the record, NOT part of `value`: two INDEPENDENT steps in flight (what a host that sweeps strategy parameters over resident
+        # columns does): step k on stream k & 1, each stream with its own context and its own output columns, no exchange.  A 625-symbol
+        # shard is 625 workgroups on 256 CUs, every wave at its own dependency latency -- a second step fills the idle SIMDs.
+        try:
+            streams = [torch.cuda.Stream(dev) for _ in range(2)]
+            sets = []
+            for st_ in streams:
+                with torch.cuda.stream(st_):
+                    sets.append((ctx(dev.index), [torch.empty((n_local, stride), dtype=torch.float64, device=dev) for _ in range(3)],
+                                 torch.empty((n_local, 8), dtype=torch.float64, device=dev)))
+
+            def run2(k):
+                hh, cv, sm = sets[k & 1]
+                with torch.cuda.stream(streams[k & 1]):
+                    check(L.pq_backtest_macd_cross(hh, C.byref(b), C.c_void_p(close.data_ptr()), 12, 26, 9, C.byref(prm),
+                                                   *[C.c_void_p(t.data_ptr()) for t in cv], C.c_void_p(sm.data_ptr())))
+            for k in range(2 * warmup):
+                run2(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(2 * steps):
+                run2(k)
+            torch.cuda.synchronize()
+            res["two_steps_in_flight_ms_per_step"] = (time.perf_counter() - t0) / (2 * steps) * 1e3
+            res["two_steps_in_flight_same_summary"] = bool(torch.equal(sets[0][2].view(torch.int64), sets[1][2].view(torch.int64)))
+        except Exception as e:  # noqa: BLE001
+            res["two_steps_in_flight_ms_per_step"] = f"failed: {e}"
         res["value"] = n_total * T / (best * 1e-3)
         res["unit"] = "rows/s"
         return res
 
-    suite, ohlcv, n_local, n_total = build(args.scaling)
+    suite, ohlcv, n_local, n_total = (suite0, ohlcv0, _nl0, _nt0) if multi else build(args.scaling)
     exchange_modes, mode = None, "kernel_only"
-    if world > 1:
+    if multi:
         # The exchange can run in series behind every step (one more small kernel on the step's stream) or double-buffered on the
         # communicator's own stream beside the next step.  Which one is cheaper is a property of the runtime and of the step's length
         # -- a cross-stream dependency costs tens of microseconds on this runtime (scripts/bench_gather.py: a 51 us backtest step
@@ -444,7 +486,7 @@ def main():
         exchange_modes["chosen"] = mode
     elapsed = time_steps(suite, ohlcv, n_total, args.steps, args.warmup, timing=True, mode=mode)
     gather_check = None
-    if world > 1 and comm is not None:   # cross-check, outside the timed region: the C-ABI gather against torch.distributed's
+    if multi and comm is not None:   # cross-check, outside the timed region: the C-ABI gather against torch.distributed's
         ref = gather_summaries(suite.summary, n_total)
         got = comm.gather_summaries(suite.summary, n_total)
         torch.cuda.synchronize()
@@ -513,7 +555,7 @@ def main():
                             "step_ms": exchange_modes,
                             "torch_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
                             "c_abi_equals_torch_gather": gather_check}
-                           if world > 1 else None),
+                           if multi else None),
             "backtest_only": bt_only,
             "config": {"workload": f"full talib suite ({len(suite.tasks()) - 2} indicator calls + 61 fused candlestick "
                                    f"recognisers) + fused MACD-cross backtest with summary, {n_total} symbols x {T} days "
@@ -559,13 +601,13 @@ def main():
         el = time_steps(dense, dense_in, n_total, args.steps, args.warmup)
         line["config"]["dense_layout"] = {"row_pitch_elements": T, "ms_per_step": el / args.steps * 1e3}
         dense.close()
-    if world > 1 and default_scaling and not args.no_secondary:
+    if multi and default_scaling and not args.no_secondary:
         # the weak-scaling figure (5000 symbols PER GPU) beside the BASELINE configuration (5000 symbols in total)
         suite.close()
         del ohlcv
         wsuite, wohlcv, wn_local, wn_total = build("weak")
         wsteps = max(5, args.steps // 2)
-        el = time_steps(wsuite, wohlcv, wn_total, wsteps, 2)
+        el = time_steps(wsuite, wohlcv, wn_total, wsteps, 2, mode=mode)
         if rank == 0:
             line["weak_scaling"] = {"symbols_per_gpu": wn_local, "symbols_total": wn_total, "steps": wsteps, "ms_per_step": el / wsteps * 1e3,
                                     "value": wn_total * T * wsteps / el, "unit": "rows/s"}
@@ -574,7 +616,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N_SYM, T)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         if comm is not None:
             try:
                 comm.close()

@@ -348,7 +348,7 @@ pq_status pq_gather_summaries(pq_ctx *, const double *local, int64_t n_symbols, 
 /* The same exchange OFF the step's critical path (round 5): at 8 GPUs a 625-symbol backtest step is ~50 us and an all-gather tens of
  * us, so a gather in series behind every step would cost a third of the throughput.
  *   pq_gather_summaries_begin  marks everything enqueued on the context's stream so far (the step that produced `local`) with an
- *                              event; the communicator's OWN stream (created by pq_comm_init, highest priority) waits for it and takes
+ *                              event; the communicator's OWN stream (created on first use, highest priority) waits for it and takes
  *                              the collective.  Returns at once: the context's stream is free for the next step.  slot = 0 / 1.
  *   pq_gather_summaries_end    the context's stream waits -- on the device, the host does not block -- for that slot's collective:
  *                              work enqueued afterwards may read `all` and overwrite `local`.  A no-op on an idle slot.
@@ -357,6 +357,9 @@ pq_status pq_gather_summaries(pq_ctx *, const double *local, int64_t n_symbols, 
  * reference counterpart (single process). */
 pq_status pq_gather_summaries_begin(pq_ctx *, const double *local, int64_t n_symbols, double *all, int32_t slot);
 pq_status pq_gather_summaries_end(pq_ctx *, int32_t slot);
+/* host-side wait for the communicator's own stream (e.g. to bound the FIRST exchange from a helper thread: a collective that never
+ * returns then blocks that thread, not the context's stream) */
+pq_status pq_comm_sync(pq_ctx *);
 
 /* ---- the README's `Strategy` signal rules (README.md:862-994; README-only, decision D-11 in
  * oracle/backtest.c): indicator columns -> uint8 buy / sell columns for the backtests above.  Row-parallel.

@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
         L.pq_gather_summaries_begin.argtypes = [vp, vp, C.c_int64, vp, C.c_int32]
         L.pq_gather_summaries_end.restype = C.c_int32
         L.pq_gather_summaries_end.argtypes = [vp, C.c_int32]
+        L.pq_comm_sync.restype = C.c_int32
+        L.pq_comm_sync.argtypes = [vp]
         L.pq_backtest_wave_stats.restype = C.c_int32
         L.pq_backtest_wave_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
         L.pq_wt_stats.restype = C.c_int32

@@ -41,6 +41,7 @@ struct pq_ctx {
     size_t rg_ws_bytes = 0;
     int64_t rg_calls = 0;        // launches that took the re-housed path (pq_ragged_rehouse_stats)
     int cus = 0;                 // compute units of the device (read once at pq_ctx_create)
+    hipStream_t suite_aux[4] = {nullptr, nullptr, nullptr, nullptr}; // side streams of suite replays (suite.hip: one per chain, shared by every suite of the context)
     unsigned *wt_gate = nullptr; // [wt_gate_tiles] flags of the wave-per-symbol kernels' direct launches (ops_wt.h): tiles the gated general path redoes
     size_t wt_gate_tiles = 0;
 };

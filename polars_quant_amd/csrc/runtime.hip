@@ -201,6 +201,7 @@ pq_status pq_ctx_destroy(pq_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->wt_gate) (void)hipFree(ctx->wt_gate);
     if (ctx->rg_ws) (void)hipFree(ctx->rg_ws);
+    for (hipStream_t &st : ctx->suite_aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PQ_OK;

@@ -158,6 +158,22 @@ class CabiComm:
         if cur != self.stream:
             cur.wait_stream(self.stream)
 
+    def sync(self) -> None:
+        """pq_comm_sync: block the HOST until the communicator's own stream is idle"""
+        with torch.cuda.device(self.device):
+            self._check(self._lib.pq_comm_sync(self.h))
+
+    def trial(self, timeout_note: str = "") -> torch.Tensor:
+        """one exchange of [1, 8] rows per rank on the communicator's OWN stream, waited for on the host: the stream the steps run on is
+        not touched by a collective that never returns (call from a helper thread with a deadline) -> the gathered [world, 8] table"""
+        loc = torch.full((1, 8), float(self.rank), dtype=torch.float64, device=self.device)
+        out = torch.empty((self.world, 8), dtype=torch.float64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        self.gather_begin(loc, self.world, out, 0)
+        self.sync()
+        self.gather_end(0)
+        return out
+
     def close(self):
         with torch.cuda.device(self.device):
             self._check(self._lib.pq_comm_destroy(self.h))

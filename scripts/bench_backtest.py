@@ -72,8 +72,34 @@ for n in (5000, 625):
             out["macd_cross_graph_replay_ms"][n] = t_event(g.replay, reps=50)
     except Exception as e:  # noqa: BLE001
         out["macd_cross_graph_replay_ms"][n] = f"capture failed: {e}"
+# two INDEPENDENT steps in flight (stream k & 1, own context, own outputs): what a host sweeping strategy parameters over resident columns does
+out["macd_cross_two_in_flight_ms"] = {}
+for n in (5000, 625):
+    buf = torch.zeros((n, PITCH), dtype=torch.float64, device="cuda")
+    buf[:, :T] = torch.from_numpy(full["close"][:n].copy()).cuda()
+    b = api.Batch(n, T, PITCH)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    sets = []
+    for st_ in streams:
+        with torch.cuda.stream(st_):
+            sets.append((ctx(0), [torch.empty((n, PITCH), dtype=torch.float64, device="cuda") for _ in range(3)], torch.empty((n, 8), dtype=torch.float64, device="cuda")))
+    cnt = [0]
+    def run2():
+        k = cnt[0]; cnt[0] += 1
+        hh, cv, sm = sets[k & 1]
+        with torch.cuda.stream(streams[k & 1]):
+            check(lib().pq_backtest_macd_cross(hh, C.byref(b), vp(buf), 12, 26, 9, C.byref(prm), *[vp(t) for t in cv], vp(sm)))
+    import time
+    for _ in range(10): run2()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(400): run2()
+    torch.cuda.synchronize()
+    out["macd_cross_two_in_flight_ms"][n] = (time.perf_counter() - t0) / 400 * 1e3
 t = out["macd_cross_ms"]
 out["projected_speedup"] = {f"{g}gpu": t[5000] / t[5000 // g] for g in (2, 4, 8)}
+tw = out["macd_cross_two_in_flight_ms"]
+out["projected_speedup_two_in_flight_8gpu"] = tw[5000] / tw[625]
 gr = out["macd_cross_graph_replay_ms"]
 if all(isinstance(gr.get(n), float) for n in (5000, 625)):
     out["projected_speedup_graph_replay_8gpu"] = gr[5000] / gr[625]
