@@ -29,7 +29,7 @@ cp "$OUT/r05_pmc_traffic.json" "$R/profiles/r05_pmc_traffic.json"   # (on the bo
 # 4b. the wave-per-symbol indicator kernels alone against the lane-per-symbol bodies (direct C-ABI calls), their per-phase device time
 #     (a PQ_WT_PROF build made on the CPU box: scripts/ab_build.sh wtprof -DPQ_WT_PROF wt) and the in-suite A/B
 ( cd "$R" && timeout -k 10 300 python3 scripts/bench_wt.py 2>> "$OUT/bench.err" | tail -1 > "$OUT/bench_wt.json" )
-if [ -f "$R/ab/libpq_wtprof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_wtprof.so PQ_WT_ALL=1 PQ_MIDPRICE_SEQ=1 timeout -k 10 200 python3 scripts/prof_wt.py > "$OUT/wt_phase_profile.txt" 2>> "$OUT/bench.err" ); fi
+if [ -f "$R/ab/libpq_wtprof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_wtprof.so PQ_WT_ALL=1 PQ_MIDPRICE_SEQ=1 timeout -k 10 200 python3 scripts/prof_wt.py > "$OUT/wt_phase_profile.txt" 2>> "$OUT/bench.err" || true ); fi
 ( cd "$R" && for v in "PQ_NO_WT=1" "PQ_WT_SUITE=1 PQ_WT_ALL=1" "PQ_WT_SUITE=1 PQ_WT_OPS=atr,midpoint" "PQ_MIDPRICE_ROW=1"; do
     echo "$v: $(env $v python3 bench.py --steps 30 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; print(round(json.loads(sys.stdin.readline())['ms_per_step'],3))") ms per step"; done > "$OUT/wt_in_suite_ab.txt" )
 # 4c. per-job accounting of the compute wave inside a step (a PQ_PROFILE_WAVES build made on the CPU box: scripts/ab_build.sh prof
