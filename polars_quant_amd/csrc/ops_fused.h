@@ -296,6 +296,7 @@ struct FastkCore {
 template <int MODE> // 0 STOCH -> (slowk, slowd); 1 STOCHF -> (fastk, fastd)     momentum.py:178-195
 struct StochOp {
     static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
+    static constexpr int64_t DIRECT_LANE_MAX = 16384; // a DIRECT call on a regular batch of up to this many series runs the per-lane form: alone on the chip it is faster (profiles/r05_direct_lane.json)
     static constexpr bool LDS_ONLY = true;
     static constexpr int NIN = 3, NOUT = 2; // high, low, close
     static constexpr int SEQ_ID = 74 + MODE;
@@ -367,6 +368,7 @@ struct StochAllOp {
 
 struct StochRsiOp {
     static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
+    static constexpr int64_t DIRECT_LANE_MAX = 16384; // a DIRECT call on a regular batch of up to this many series runs the per-lane form: alone on the chip it is faster (profiles/r05_direct_lane.json)
     static constexpr bool LDS_ONLY = true; // momentum.py:197-205
     static constexpr int NIN = 1, NOUT = 2;
     static constexpr int SEQ_ID = 76;

@@ -107,6 +107,7 @@ struct AdOp {
 };
 struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
     static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
+    static constexpr int64_t DIRECT_LANE_MAX = 8192;
     static constexpr int NIN = 2, NOUT = 1; // close, volume
     static constexpr int SEQ_ID = 44;
     static constexpr int COST_NS = 120;
@@ -143,6 +144,7 @@ struct ObvOp { // volume.rs:70-94 (quirk Q-OBV: d = prev_close - close)
 template <int MODE>
 struct HtOp {
     static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
+    static constexpr int64_t DIRECT_LANE_MAX = (int64_t)1 << 40; // a DIRECT call always runs the per-lane form (register delay lines: 1.15 against 1.57 ms for ht_dcperiod at any batch size, profiles/r05_direct_lane.json); the tiled form is the suite's (192-register cap)
     static constexpr int NIN = 1, NOUT = (MODE >= 2 ? 2 : 1);
     static constexpr int SEQ_ID = 45 + MODE;
     static constexpr int COST_NS = 880;

@@ -556,6 +556,7 @@ __device__ __forceinline__ double n0(double x) { return pq_isnull(x) ? 0.0 : x; 
 
 struct SarextOp {
     static constexpr bool RG_GATHER = true; // a direct call on a ragged batch keeps the per-lane form: alone on the chip it beats re-housing + the tiled body (profiles/r05_bench_ragged.json)
+    static constexpr int64_t DIRECT_LANE_MAX = 16384; // a DIRECT call on a regular batch of up to this many series runs the per-lane form: alone on the chip it is faster (profiles/r05_direct_lane.json)
     static constexpr int NIN = 2, NOUT = 1;
     static constexpr int SEQ_ID = 11;
     static constexpr int COST_NS = 450;

@@ -957,6 +957,18 @@ template <class Op, class = void>
 struct RgGather { static constexpr bool value = false; }; // Op::RG_GATHER: compute-bound walks (SAR, STOCH, the Hilbert pipeline, OBV) are faster per-lane when called alone
 template <class Op>
 struct RgGather<Op, decltype((void)Op::RG_GATHER)> { static constexpr bool value = Op::RG_GATHER; };
+// Op::DIRECT_LANE_MAX: for a DIRECT call (no recording) on a regular batch of at most that many series the per-lane form is the faster
+// one -- a handful of lone workgroups are bound by their own dependency latency, and for compute-bound walks the tiled body's LDS rings,
+// transposes and hand-offs lengthen exactly that path (STOCHF 0.54 against 1.35 ms at 5 000 x 2 520, the Hilbert functions 1.15 against
+// 1.57 at any size).  Inside a suite, where the chip is full, the tiled forms win (section 4).
+template <class Op, class = void>
+struct DirectLaneMax { static constexpr int64_t value = 0; };
+template <class Op>
+struct DirectLaneMax<Op, decltype((void)Op::DIRECT_LANE_MAX)> { static constexpr int64_t value = Op::DIRECT_LANE_MAX; };
+template <class Op>
+static inline bool direct_lane(const pq_ctx *ctx, const pq_batch *b) {
+    return DirectLaneMax<Op>::value > 0 && !ctx->rec && !b->offsets && b->n_series <= DirectLaneMax<Op>::value && !getenv("PQ_NO_DIRECT_LANE");
+}
 template <class Op>
 struct IsPackable { static constexpr bool value = !IsMasked<Op>::value && !HasFinish<Op>::value && NDer<Op>::value == 0 && !RgGather<Op>::value; };
 static inline bool rg_worth(const pq_batch *b) {
@@ -973,6 +985,7 @@ pq_status rg_unpack(pq_ctx *ctx, const pq_batch *b, int64_t pitch, const double 
 template <class Op>
 static inline bool seq_can_lds(const pq_ctx *ctx, const pq_batch *b, const Op &op, const InCols<Op::NIN> &in, const OutCols<Op::NOUT> &out) {
     if (seq_lds_bytes(op) > SEQ_LDS_LIMIT) return false;
+    if (direct_lane<Op>(ctx, b)) return false; // (an LDS-only fused op: its caller then runs the chain of basic per-lane kernels)
     if (b->offsets && !ctx->rec && IsPackable<Op>::value && rg_worth(b) && !getenv("PQ_NO_RG_PACK")) return true; // (launch_seq re-houses the batch)
     return seq_cols_tiling<Op::NIN, Op::NOUT>(b, in.p, out.p) >= 0;
 }
@@ -1013,6 +1026,7 @@ static inline pq_status launch_seq(pq_ctx *ctx, const pq_batch *b, const Op &op,
     // (the 8-byte form of the tiled body exists for the light job kernel only -- seq_jobs_kernel<3> -- so a recorded HEAVY op on 8-byte
     //  rows takes the gather class; no op is marked HEAVY at present)
     if (IsHeavy<Op>::value && tiling == 1 && ctx->rec && !IsLdsOnly<Op>::value) use_lds = false;
+    if (!IsLdsOnly<Op>::value && direct_lane<Op>(ctx, b)) use_lds = false; // compute-bound walk called alone: the per-lane form
     static_assert(!(IsHeavy<Op>::value && IsLdsOnly<Op>::value), "a HEAVY op needs a gather body: it is what 8-byte-aligned rows run when recorded");
     if (IsLdsOnly<Op>::value && !use_lds) {
         pq_set_error("internal: fused op launched without checking seq_can_lds");
