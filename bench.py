@@ -34,7 +34,7 @@ COPY_GBS = 4900.0   # a grid-stride 16-byte copy kernel on MI355X, read + writte
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured here: streaming read 6.1, fill 6.6 TB/s
 FUSED_FLOOR_BYTES_PER_ROW = 928   # SURVEY 8(d) second denominator: OHLCV read once (40 B) + every output of the step written once
                                   # (64 + 17 f64 indicator columns, 62 int32 columns, 3 backtest columns = 888 B)
-ROUND = "r05"          # evidence under profiles/ is named per round (scripts/collect_profiles.sh writes profiles/<ROUND>_*)
+ROUND = "r06"          # evidence under profiles/ is named per round (scripts/collect_profiles.sh writes profiles/<ROUND>_*)
 PMC_FILE = ROOT / "profiles" / f"{ROUND}_pmc_traffic.json"
 
 
@@ -110,7 +110,10 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
     from polars_quant_amd.loader import DeviceFrame, HostFrame
     L, h = lib(), ctx(dev.index)
     host = HostFrame([str(i) for i in range(n_local)], np.arange(T), {k: np.ascontiguousarray(v.cpu().numpy()) for k, v in ohlcv.items()})
-    frame = DeviceFrame(columns=dict(ohlcv), stride=suite.stride)
+    # the frame uploads into the columns the recorded suite READS: the suite re-houses inputs handed over at a slow row pitch (a dense
+    # [n, 2520] tensor) into its own pitched buffers, and an upload into the caller's tensors would neither reach the step nor fit them
+    cols = dict(getattr(suite, "_ohlcv", None) or suite.house(ohlcv))
+    frame = DeviceFrame(columns=cols, stride=suite.stride)
     frame.register(host)
     summ = np.empty((n_local, 8))
     check(L.pq_host_register(summ.ctypes.data_as(C.c_void_p), summ.nbytes))
@@ -121,7 +124,7 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
 
     def serial(all_outputs):
         frame.upload(host, order=order, copy_stream=torch.cuda.current_stream(dev))
-        suite.run(ohlcv)
+        suite.run()                                    # (the upload went into the columns the recording reads)
         check(L.pq_memcpy_d2h(h, summ.ctypes.data_as(C.c_void_p), C.c_void_p(suite.summary.data_ptr()), summ.nbytes))
         if all_outputs:
             for t in outs:
@@ -144,7 +147,7 @@ def end_to_end(suite, ohlcv, n_local, T, dev):
         dt = (time.perf_counter() - t0) / reps
         res[label] = {"ms": dt * 1e3, "rows_per_s": n_local * T / dt}
     ref_summary = suite.summary.clone()
-    res["stages"] = suite.record_staged(ohlcv)        # (replaces the single recorded suite of this object)
+    res["stages"] = suite.record_staged(cols)         # (replaces the single recorded suite of this object; reads the buffers the frame fills)
     overlapped()
     t0 = time.perf_counter()
     for _ in range(5):
@@ -414,7 +417,8 @@ def main():
         if multi and len(getattr(st, "_summaries", [])) < 2:   # two recordings of the step, one per summary buffer
             st.record(ohlcv, summaries=[st.summary, torch.empty_like(st.summary)])
         two = len(st._summaries) == 2
-        return time_loop(lambda slot: st.run(ohlcv, slot=slot if two else 0), st._summaries if two else [st.summary, st.summary], n_total,
+        # (run() without tensors: the inputs are resident -- where record() re-housed a slow-pitch column, resident means the suite's copy)
+        return time_loop(lambda slot: st.run(slot=slot if two else 0), st._summaries if two else [st.summary, st.summary], n_total,
                          steps, warmup, mode, on_timed=(lambda: st.set_timing(True)) if timing else None)
 
     def backtest_only(ohlcv, n_local, n_total, steps, warmup, stride):

@@ -7,6 +7,8 @@
 //   PQ_EXP_PLAIN_STORES  plain instead of non-temporal stores
 //   PQ_EXP_NOLOAD        tile loads replaced by constants (with NOCOMPUTE: what do the input reads cost?)
 //   PQ_EXP_NOCOMPUTE     outputs = the first input: the traffic and the hand-off machinery alone
+//   PQ_EXP_STOREONLY     the store replica: the storer waves of the tiled job bodies issue exactly the step's stores (grids, addresses, piece
+//                        sizes, non-temporal policy) from register values; the compute wave returns at once, no LDS traffic, no barriers
 //   PQ_PROFILE_WAVES     s_memtime accounting of the compute wave per job kind (load wait + LDS fill, rows, hand-off), SIMD histogram
 //   PQ_STORER_ACC=2|4    the storer wave keeps 2 / 4 out tiles and stores them back to back
 //   PQ_PF2_MAX=<n>       a second tile of register prefetch for ops whose inputs need <= n VGPRs
@@ -20,6 +22,16 @@
 #else
 #define PQ_EXP_NOSTORE_ON 0
 #endif
+
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_STOREONLY)
+#define PQ_EXP_STOREONLY_ON 1
+#else
+#define PQ_EXP_STOREONLY_ON 0
+#endif
+// (SO: a constant of run_seq_lds -- the replica applies to this op)
+#define PQ_HOOK_STORER_BARRIER() do { if constexpr (!SO) __builtin_amdgcn_s_barrier(); } while (0)
+#define PQ_HOOK_STORER_PULL(q, kk, i) (SO ? make_double2((double)(kk), (double)((i) + lane)) : make_double2((q)[0], (q)[1]))
+#define PQ_HOOK_STORER_PULL_G(expr, kk, i) (SO ? make_double2((double)(kk), (double)((i) + lane)) : (expr))
 
 #ifndef PQ_EXPERIMENTS
 // ---------------------------------------------------------------- product: the plain operations

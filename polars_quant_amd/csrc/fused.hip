@@ -131,7 +131,7 @@ pq_status pq_ema_all(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
     EmaAllOp op{};
     op.a.a.p = p; op.a.b.p = p; op.b.a.p = p; op.b.b.p = p;
     InCols<1> in{{real}}; OutCols<4> o{{ema, dema, tema, trix}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_ema(ctx, b, real, p, ema)); PQ_TRY(pq_dema(ctx, b, real, p, dema)); PQ_TRY(pq_tema(ctx, b, real, p, tema));
     return pq_trix(ctx, b, real, p, trix);
 }
@@ -140,7 +140,7 @@ pq_status pq_atr_all(pq_ctx *ctx, const pq_batch *b, const double *h, const doub
     { pq_status st; if (wt_atr(ctx, b, h, l, c, p, atr, natr, &st)) return st; }
     AtrAllOp op{}; op.a.p = p; op.b.p = p;
     InCols<3> in{{h, l, c}}; OutCols<2> o{{atr, natr}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_atr(ctx, b, h, l, c, p, atr));
     return pq_natr(ctx, b, h, l, c, p, natr);
 }
@@ -149,7 +149,7 @@ pq_status pq_dm_pair(pq_ctx *ctx, const pq_batch *b, const double *h, const doub
     { pq_status st; if (wt_dm_pair(ctx, b, h, l, p, plus_dm, minus_dm, &st)) return st; }
     DmPairOp op{}; op.a.p = p; op.b.p = p;
     InCols<2> in{{h, l}}; OutCols<2> o{{plus_dm, minus_dm}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_plus_dm(ctx, b, h, l, p, plus_dm));
     return pq_minus_dm(ctx, b, h, l, p, minus_dm);
 }
@@ -158,7 +158,7 @@ pq_status pq_ad_all(pq_ctx *ctx, const pq_batch *b, const double *h, const doubl
     CHK("pq_ad_all", h && l && c && v && ad && adosc);
     AdAllOp op{}; op.a.fast = op.a.slow = 0; op.b.fast = fast; op.b.slow = slow;
     InCols<4> in{{h, l, c, v}}; OutCols<2> o{{ad, adosc}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_ad(ctx, b, h, l, c, v, ad));
     return pq_adosc(ctx, b, h, l, c, v, fast, slow, adosc);
 }
@@ -169,7 +169,7 @@ pq_status pq_macd_pair(pq_ctx *ctx, const pq_batch *b, const double *real, int64
     MacdPairOp op{};
     op.a.fast = fast; op.a.slow = slow; op.a.sig = sig; op.b.fast = 12; op.b.slow = 26; op.b.sig = fix_sig; // momentum.py:90-92
     InCols<1> in{{real}}; OutCols<6> o{{macd, signal, hist, fmacd, fsignal, fhist}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_macd(ctx, b, real, fast, slow, sig, macd, signal, hist));
     return pq_macdfix(ctx, b, real, fix_sig, fmacd, fsignal, fhist);
 }
@@ -183,7 +183,7 @@ pq_status pq_sar_pair(pq_ctx *ctx, const pq_batch *b, const double *high, const 
     op.b.ext = true; op.b.startvalue = startvalue; op.b.offset = offsetonreverse;
     op.b.ai_long = ai_long; op.b.a_long = a_long; op.b.am_long = am_long; op.b.ai_short = ai_short; op.b.a_short = a_short; op.b.am_short = am_short;
     InCols<2> in{{high, low}}; OutCols<2> o{{sar, sarext}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_sar(ctx, b, high, low, accel, maxv, sar));
     return pq_sarext(ctx, b, high, low, startvalue, offsetonreverse, ai_long, a_long, am_long, ai_short, a_short, am_short, sarext);
 }
@@ -193,7 +193,7 @@ pq_status pq_volume_all(pq_ctx *ctx, const pq_batch *b, const double *h, const d
     VolumeAllOp op{};
     op.a.p = mfi_p; op.b.a.a.fast = op.b.a.a.slow = 0; op.b.a.b.fast = fast; op.b.a.b.slow = slow;
     InCols<4> in{{h, l, c, v}}; OutCols<4> o{{mfi, ad, adosc, obv}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_mfi(ctx, b, h, l, c, v, mfi_p, mfi)); PQ_TRY(pq_ad(ctx, b, h, l, c, v, ad));
     PQ_TRY(pq_adosc(ctx, b, h, l, c, v, fast, slow, adosc));
     return pq_obv(ctx, b, c, v, obv);
@@ -210,7 +210,7 @@ pq_status pq_dm_system_all(pq_ctx *ctx, const pq_batch *b, const double *h, cons
     }
     DmiAtrOp op{}; op.a.p = p; op.b.a.p = p; op.b.b.p = p;
     InCols<3> in{{h, l, c}}; OutCols<7> o{{dx, plus_di, minus_di, adx, adxr, atr, natr}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_dmi_all(ctx, b, h, l, c, p, dx, plus_di, minus_di, adx, adxr));
     return pq_atr_all(ctx, b, h, l, c, p, atr, natr);
 }
@@ -218,7 +218,7 @@ pq_status pq_sma_ma(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t 
     CHK("pq_sma_ma", real && sma && ma);
     SmaDupOp op{}; op.a.p = p;
     InCols<1> in{{real}}; OutCols<2> o{{sma, ma}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_sma(ctx, b, real, p, sma));
     return pq_ma(ctx, b, real, p, 0, ma);
 }
@@ -230,7 +230,7 @@ pq_status pq_cmo_rsi(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
     }
     CmoRsiOp op{}; op.a.p = p; op.b.p = p;
     InCols<1> in{{real}}; OutCols<2> o{{cmo, rsi}};
-    if (seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_cmo(ctx, b, real, p, cmo));
     return pq_rsi(ctx, b, real, p, rsi);
 }
@@ -241,7 +241,7 @@ pq_status pq_stoch_all(pq_ctx *ctx, const pq_batch *b, const double *h, const do
     StochAllOp op{};
     op.fastk = fastk; op.slowk = slowk; op.slowk_mt = slowk_mt; op.slowd = slowd; op.slowd_mt = slowd_mt; op.fastd = fastd; op.fastd_mt = fastd_mt;
     InCols<3> in{{h, l, c}}; OutCols<4> o{{slowk_out, slowd_out, fastk_out, fastd_out}};
-    if (Ma2::supports(slowk_mt) && Ma2::supports(slowd_mt) && Ma2::supports(fastd_mt) && seq_can_lds(ctx, b, op, in, o))
+    if (PQ_FUSE_OK(ctx) && Ma2::supports(slowk_mt) && Ma2::supports(slowd_mt) && Ma2::supports(fastd_mt) && seq_can_lds(ctx, b, op, in, o))
         return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_stoch(ctx, b, h, l, c, fastk, slowk, slowk_mt, slowd, slowd_mt, slowk_out, slowd_out));
     return pq_stochf(ctx, b, h, l, c, fastk, fastd, fastd_mt, fastk_out, fastd_out);
@@ -251,7 +251,7 @@ pq_status pq_apo_ppo(pq_ctx *ctx, const pq_batch *b, const double *real, int64_t
     ApoPpoOp op{};
     op.a.fast = fast; op.a.slow = slow; op.a.matype = matype; op.b.fast = fast; op.b.slow = slow; op.b.matype = matype;
     InCols<1> in{{real}}; OutCols<2> o{{apo, ppo}};
-    if (Ma2::supports(matype) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
+    if (PQ_FUSE_OK(ctx) && Ma2::supports(matype) && seq_can_lds(ctx, b, op, in, o)) return launch_seq(ctx, b, op, in, o);
     PQ_TRY(pq_apo(ctx, b, real, fast, slow, matype, apo));
     return pq_ppo(ctx, b, real, fast, slow, matype, ppo);
 }

@@ -102,7 +102,8 @@ pq_status pq_midprice(pq_ctx *ctx, const pq_batch *b, const double *high, const 
     // The ROW form rescans the last p valid values per row (walking further back over NULLs): O(p) per row -- taken up to p = 64 (0.1 ms
     // at p = 14; beyond that the O(1)-amortised wave-per-symbol / lane-per-symbol forms below win, and a column of long NULL runs cannot
     // turn the call quadratic)
-    if (p <= 64 && (!ctx->rec || getenv("PQ_MIDPRICE_ROW")) && !getenv("PQ_MIDPRICE_SEQ")) { MidpriceRowOp rop{}; rop.p = p; return launch_row(ctx, b, rop, IN2(high, low), OutColsT<MidpriceRowOp, double>{{out}}); }
+    // (a recording of a SMALL shard takes the ROW form too: there the sequential job is 1.4 ms of a lone wave and the ROW grid is not the tail)
+    if (p <= 64 && (!ctx->rec || ctx->rec_small || getenv("PQ_MIDPRICE_ROW")) && !getenv("PQ_MIDPRICE_SEQ")) { MidpriceRowOp rop{}; rop.p = p; return launch_row(ctx, b, rop, IN2(high, low), OutColsT<MidpriceRowOp, double>{{out}}); }
     { pq_status st; if (wt_midprice(ctx, b, high, low, p, out, &st)) return st; }
     MidpriceOp op{}; op.p = p;
     return launch_seq(ctx, b, op, IN2(high, low), OUT1(out));
@@ -131,7 +132,8 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
         return launch_row(ctx, b, FillNullOp{}, InCols<0>{}, OutColsT<FillNullOp, double>{{out}});
     const double *r0 = real; // the select jobs map nulls to 0.0 themselves (overlap.rs:416-424)
     const bool sma_core = matype != 1 && matype != 2 && matype != 3 && matype != 4 && matype != 5 && matype != 6 && matype != 8;
-    if (sma_core && maxp - minp < 32 && maxp < (1 << 30)) { // every candidate in ONE job: an ordinary (unmasked) output column
+    // (not in a recording of a SMALL shard: there the job's length counts, and blocks of sixteen candidates are two jobs of half the length)
+    if (sma_core && maxp - minp < 32 && maxp < (1 << 30) && (PQ_FUSE_OK(ctx) || maxp - minp < 16)) { // every candidate in ONE job: an ordinary (unmasked) output column
         MavpSma32Op op{}; op.lo = (int)minp; op.hi = (int)maxp; op.minp = (int)minp; op.maxp = (int)maxp;
         InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
         if (seq_can_lds(ctx, b, op, in, o1)) return launch_seq(ctx, b, op, in, o1); // (one job: a plain launch, or one recorded job)

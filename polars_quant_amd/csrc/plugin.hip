@@ -282,6 +282,9 @@ static pq_status plan_layout(pq_ctx *ctx, const pq_series_export *key, int64_t n
 // a flat host column [n] of `elem`-byte values -> a fresh device column in the call's layout (and back)
 static pq_status upload_col(pq_ctx *ctx, const Layout &L, const void *host, size_t elem, void **d) {
     PQ_TRY(pq_malloc(ctx, L.dev_elems() * elem, d));
+    // a pitched panel: the tiled bodies load whole 16-byte tile pieces, i.e. the padding behind every group's rows too -- zeros, not whatever
+    // the allocation held (the results inside the rows never depend on it, but no kernel should consume indeterminate bits)
+    if (L.pitched) PQ_HIP_TRY(hipMemsetAsync(*d, 0, L.dev_elems() * elem, ctx->stream));
     if (L.pitched) return pq_memcpy_h2d_pitched(ctx, *d, (size_t)L.pitch * elem, host, (size_t)L.glen * elem, (size_t)L.glen * elem, (size_t)L.groups);
     return pq_memcpy_h2d(ctx, *d, host, (size_t)L.n * elem);
 }

@@ -30,10 +30,15 @@ struct pq_ctx {
     size_t ws_bytes;
     int64_t *d_flag; // 8 x int64 device scalars: [0] reductions, [4..6] statistics of the wave-per-symbol backtest
     Recorder *rec;   // non-null while a suite is being recorded
+    // the suite being recorded covers a SMALL shard (suite.hip small_shard: few 64-series tiles, e.g. 625 symbols = one rank's share of
+    // 5 000 on 8 GPUs): every job is then a handful of lone wavefronts bound by their own instruction stream, the chip is mostly idle,
+    // and what shortens the step is the LENGTH of the longest job, not bytes -- the multi-output forms record their members as separate
+    // jobs, MAVP its candidate periods in blocks of 16, MIDPRICE its row-parallel form, the Hilbert job its time-split form
+    bool rec_small = false;
     void *comm;      // ncclComm_t of pq_comm_init (comm.hip), or null
     int comm_rank, comm_world;
     // the communicator's own stream + one event pair per slot: pq_gather_summaries_begin / _end run the exchange of step k beside the
-    // kernels of step k + 1 (comm.hip); created by pq_comm_init, destroyed by pq_comm_destroy
+    // kernels of step k + 1 (comm.hip); the stream is created lazily by the first pq_gather_summaries_begin (comm_stream_make), destroyed by pq_comm_destroy
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ev_in[2] = {nullptr, nullptr}, comm_ev_done[2] = {nullptr, nullptr};
     bool comm_pending[2] = {false, false};
@@ -56,6 +61,8 @@ double *pq_ws_col(pq_ctx *ctx, const pq_batch *b, int k);
     double *var = pq_ws_col(ctx, b, k);                                                            \
     if (!var) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; }
 pq_status pq_check(pq_ctx *ctx, const pq_batch *b);
+pq_status ctx_gate(pq_ctx *ctx, size_t tiles, unsigned **gate); // runtime.hip: the context's tile flags of gated direct launches
+void *rec_alloc_zero(pq_ctx *ctx, size_t bytes);                // suite.hip: zeroed device memory owned by the suite being recorded
 
 #define PQ_HIP_TRY(expr)                                                                         \
     do {                                                                                         \
@@ -503,6 +510,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     constexpr int NI = K / 2;       // register pairs per lane and column tile = 16-byte accesses (UNAL: each pair holds two 8-byte accesses)
     constexpr int EB = UNAL ? 8 : 16;
     constexpr bool MASKED = SeqTile<Op>::DIRECT; // per-lane stores by wave 0 (row-masked outputs)
+    // the store replica (an A/B build, experiments.h PQ_EXP_STOREONLY): the step's grids, addresses, piece sizes and store policy with the
+    // compute wave gone -- no loads, no LDS traffic, no barriers; what the write pattern alone costs
+    constexpr bool SO = PQ_EXP_STOREONLY_ON && !MJ && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value && !UNAL;
     static_assert(NTap<Op>::value == 0 || HasRings<Op>::value, "an op with lag taps needs a ring variant for the LDS body");
     static_assert(!MJ || (!UNAL && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value), "multi-job workgroups: aligned, tile-output ops without an epilogue");
     const int lane = threadIdx.x & 63, wave = MJ ? 0 : (int)(threadIdx.x >> 6);
@@ -610,7 +620,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     for (int a = 0; a < 2; a++) {
                         if (it + a < nt) {
                             double2 v[R > 0 ? R : 1][NI];
-                            __builtin_amdgcn_s_barrier(); // A: out tile `it + a` is complete
+                            PQ_HOOK_STORER_BARRIER(); // A: out tile `it + a` is complete
                             lds_fence();
                             if (half == a) {
 #pragma unroll
@@ -620,7 +630,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                                     for (int i = 0; i < 8; i++) {
                                         const double *q = reinterpret_cast<const double *>(pr_row + i * 8 * ROWB + kk * TB);
-                                        w[k][i] = make_double2(q[0], q[1]);
+                                        w[k][i] = PQ_HOOK_STORER_PULL(q, kk, i);
                                     }
                                 }
                             }
@@ -631,11 +641,11 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                                 for (int i = 0; i < NI; i++) {
                                     const double *q = reinterpret_cast<const double *>(co_row(i) + kk * TB);
-                                    v[k][i] = make_double2(q[0], q[1]);
+                                    v[k][i] = PQ_HOOK_STORER_PULL(q, kk, i);
                                 }
                             }
                             lds_fence();
-                            __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
+                            PQ_HOOK_STORER_BARRIER(); // B: LDS may be overwritten
                             const int64_t t0 = (it + a) * K;
 #pragma unroll
                             for (int k = 0; k < R; k++) {
@@ -670,16 +680,16 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
 #pragma unroll
                 for (int a = 0; a < ACC; a++) {
                     if (it + a < nt) {
-                        __builtin_amdgcn_s_barrier(); // A: out tile `it + a` is complete
+                        PQ_HOOK_STORER_BARRIER(); // A: out tile `it + a` is complete
                         lds_fence();
                         if (NS == 1 || si == 0) { // (this per-tile form is not split over storers: a second one only keeps the barriers company)
 #pragma unroll
                         for (int k = 0; k < NOUT; k++)
 #pragma unroll
-                            for (int i = 0; i < NI; i++) v[a][k][i] = l_get(i, k * TB);
+                            for (int i = 0; i < NI; i++) v[a][k][i] = PQ_HOOK_STORER_PULL_G(l_get(i, k * TB), k, i);
                         }
                         lds_fence();
-                        __builtin_amdgcn_s_barrier(); // B: LDS may be overwritten
+                        PQ_HOOK_STORER_BARRIER(); // B: LDS may be overwritten
                     }
                 }
                 if (NS > 1 && si != 0) continue;
@@ -715,6 +725,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         return;
     }
     // -------------------------------------------------------------------------------- loader + compute
+    if constexpr (SO) return; // the store replica: storer waves only
     const int64_t s = tile_s0 + lane;
     const bool live = s < d.n;
     const int64_t srow = live ? s : d.n - 1; // dead lanes shadow the last series (never stored)
@@ -931,6 +942,8 @@ struct RowThunk { // type-erased ROW launch for replay
 pq_status rec_add_row(pq_ctx *ctx, const RowThunk &t);
 void rec_set_shared_out(pq_ctx *ctx, bool on); // jobs recorded while on may write disjoint rows of one column
 // Records the enclosed calls into a suite and runs it once at finish(); a no-op inside an outer recording.
+// PQ_FUSE_OK(ctx): record / launch a multi-output form as ONE job (shared input tiles: what pays on a full chip)
+#define PQ_FUSE_OK(ctx) (!((ctx)->rec && (ctx)->rec_small))
 struct SuiteScope {
     pq_ctx *ctx;
     bool owner;

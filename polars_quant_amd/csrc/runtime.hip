@@ -112,6 +112,22 @@ extern "C" pq_status pq_ragged_rehouse_stats(pq_ctx *ctx, int64_t *calls, int32_
     return PQ_OK;
 }
 
+// the context's tile flags for DIRECT launches of a fast form with a gated general path behind it (ops_wt.h, misc.hip): all zero
+// between launches -- the gated kernel clears what it consumes, in stream order
+pq_status ctx_gate(pq_ctx *ctx, size_t tiles, unsigned **gate) {
+    if (ctx->wt_gate_tiles < tiles) {
+        PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->wt_gate) (void)hipFree(ctx->wt_gate);
+        ctx->wt_gate = nullptr; ctx->wt_gate_tiles = 0;
+        if (hipMalloc((void **)&ctx->wt_gate, tiles * sizeof(unsigned)) != hipSuccess || hipMemset(ctx->wt_gate, 0, tiles * sizeof(unsigned)) != hipSuccess) {
+            pq_set_error("out of device memory for a gate");
+            return PQ_ERR_NOMEM;
+        }
+        ctx->wt_gate_tiles = tiles;
+    }
+    *gate = ctx->wt_gate;
+    return PQ_OK;
+}
 pq_status pq_ws_reserve(pq_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return PQ_OK;
     // grow-only; earlier launches may still read the old block -> drain the stream before freeing it

@@ -197,6 +197,15 @@ __global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_WIDE_B
 #endif
 #endif
 
+// A recording covers a SMALL shard when one job is at most cus / 8 workgroups (32 tiles = 2 048 series on MI355X): with the ~40 jobs of
+// an un-fused indicator suite that is at most ~5 workgroups per CU, i.e. at most about one compute wave per SIMD -- every wave then runs
+// at its own instruction rate and the step ends with its longest job.  PQ_SMALL_SHARD_TILES=<n> moves the bound (0: never small).
+static bool small_shard(const pq_ctx *ctx, const pq_batch *b) {
+    if (b->offsets) return false;
+    int64_t bound = (ctx->cus > 0 ? ctx->cus : 256) / 8;
+    if (const char *e = getenv("PQ_SMALL_SHARD_TILES")) bound = atoll(e);
+    return (b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK <= bound;
+}
 static int phase_for(Recorder &r, const void *const *reads, int nr, void *const *writes, int nw) {
     int ph = 0;
     for (int i = 0; i < nr; i++) {
@@ -742,6 +751,7 @@ SuiteScope::SuiteScope(pq_ctx *c, const pq_batch *b) : ctx(c), owner(false), sta
     pq_suite *s = new pq_suite();
     s->rec.b = *b;
     ctx->rec = &s->rec;
+    ctx->rec_small = small_shard(ctx, b);
     owner = true;
 }
 SuiteScope::~SuiteScope() {
@@ -772,6 +782,7 @@ pq_status pq_suite_begin(pq_ctx *ctx, const pq_batch *b) {
     pq_suite *s = new pq_suite();
     s->rec.b = *b;
     ctx->rec = &s->rec;
+    ctx->rec_small = small_shard(ctx, b);
     return PQ_OK;
 }
 pq_status pq_suite_end(pq_ctx *ctx, pq_suite **out) {

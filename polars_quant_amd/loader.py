@@ -183,6 +183,10 @@ class DeviceFrame:
                 a = host.columns[c]
                 if a.shape != (n, T):
                     raise ValueError(f"column {c}: host shape {a.shape}, device shape {(n, T)}")
+                col = self.columns[c]
+                if tuple(col.shape) != (n, T) or (T > 1 and col.stride(1) != 1) or (n > 1 and col.stride(0) != self.stride):
+                    # (a pitched copy into a buffer of another pitch writes past its rows)
+                    raise ValueError(f"column {c}: device column has a row pitch of {col.stride(0)} elements, the frame's is {self.stride}")
                 check(lib().pq_memcpy_h2d_pitched(h, C.c_void_p(self.columns[c].data_ptr()), self.stride * 8, a.ctypes.data_as(C.c_void_p), T * 8,
                                                   T * 8, n))
                 ev = self.events.get(c) or torch.cuda.Event()

@@ -181,13 +181,23 @@ class Suite:
                 buf = self._housed[k] = torch.zeros((self.n, self.stride), dtype=torch.float64, device=self.dev)
             buf[:, :self.T].copy_(t)
             out[k] = buf[:, :self.T]
+        self._stale_warned = False
         return out
+
+    def _needs_housing(self, ohlcv: dict) -> list:
+        """the columns of `ohlcv` that record() would copy instead of using in place"""
+        if self.exact_layout:
+            return []
+        return [k for k, t in ohlcv.items()
+                if not (t.dim() == 2 and tuple(t.shape) == (self.n, self.T) and t.dtype == torch.float64 and t.device == self.dev and
+                        (self.T <= 1 or t.stride(1) == 1) and (self.n <= 1 or t.stride(0) == self.stride) and t.data_ptr() % 16 == 0)]
 
     house = _house
 
     def refresh_inputs(self, ohlcv: dict) -> None:
-        """after the caller changed input columns that record() had to re-house: copy them again (same buffers, no re-recording)"""
-        self._house(ohlcv)
+        """after the caller changed input columns that record() had to re-house: copy them again (same buffers, no re-recording).
+        run(ohlcv) does this itself; run() without tensors replays on the copies as they are."""
+        self._house({k: t for k, t in ohlcv.items() if k in self._housed})
 
     def record(self, ohlcv: dict, tasks=None, summaries=None) -> None:
         """record the step once (pq_suite_begin/end): the sequential jobs of all functions become one grid per phase.
@@ -198,7 +208,7 @@ class Suite:
         L, h = lib(), ctx(self.dev.index)
         ohlcv = self._house(ohlcv)
         self._ohlcv = ohlcv  # keep the inputs alive: the suite holds raw device pointers
-        handles, keep = [], self.summary
+        handles, keep, ok = [], self.summary, False
         try:
             for summ in (summaries or [self.summary]):
                 assert summ.shape == (self.n, 8) and summ.dtype == torch.float64 and summ.is_contiguous()
@@ -214,8 +224,14 @@ class Suite:
                     out = C.c_void_p()
                     check(L.pq_suite_end(h, C.byref(out)))
                 handles.append(out)
+            ok = True
         finally:
-            self.summary = summaries[0] if summaries else keep
+            if ok:
+                self.summary = summaries[0] if summaries else keep
+            else:   # a later recording failed: the earlier handles (job tables, events) must not leak, the object keeps its old table
+                self.summary = keep
+                for hnd in handles:
+                    L.pq_suite_destroy(h, hnd)
         self._summaries = list(summaries) if summaries else [self.summary]
         self._suites = handles
         self._suite = handles[0]
@@ -238,9 +254,14 @@ class Suite:
 
     def record_staged(self, ohlcv: dict) -> list:
         """one recorded suite per prefix of STAGE_ORDER that completes some task's inputs -> [(columns needed, n tasks)]"""
+        # The staged step waits for the upload events of the buffers it READS: a column that had to be re-housed would be read from
+        # the suite's copy while the events speak of the caller's tensor.  Upload into the suite's own layout instead
+        # (DeviceFrame(columns=suite.house(cols), stride=suite.stride), as bench.py --e2e does).
+        slow = self._needs_housing(ohlcv)
+        if slow:
+            raise ValueError(f"record_staged: columns {slow} are not on the suite's row pitch ({self.stride} elements): pass suite.house(columns)")
         self.close()
         L, h = lib(), ctx(self.dev.index)
-        ohlcv = self._house(ohlcv)
         self._ohlcv = ohlcv
         stages, have, left = [], set(), list(self.tasks(fused=True))
         for col in self.STAGE_ORDER:
@@ -314,6 +335,17 @@ class Suite:
         (slot: which of the recordings of record(summaries=[...]) to replay)"""
         if getattr(self, "_suite", None) is None:
             self.record(ohlcv)
+        elif self._housed:
+            # the recording reads suite-owned copies of the columns that were handed over at a slow row pitch: tensors passed here are
+            # copied into them again (current stream); without tensors the step replays on the copies as they are -- said once
+            if ohlcv is not None:
+                self.refresh_inputs(ohlcv)
+            elif not getattr(self, "_stale_warned", True):
+                import warnings
+                from .api import PqLayoutWarning
+                self._stale_warned = True
+                warnings.warn(f"Suite.run(): columns {sorted(self._housed)} were re-housed at record time; this replay reads those copies, not the "
+                              f"caller's tensors -- pass the tensors to run() or call refresh_inputs() after changing them", PqLayoutWarning, stacklevel=2)
         with torch.cuda.device(self.dev):
             check(lib().pq_suite_run(ctx(self.dev.index), self._suites[slot]))
 

@@ -14,8 +14,8 @@ cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats
 # 2. HBM traffic counters, one pass each
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > /dev/null 2> "$OUT/pmc_write.err"
-( cd "$R" && python scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r05" 23 > "$OUT/pmc_summary.txt" )
-cp "$OUT/r05_pmc_traffic.json" "$R/profiles/r05_pmc_traffic.json"   # (on the box: the bench runs below quote it; it carries this build's source hash)
+( cd "$R" && python scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r06" 23 > "$OUT/pmc_summary.txt" )
+cp "$OUT/r06_pmc_traffic.json" "$R/profiles/r06_pmc_traffic.json"   # (on the box: the bench runs below quote it; it carries this build's source hash)
 # 3. workgroup residency of one step (device timestamps)
 ( cd "$R" && PQ_SUITE_DEBUG=2 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/wg.log" 2>&1; python scripts/wg_residency.py "$OUT/wg.log" > "$OUT/wg_residency.txt" )
 # 4. the plain bench line (with the CPU baseline) for reference, the end-to-end figures, the backtest alone on shards (strong scaling

@@ -1,0 +1,35 @@
+"""ms per recorded suite step on a shard of n symbols (the bench's suite, nothing else): python scripts/step_time.py 625 [1250 ...]
+Environment switches of the library / of Suite apply (PQ_SUITE_UNFUSE, PQ_WT_SUITE, PQ_LIB_PATH, PQ_SMALL_SHARD ...).  One line per size."""
+import sys
+
+sys.path.insert(0, ".")
+import torch
+
+from polars_quant_amd.suite import Suite
+from polars_quant_amd.synthetic import gen_ohlcv
+
+T = 2520
+PITCH = (T + 15) // 16 * 16
+sizes = [int(a) for a in sys.argv[1:]] or [625]
+full = gen_ohlcv(0x5EED0002, max(sizes), T, 0)
+for n in sizes:
+    g = {}
+    for k, v in full.items():
+        buf = torch.zeros((n, PITCH), dtype=torch.float64, device="cuda")
+        buf[:, :T] = torch.from_numpy(v[:n].copy()).cuda()
+        g[k] = buf[:, :T]
+    st = Suite(n, T, "cuda", stride=PITCH)
+    st.record(g)
+    for _ in range(5):
+        st.run()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            st.run()
+        e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20)
+    print(f"n={n} ms_per_step={best:.4f} info={st.info()}", flush=True)
+    st.close()

@@ -17,7 +17,7 @@ def test_pmc_traffic_file_was_collected_on_these_kernel_sources():
     if not PMC_FILE.exists():
         pytest.skip(f"{PMC_FILE.name}: this round's counters are not collected yet (bench.py then prints traffic: null)")
     pm = json.loads(PMC_FILE.read_text())
-    assert pm["source_hash"] == source_hash(), "re-run scripts/collect_profiles.sh on the GPU box and copy gpurun_out/prof/* to profiles/r05_*"
+    assert pm["source_hash"] == source_hash(), "re-run scripts/collect_profiles.sh on the GPU box and copy gpurun_out/prof/* to profiles/<ROUND>_*"
     assert pm["launches_per_step"].get("seq_jobs_kernel<0>") == 2 and "cdl_all_kernel<true, true>" in pm["kernels"]
     step = sum(v["hbm_bytes_per_launch"] * pm["launches_per_step"].get(k, 1) for k, v in pm["kernels"].items() if not k.startswith(("at::", "__amd")))
     assert 14.5e9 < step < 16e9, step      # the step moves ~15.1 GB
