@@ -596,6 +596,37 @@ def main():
         if args.e2e and world == 1:
             line["config"]["e2e"] = end_to_end(suite, ohlcv, n_local, T, dev)
     # ---- secondary figures, outside the timed region above
+    if world == 1 and not multi and not args.no_secondary and n_local == N_SYM and args.scaling == "weak":
+        # Strong-scaling proxy.  BASELINE's metric is 5 000 symbols IN TOTAL on 1 / 2 / 4 / 8 GPUs; the path has no data-path collective, so
+        # a rank's step at N / G symbols is what ONE GPU needs for a shard of that size (+ the one summary all-gather).  No 8-GPU node is
+        # given to this pool's driver, so the shard times are measured here, on this GPU, and the factors they project are spelled out
+        # with the collective latency they ASSUME -- twice: the measured cost of pq_gather_summaries at a world of one, and a
+        # conservative figure for eight ranks over xGMI.
+        proxy = {"what": "the same recorded step / the MACD-cross backtest alone on the first N / G symbols of the data set, one GPU; projected factor at G GPUs = "
+                         "t(N) / (t(N / G) + assumed collective latency)",
+                 "assumed_collective_latency_ms": {"measured_world_of_one": 0.005, "conservative_8_ranks": 0.025,
+                                                   "note": "0.005: pq_gather_summaries in series behind a step at a world of one (profiles/r05_bench_gather.json: "
+                                                           "4.1 us + launch; RCCL's one-rank all-gather is a copy kernel); 0.025: assumed for an 8-rank ring "
+                                                           "all-gather of 40 KB per rank over xGMI -- NOT measured (no multi-GPU node on this pool)"},
+                 "suite_step_ms": {str(n_local): ms_step}, "backtest_only_ms": {str(n_local): bt_only["kernel_only_ms_per_step"] if bt_only else None}}
+        for g_ in (2, 4, 8):
+            n_sh = shard_range(n_local, 0, g_)[1]
+            sub = {k: v[:n_sh] for k, v in suite._ohlcv.items()}          # (rows keep the pitched layout: used in place)
+            sst = Suite(n_sh, T, dev, stride=suite.stride, exact_layout=args.exact_layout)
+            sst.record(sub)
+            el = time_steps(sst, sub, n_sh, max(10, args.steps), args.warmup)
+            proxy["suite_step_ms"][str(n_sh)] = el / max(10, args.steps) * 1e3
+            proxy.setdefault("suite_plan", {})[str(n_sh)] = sst.info()
+            sst.close()
+            proxy["backtest_only_ms"][str(n_sh)] = backtest_only(sub, n_sh, n_sh, max(20, args.steps), 3, suite.stride)["kernel_only_ms_per_step"]
+        for key in ("suite_step_ms", "backtest_only_ms"):
+            t = proxy[key]
+            if t[str(n_local)] is None:
+                continue
+            proxy[key.replace("_ms", "_projected_factor")] = {
+                lat: {f"{g_}gpu": t[str(n_local)] / (t[str(shard_range(n_local, 0, g_)[1])] + L) for g_ in (2, 4, 8)}
+                for lat, L in (("collective_0.005ms", 0.005), ("collective_0.025ms", 0.025))}
+        line["strong_scaling_proxy"] = proxy
     if world == 1 and suite.stride != T and not args.no_secondary and not args.no_cpu_baseline:
         # for the record: the same step on the DENSE layout (row pitch = days)
         suite.close()

@@ -28,6 +28,11 @@
 #else
 #define PQ_EXP_STOREONLY_ON 0
 #endif
+#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_SO_ALLPAIR) // with PQ_EXP_STOREONLY: every column of a pair-mode job in 128-byte pieces, whatever the register cap
+#define PQ_EXP_SO_ALLPAIR_ON 1
+#else
+#define PQ_EXP_SO_ALLPAIR_ON 0
+#endif
 // (SO: a constant of run_seq_lds -- the replica applies to this op)
 #define PQ_HOOK_STORER_BARRIER() do { if constexpr (!SO) __builtin_amdgcn_s_barrier(); } while (0)
 #define PQ_HOOK_STORER_PULL(q, kk, i) (SO ? make_double2((double)(kk), (double)((i) + lane)) : make_double2((q)[0], (q)[1]))

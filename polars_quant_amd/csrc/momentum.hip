@@ -136,6 +136,10 @@ pq_status pq_adxr_chain(pq_ctx *ctx, const pq_batch *b, const double *h, const d
     AdxrOp op{}; op.p = p;
     return launch_row(ctx, b, op, InCols<1>{{adx}}, OutColsT<AdxrOp, double>{{out}});
 }
+pq_status pq_adxr_from_adx(pq_ctx *ctx, const pq_batch *b, const double *adx, int64_t p, double *out) { // the second half of pq_adxr_chain
+    AdxrOp op{}; op.p = p;
+    return launch_row(ctx, b, op, InCols<1>{{adx}}, OutColsT<AdxrOp, double>{{out}});
+}
 pq_status pq_plus_dm(pq_ctx *ctx, const pq_batch *b, const double *h, const double *l, int64_t p, double *out) {
     CHK("pq_plus_dm", h && l && out);
     { pq_status st; if (wt_dm_pair(ctx, b, h, l, p, out, nullptr, &st)) return st; }
@@ -200,7 +204,10 @@ pq_status pq_stochrsi_chain(pq_ctx *ctx, const pq_batch *b, const double *real, 
     CHK("pq_stochrsi", real && outk && outd); // momentum.py:197-205
     WS(8);
     PQ_WS_COL(rsi, ctx, b, 0);
-    PQ_TRY(pq_rsi(ctx, b, real, p, rsi));
+    ctx->chain_head = true; // (a small-shard recording: this RSI is what the rest of the chain waits for)
+    const pq_status st_rsi = pq_rsi(ctx, b, real, p, rsi);
+    ctx->chain_head = false;
+    PQ_TRY(st_rsi);
     FastkOp op{}; op.k = fastk;
     PQ_TRY(launch_row(ctx, b, op, InCols<3>{{rsi, rsi, rsi}}, OutColsT<FastkOp, double>{{outk}}));
     return pq_ma(ctx, b, outk, fastd, fastd_mt, outd);

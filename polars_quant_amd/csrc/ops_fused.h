@@ -619,6 +619,15 @@ struct HtAll6Op : HtAllOp {
     static constexpr int ALG_COLS = 2 + 3 + 2 + 3; // ht_dcperiod, ht_phasor, ht_dcphase, ht_sine
     static constexpr int NDER = 3;
     double *der[3]; // dcphase, sine, leadsine
+    // Recorded for a SMALL shard the job is split in time (pq_ht_all, fused.hip): the Hilbert pipeline forgets its start -- a walk that
+    // begins 640 rows early agrees with the full walk to a few ulp (4e-15 of the value over 2 000 series x 2 starts, the same size as the
+    // device atan's own difference from the host's), and its outputs are tolerance-class (<= 1e-12) to begin with
+    static constexpr bool TS_OK = true;
+    double *chk[3]; // the check columns of a time-split job (dcperiod, inphase, quadrature of its last warm-up tile), else unused
+    __device__ void ts_shift(int64_t row0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { der[k] += row0; chk[k] = chk[k] ? chk[k] + row0 : nullptr; }
+    }
     __device__ static void derive(const double (&y)[3], double (&z)[3]) { ht_phase_sine(y[1], y[2], z); }
 };
 

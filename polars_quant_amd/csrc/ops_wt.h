@@ -141,6 +141,10 @@ __device__ __forceinline__ void wt_updown(const double *x, int i, double &u, dou
 // RSI (= RsiOp; momentum.rs:507-541, calc_rma D-1).  Columns: A = up -> rma(up), B = down -> rma(down).
 struct WtRsiOp {
     static constexpr const char *NAME = "rsi";
+    // recorded for a SMALL shard too where RSI heads a dependency chain (STOCHRSI = RSI -> fast-k -> MA, momentum.py:197-205; pq_ctx::chain_head)
+    // and the shard is at most 12 tiles: 625 symbols run this form in 0.1 - 0.15 ms against 0.55 - 0.85 ms for the lone-wave job the chain
+    // would wait for (1 250 symbols: 0.2 - 0.65 ms, no better than the job)
+    static constexpr bool SMALL_SUITE = true;
     static constexpr int NCOL = 2;
     const double *x;
     double *rsi;
@@ -390,6 +394,10 @@ struct WtBlob {
     unsigned lds_wt, lds_seq;
     int gather; // the gated general path is the per-lane gather body (ragged batches)
 };
+template <class Op, class = void>
+struct WtSmallSuite { static constexpr bool value = false; };
+template <class Op>
+struct WtSmallSuite<Op, decltype((void)Op::SMALL_SUITE)> { static constexpr bool value = Op::SMALL_SUITE; };
 template <class WtOp, class SeqOp>
 static void wt_launch_blob(const void *blob, hipStream_t stream) {
     const WtBlob<WtOp, SeqOp> &w = *reinterpret_cast<const WtBlob<WtOp, SeqOp> *>(blob);
@@ -414,7 +422,9 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
     // Inside a recorded suite the lane-per-symbol jobs win: many functions over thousands of symbols fill the chip by themselves, and a
     // wave-per-symbol job holds 21 KB of LDS per column and symbol (measured at 5 000 x 2 520: the step takes 6.6 ms with these
     // kernels recorded in place of their jobs against 4.0 ms).  PQ_WT_SUITE=1 records them anyway (A/B runs).
-    if (ctx->rec && !getenv("PQ_WT_SUITE")) return false;
+    if (ctx->rec && !getenv("PQ_WT_SUITE") &&
+        !(ctx->rec_small && ctx->chain_head && WtSmallSuite<WtOp>::value && b->n_series <= 12 * SEQ_BLOCK && !getenv("PQ_NO_WT_SMALL")))
+        return false;
     if (!wt_on() || !wt_op_on(WtOp::NAME) || b->len > WT_MAX_LEN || b->n_series <= 0 || b->n_series > 0x7fffffffLL) return false;
     const bool ragged = b->offsets != nullptr;
     if (ragged) {

@@ -35,6 +35,8 @@ struct pq_ctx {
     // and what shortens the step is the LENGTH of the longest job, not bytes -- the multi-output forms record their members as separate
     // jobs, MAVP its candidate periods in blocks of 16, MIDPRICE its row-parallel form, the Hilbert job its time-split form
     bool rec_small = false;
+    bool chain_head = false; // set by a composite around the call that heads its dependency chain (pq_stochrsi_chain: its RSI): a small-shard
+                             // recording then takes the call's fastest form even where that form does not pay for a call nobody waits for
     void *comm;      // ncclComm_t of pq_comm_init (comm.hip), or null
     int comm_rank, comm_world;
     // the communicator's own stream + one event pair per slot: pq_gather_summaries_begin / _end run the exchange of step k beside the
@@ -127,6 +129,15 @@ template <class Op, class = void>
 struct NDer { static constexpr int value = 0; };
 template <class Op>
 struct NDer<Op, decltype((void)Op::NDER)> { static constexpr int value = Op::NDER; };
+// Time-split jobs (small shards, fused.hip pq_ht_all): an op with `static constexpr bool TS_OK = true; double *chk[NOUT];` may be recorded
+// as several jobs over row ranges of the same series -- each a plain job on columns offset to its first row (so the op sees a series that
+// starts there), told to keep its first `skip` tiles to itself: the warm-up of a chunk that starts W rows early.  Of those, only the LAST
+// tile leaves the workgroup, into the op's `chk` columns (same layout as the outputs): the hand-over check compares it with what the
+// previous chunk wrote for the same rows.
+template <class Op, class = void>
+struct TsOk { static constexpr bool value = false; };
+template <class Op>
+struct TsOk<Op, decltype((void)Op::TS_OK)> { static constexpr bool value = Op::TS_OK; };
 template <class Op, class = void>
 struct HasFinish { static constexpr bool value = false; }; // void finish(double *const *outp, const Dims &, int64_t s): per-series epilogue
 template <class Op>
@@ -502,7 +513,7 @@ constexpr unsigned MJ_SPIN_LIMIT = 1u << 22; // polls before a waiting wave give
 // by its store stream, so its columns are dealt out to two storers: storer s takes the columns s, s + 2, ...).
 template <class Op, bool UNAL = false, bool MJ = false, bool LENS = false, int NS = 1>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
-                                            int64_t tile_s0, unsigned char *lds, MjCtl *ctl = nullptr, unsigned *mj_err = nullptr) {
+                                            int64_t tile_s0, unsigned char *lds, MjCtl *ctl = nullptr, unsigned *mj_err = nullptr, int skip = 0) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
     constexpr int TB = SeqTile<Op>::TILE_BYTES;
     constexpr int CPL = UNAL ? K : K / 2; // lanes per series segment: 16-byte chunks (UNAL: 8-byte elements)
@@ -517,6 +528,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     static_assert(!MJ || (!UNAL && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value), "multi-job workgroups: aligned, tile-output ops without an epilogue");
     const int lane = threadIdx.x & 63, wave = MJ ? 0 : (int)(threadIdx.x >> 6);
     const int64_t T = d.len, nt = T / K;
+    const int64_t it_first = (TsOk<Op>::value && skip > 0) ? skip - 1 : 0; // the first tile that is handed to the storer (wave-uniform; 0 unless time-split)
     const int csym = lane / CPL, cchunk = lane % CPL;
     // Global addresses of the cooperative tile accesses: a wave-uniform 64-bit base (column + first series of the tile + first row of
     // the tile: scalar arithmetic) plus a 32-bit BYTE offset per lane -- the global_load / global_store form with a scalar base and a
@@ -611,9 +623,10 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 // (this storer's j-th column is column kk = j * NS + si of the job; with one storer kk = j)
                 constexpr int CAP = IsHeavy<Op>::value ? 208 : PQ_PAIR_CAP;
                 constexpr int W0 = (CAP - NOS * NI * 4) / (NI * 4);
-                constexpr int W = W0 < 0 ? 0 : (W0 > NOS ? NOS : W0), R = NOS - W;
+                constexpr int W = (SO && PQ_EXP_SO_ALLPAIR_ON) ? NOS : (W0 < 0 ? 0 : (W0 > NOS ? NOS : W0)), R = NOS - W; // (replica variant: every column in 128-byte pieces)
                 const int half = (lane >> 2) & 1, sub = lane >> 3;
                 const unsigned char *pr_row = lds + sub * ROWB + (lane & 3) * 16;
+                static_assert(!TsOk<Op>::value, "a time-split op stores per tile: its check tile and its first own tile go to different columns");
                 for (int64_t it = 0; it < nt; it += 2) {
                     double2 w[W > 0 ? W : 1][8];
 #pragma unroll
@@ -675,7 +688,8 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
             // (an op with derived columns takes this per-tile form: the 64-bit constants of derive() -- ~80 registers for an atan -- leave
             //  no room for the two held tiles of pair mode under the 192-VGPR cap; its columns go out in 64-byte pieces)
             constexpr int ACC = (NOUT * NI * 4 * PQ_STORER_ACC <= 136 && NDer<Op>::value == 0) ? PQ_STORER_ACC : 1; // registers of the (otherwise idle) storer wave
-            for (int64_t it = 0; it < nt; it += ACC) {
+            static_assert(!TsOk<Op>::value || ACC == 1, "a time-split op stores tile by tile");
+            for (int64_t it = it_first; it < nt; it += ACC) {
                 double2 v[ACC][NOUT][NI];
 #pragma unroll
                 for (int a = 0; a < ACC; a++) {
@@ -694,13 +708,19 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 }
                 if (NS > 1 && si != 0) continue;
                 const int64_t t0 = it * K;
+                bool check_tile = false; // time-split: the last warm-up tile goes to the op's check columns, nothing is derived from it
+                if constexpr (TsOk<Op>::value) check_tile = it < skip;
 #pragma unroll
-                for (int k = 0; k < NOUT; k++)
+                for (int k = 0; k < NOUT; k++) {
+                    double *oc = outp[k];
+                    if constexpr (TsOk<Op>::value) oc = check_tile ? op.chk[k] : oc;
 #pragma unroll
                     for (int i = 0; i < NI; i++)
 #pragma unroll
                         for (int a = 0; a < ACC; a++)
-                            if (it + a < nt) g_store(outp[k], i, t0 + a * K, v[a][k][i]);
+                            if (it + a < nt) g_store(oc, i, t0 + a * K, v[a][k][i]);
+                }
+                if (check_tile) continue;
                 if constexpr (NDer<Op>::value > 0) { // derived columns from the two rows per access this lane holds
                     constexpr int ND = NDer<Op>::value;
 #pragma unroll
@@ -792,7 +812,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 }
                 lds_fence();
                 PQ_PROF_T(f2);
-                hand_off(t0);
+                if (it >= it_first) hand_off(t0);
                 PQ_PROF_T(f3);
                 PQ_PROF_ADD(0, c1 - c0); PQ_PROF_ADD(1, f2 - c1); PQ_PROF_ADD(2, f3 - f2); PQ_PROF_ADD(3, 1);
                 return;
@@ -825,7 +845,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
         }
         lds_fence();
         PQ_PROF_T(c2);
-        hand_off(t0);
+        if (it >= it_first) hand_off(t0);
         PQ_PROF_T(c3);
         PQ_PROF_ADD(0, c1 - c0); PQ_PROF_ADD(1, c2 - c1); PQ_PROF_ADD(2, c3 - c2); PQ_PROF_ADD(3, 1);
     };
@@ -921,6 +941,8 @@ struct SeqTraits { // what the scheduler needs to know about a recorded job
     const void *extra_reads[4];      // columns read outside the tile path (signal / benchmark columns): ordering hazards only
     bool unal = false;               // the tiled body in its 8-byte form (rows not 16-byte aligned)
     int tile_k = 0;                  // SeqTile<Op>::K
+    int ts_len = 0, ts_skip = 0, ts_row0 = 0; // a time-split job (TsOk): rows of its range, leading tiles it keeps to itself, its first row
+    double alg_frac = 1.0;           // share of the op's algorithmic bytes this job is credited with (a time-split job: its own rows)
 };
 template <class Op, class = void>
 struct HasExtraReads { static constexpr bool value = false; };

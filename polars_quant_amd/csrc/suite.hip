@@ -98,6 +98,13 @@ struct Phase {
     unsigned mj_lds = 0;
     unsigned *d_mj_err = nullptr;
     bool wide = false; // class HEAVY holds light jobs with many output columns and runs seq_jobs_kernel<4> (two storers per workgroup)
+    // small-shard schedule (Recorder::small): what chain c of this phase waits for -- (phase, chain) pairs of earlier phases whose launches
+    // wrote a column it touches or read a column it writes -- and the event recorded behind its launches
+    std::vector<std::pair<int, int>> deps[NCHAIN];
+    hipEvent_t ev_done[NCHAIN] = {};
+    bool work[NCHAIN] = {};
+    int chain_of[NCLS] = {0, 1, 2, 3}; // small-shard schedule: the chain (stream) the grid of class c runs on in this phase
+    int row_chain = ROW_CHAIN;         // ... and the chain of its ROW launches
 };
 struct Recorder {
     pq_batch b;
@@ -107,6 +114,8 @@ struct Recorder {
     std::map<const void *, int> writer_phase, reader_phase;
     std::vector<void *> scratch;
     bool shared_out = false;
+    bool small = false; // the recording covers a small shard (small_shard): chains ordered by data dependencies instead of phase barriers
+    std::set<const void *> feeds_seq; // small: columns that a sequential job of a LATER phase reads, directly or through ROW launches
     bool timing = false;
     static constexpr int MAX_TIMED_RUNS = 64;
 };
@@ -114,6 +123,26 @@ struct pq_suite {
     Recorder rec;
 };
 
+// the tiled body of one job of the light kernel; an op that may be split in time (pq_dev.h TsOk) walks the row range of its job
+template <class OP, bool TS = TsOk<OP>::value>
+struct TiledJob {
+    __device__ static __forceinline__ void run(OP &op, const SeqJob &job, const Dims &d, int64_t s0, unsigned char *lds) { run_seq_lds<OP, false>(op, job.in, job.out, d, s0, lds); }
+};
+template <class OP>
+struct TiledJob<OP, true> {
+    __device__ static __forceinline__ void run(OP &op, const SeqJob &job, const Dims &d, int64_t s0, unsigned char *lds) {
+        Dims dj = d;
+        if (job.ts_len) dj.len = job.ts_len;
+        const double *inj[OP::NIN];
+        double *outj[OP::NOUT];
+#pragma unroll
+        for (int k = 0; k < OP::NIN; k++) inj[k] = job.in[k] + job.ts_row0;
+#pragma unroll
+        for (int k = 0; k < OP::NOUT; k++) outj[k] = job.out[k] + job.ts_row0;
+        op.ts_shift(job.ts_row0);
+        run_seq_lds<OP, false>(op, inj, outj, dj, s0, lds, nullptr, nullptr, job.ts_skip);
+    }
+};
 template <int V>
 __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     extern __shared__ __align__(16) unsigned char jobs_lds[];
@@ -137,6 +166,7 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
         __builtin_memcpy(&op, job.op, sizeof(OP));                                                                   \
         if constexpr (V == 2) run_seq(op, job.in, job.out, d, s);                                                    \
         else if constexpr (V == 4) run_seq_lds<OP, false, false, false, 2>(op, job.in, job.out, d, s0, jobs_lds);    \
+        else if constexpr (V == 0) TiledJob<OP>::run(op, job, d, s0, jobs_lds);                                      \
         else                                                                                                         \
             run_seq_lds<OP, V == 3>(op, job.in, job.out, d, s0, jobs_lds); \
     } break;
@@ -254,6 +284,7 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
     j.unal = tr.unal ? 1 : 0;
     j.tile_k = tr.tile_k;
     j.alg_cols = tr.alg_cols > 0 ? tr.alg_cols : nin + nout;
+    j.ts_len = tr.ts_len; j.ts_skip = tr.ts_skip; j.ts_row0 = tr.ts_row0; j.alg_frac = (float)tr.alg_frac;
     j.summary_bytes = tr.summary_bytes_per_series;
     for (int k = 0; k < nin; k++) j.in[k] = in[k];
     for (int k = 0; k < nout; k++) j.out[k] = out[k];
@@ -261,6 +292,7 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
     void *writes[12];
     for (int k = 0; k < nout; k++) writes[k] = out[k];
     for (int k = 0; k < 4; k++) writes[nout + k] = extra_writes ? extra_writes[k] : nullptr; // e.g. a summary table, derived columns: hazard tracking only
+    for (int k = 0; k < 4; k++) { j.xr[k] = tr.extra_reads[k]; j.xw[k] = extra_writes ? extra_writes[k] : nullptr; }
     const void *reads[10];
     int nr = 0;
     for (int k = 0; k < nin; k++) reads[nr++] = in[k];
@@ -281,6 +313,7 @@ pq_status rec_add_backtest(pq_ctx *ctx, const pq_batch *b, int kind, const BtArg
     void *writes[4] = {a.position, a.cash, a.equity, a.summary};
     const void *rd[4]; int nr = 0;
     for (int i = 0; i < 4; i++) if (reads[i]) rd[nr++] = reads[i];
+    for (int i = 0; i < 4; i++) { j.xr[i] = reads[i]; j.xw[i] = writes[i]; }
     int ph = phase_for(r, rd, nr, writes, 4);
     r.phases[ph].seq.push_back(j);
     return PQ_OK;
@@ -336,7 +369,93 @@ static bool row_fusable(const RowThunk &t, const Dims &d) {
     return t.row_id > 0 && t.blob_bytes <= ROW_FUSE_BLOB && t.dims.n == d.n && t.dims.len == d.len && t.dims.stride == d.stride && t.dims.offs == d.offs;
 }
 
+// Small-shard schedule: which earlier (phase, chain) launches must have finished before chain c of phase q starts -- those that wrote a
+// column it reads or writes, or read a column it writes.  The launches of one phase are independent of each other (phase_for), a chain
+// is a stream (its own earlier phases are ordered before it), and per foreign chain only its latest phase needs a wait.
+static int chain_of_row(const Phase &p, size_t k) { return p.row_late[k] ? p.row_late[k] - 1 : p.row_chain; }
+static void small_deps(Recorder &r) {
+    // Chains.  Phase 0: the LONG grid (jobs nobody waits for) on the caller's stream, the SHORT grid (jobs that feed later phases) on chain
+    // 1, the ROW launches on chain 3.  The job grids of LATER phases run on chain 2 -- idle otherwise (no op is register-heavy): behind
+    // chain 1 they would queue up behind the phase-0 producers they do not all depend on.
+    bool heavy_any = false;
+    for (const Phase &p : r.phases) for (const SeqJob &j : p.seq) heavy_any |= j.cls == CLS_HEAVY;
+    for (size_t q = 0; q < r.phases.size(); q++) {
+        Phase &p = r.phases[q];
+        for (int c = 0; c < NCLS; c++) p.chain_of[c] = c;
+        p.row_chain = ROW_CHAIN;
+        // (the ROW launches of later phases too: they are links of the same dependency chains -- MACD = fast - slow under MACDEXT, fast-k
+        //  of RSI under STOCHRSI -- and must not queue behind the patterns, the backtest and the fused ROW grid of phase 0)
+        if (q > 0 && !heavy_any) { p.chain_of[CLS_SHORT] = CLS_HEAVY; p.row_chain = CLS_HEAVY; }
+        // ROW chain: the launches whose columns a later phase reads go first (they are the heads of dependency chains), the others keep
+        // their recorded order
+        std::vector<size_t> idx(p.rows.size());
+        for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
+        auto feeds = [&](const RowThunk &t) {
+            for (int i = 0; i < t.n_writes; i++) if (r.feeds_seq.count(t.writes[i])) return true;
+            return false;
+        };
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return feeds(p.rows[a]) > feeds(p.rows[b]); });
+        std::vector<RowThunk> rows2; std::vector<char> late2, fused2;
+        for (size_t k : idx) { rows2.push_back(p.rows[k]); late2.push_back(p.row_late[k]); fused2.push_back(p.row_fused[k]); }
+        p.rows.swap(rows2); p.row_late.swap(late2); p.row_fused.swap(fused2);
+    }
+    std::map<const void *, std::vector<std::pair<int, int>>> last_w, readers; // (several jobs of ONE phase may write disjoint rows of a column: MAVP's blocks)
+    for (size_t q = 0; q < r.phases.size(); q++) {
+        Phase &p = r.phases[q];
+        std::set<const void *> R[NCHAIN], W[NCHAIN];
+        for (int c = 0; c < NCHAIN; c++) { p.deps[c].clear(); p.work[c] = false; }
+        for (const SeqJob &j : p.seq) {
+            const int c = p.chain_of[j.cls];
+            p.work[c] = true;
+            for (int k = 0; k < j.nin; k++) R[c].insert(j.in[k]);
+            for (int k = 0; k < j.nout; k++) W[c].insert(j.out[k]);
+            for (int k = 0; k < 4; k++) { if (j.xr[k]) R[c].insert(j.xr[k]); if (j.xw[k]) W[c].insert(j.xw[k]); }
+        }
+        for (size_t k = 0; k < p.rows.size(); k++) {
+            const int c = chain_of_row(p, k);
+            p.work[c] = true;
+            for (int i = 0; i < p.rows[k].n_reads; i++) R[c].insert(p.rows[k].reads[i]);
+            for (int i = 0; i < p.rows[k].n_writes; i++) if (p.rows[k].writes[i]) W[c].insert(p.rows[k].writes[i]);
+        }
+        for (int c = 0; c < NCHAIN; c++) {
+            int latest[NCHAIN];
+            for (int x = 0; x < NCHAIN; x++) latest[x] = -1;
+            auto need = [&](const std::pair<int, int> &d) { if (d.second != c && d.first > latest[d.second]) latest[d.second] = d.first; };
+            for (const void *col : R[c]) { auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d); }
+            for (const void *col : W[c]) {
+                auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d);
+                auto ir = readers.find(col); if (ir != readers.end()) for (const auto &d : ir->second) need(d);
+            }
+            for (int x = 0; x < NCHAIN; x++) if (latest[x] >= 0) p.deps[c].push_back({latest[x], x});
+        }
+        for (int c = 0; c < NCHAIN; c++) {
+            for (const void *col : W[c]) {
+                auto &lw = last_w[col];
+                if (!lw.empty() && lw.front().first != (int)q) lw.clear();
+                lw.push_back({(int)q, c});
+                readers.erase(col);
+            }
+            for (const void *col : R[c]) readers[col].push_back({(int)q, c});
+        }
+    }
+}
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
+    if (r.small) { // columns that feed a sequential job of a later phase: from the last phase back, through the ROW launches
+        r.feeds_seq.clear();
+        for (size_t q = r.phases.size(); q-- > 0;) {
+            Phase &p = r.phases[q];
+            if (q > 0)
+                for (const SeqJob &j : p.seq) {
+                    for (int k = 0; k < j.nin; k++) r.feeds_seq.insert(j.in[k]);
+                    for (int k = 0; k < 4; k++) if (j.xr[k]) r.feeds_seq.insert(j.xr[k]);
+                }
+            for (const RowThunk &t : p.rows) {
+                bool feeds = false;
+                for (int i = 0; i < t.n_writes; i++) feeds |= r.feeds_seq.count(t.writes[i]) > 0;
+                if (feeds) for (int i = 0; i < t.n_reads; i++) r.feeds_seq.insert(t.reads[i]);
+            }
+        }
+    }
     hipDeviceProp_t prop;
     PQ_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
     const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
@@ -349,7 +468,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // behind the LONG grid, A/B in one session).  Measured alternatives: all ROW launches on one chain (that chain becomes the
         // critical path), the light half behind the HEAVY grid, early fractions of 0 / 0.3 / 0.7: 2 - 8 % slower per step.
         p.row_late.assign(p.rows.size(), 0);
-        if (!p.seq.empty()) {
+        if (!p.seq.empty() && !r.small) { // (a small shard: every ROW launch on the ROW chain from t = 0 -- nothing there is a tail)
             double total = 0, early = 0;
             auto weight = [](const RowThunk &t) { return (double)(t.n_reads + t.n_writes); };
             for (const RowThunk &t : p.rows) total += weight(t);
@@ -420,10 +539,23 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         }
         if (mj || r.b.offsets) wide_min = 0;
         p.wide = false;
+        // Small shard: the chip is mostly idle, a grid ends with its longest job, and a stream runs its grids one after the other.  So the
+        // jobs whose columns a LATER phase reads (the first links of the chains a composite function was taken apart into: RSI under
+        // STOCHRSI, the two averages of MACDEXT) form the SHORT grid of phase 0, every job of a later phase follows on the same chain, and
+        // the jobs nobody waits for -- the long ones among them -- are the LONG grid, which nothing queues behind.
+        // "feeds a later phase" = some SEQUENTIAL job of a later phase reads the column, directly or through ROW launches: a column that only
+        // a trailing ROW launch reads (ADX under ADXR, the chunks of a time-split job under their hand-over check) costs that launch a few
+        // microseconds behind the LONG grid and makes nobody else wait.
+        auto feeds_later = [&](const SeqJob &j) {
+            for (int k = 0; k < j.nout; k++) if (r.feeds_seq.count(j.out[k])) return true;
+            return false;
+        };
         for (SeqJob &j : p.seq) {
             const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1; // the per-lane scan lives in the heavy kernel
             if (j.heavy && (j.lds_bytes > 0 || bt)) j.cls = CLS_HEAVY;
             else if (j.lds_bytes == 0) j.cls = CLS_GATHER;
+            // (the chunks of a time-split job are read by their hand-over check only -- a few microseconds behind the LONG grid: no producer)
+            else if (r.small) j.cls = (pi > 0 || feeds_later(j)) ? CLS_SHORT : CLS_LONG;
             else if (wide_min > 0 && (j.nout >= wide_min || wide_kind_listed(j.kind)) && !j.masked && j.summary_bytes == 0.0 && wide_kind_ok(j.kind)) { j.cls = CLS_HEAVY; p.wide = true; }
             else if (mj) j.cls = mj_job(j) ? CLS_LONG : CLS_SHORT;
             else if (j.lds_bytes > THIN_LDS_MAX) j.cls = CLS_LONG;
@@ -433,7 +565,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // A ROW launch of the NEXT phase whose inputs come only from sequential jobs of ONE class of this phase (e.g. dcphase / sine /
         // leadsine from the Hilbert job's phasor columns) needs no phase barrier: behind that class's grid on the same stream it is
         // ordered after its producers and overlaps the other chains' tails instead of extending the step.
-        if (pi + 1 < r.phases.size()) {
+        if (pi + 1 < r.phases.size() && !r.small) { // (a small shard orders its chains by data dependencies: suite_launch_small)
             Phase &q = r.phases[pi + 1];
             std::vector<RowThunk> stay;
             for (const RowThunk &t : q.rows) {
@@ -474,7 +606,7 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             st.n_jobs++;
             if (j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1) { st.alg_bytes += 32.0 * rows + 64.0 * r.b.n_series; continue; }
             st.alg_bytes += j.summary_bytes * r.b.n_series; // + the summary row of an op with an epilogue
-            if (!j.masked) { st.alg_bytes += 8.0 * rows * j.alg_cols; continue; }
+            if (!j.masked) { st.alg_bytes += 8.0 * rows * j.alg_cols * (double)j.alg_frac; continue; }
             st.alg_bytes += 8.0 * rows * j.nin; // jobs that share one output column row-disjointly: the column counts once
             for (int k = 0; k < j.nout; k++) {
                 if (masked_seen[g][j.out[k]]++) continue;
@@ -526,12 +658,115 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         PQ_HIP_TRY(hipMemcpyAsync(p.d_seq, p.seq.data(), sizeof(SeqJob) * p.seq.size(), hipMemcpyHostToDevice, ctx->stream));
         if (getenv("PQ_SUITE_DEBUG")) PQ_HIP_TRY(hipMalloc((void **)&p.d_dbg, 16 * p.seq.size()));
     }
+    if (r.small) small_deps(r);
     PQ_HIP_TRY(hipStreamSynchronize(ctx->stream)); // the host vectors are pageable
     for (size_t pi = r.phases.size(); pi-- > 0;) // a phase whose only launches were hoisted is gone
         if (r.phases[pi].seq.empty() && r.phases[pi].rows.empty()) r.phases.erase(r.phases.begin() + (long)pi);
     return PQ_OK;
 }
+// The replay of a SMALL-shard recording.  Same chains (streams), same grids; what differs is the ordering between them: no phase
+// barrier -- a barrier makes every chain wait for the longest job of a phase, and on a mostly idle chip the step IS its longest chain --
+// but, per chain and phase, a wait for exactly the earlier launches it depends on (small_deps; a dependency between two streams costs
+// ~10 us on this runtime, scripts/ubench/xstream.hip).  A composite function taken apart into its basic calls (fused.hip: STOCH = the
+// fast-k ROW kernel, then two moving-average jobs) then costs the sum of ITS links, beside everything else.
+static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
+    const Dims d = dims_of(&r.b);
+    if (!r.ev_fork) PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
+    const unsigned tiles = (unsigned)((r.b.n_series + SEQ_BLOCK * 8 - 1) / (SEQ_BLOCK * 8)) * 8;
+    hipStream_t chain_st[NCHAIN] = {ctx->stream, nullptr, nullptr, nullptr};
+    bool started[NCHAIN] = {true, false, false, false};
+    int last_phase[NCHAIN] = {-1, -1, -1, -1};
+    bool any_side = false;
+    for (Phase &p : r.phases) for (int c = 1; c < NCHAIN; c++) any_side |= p.work[c];
+    if (any_side) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
+    for (size_t q = 0; q < r.phases.size(); q++) {
+        Phase &p = r.phases[q];
+        if (p.d_dbg) { // min slots start at ~0, max slots at 0
+            std::vector<unsigned long long> init(2 * p.seq.size());
+            for (size_t i = 0; i < p.seq.size(); i++) { init[2 * i] = ~0ULL; init[2 * i + 1] = 0; }
+            PQ_HIP_TRY(hipMemcpy(p.d_dbg, init.data(), 16 * p.seq.size(), hipMemcpyHostToDevice));
+        }
+        bool chain_done[NCHAIN] = {};
+        bool rows_done = false;
+        for (int oi = 0; oi < NCHAIN; oi++) {
+            const int cls = k_chain_order[oi];
+            const int nj = p.first[cls + 1] - p.first[cls];
+            // the ROW launches of the phase are issued with the class whose chain they share, in front of its grid
+            const bool rows_here = !rows_done && !p.rows.empty() && p.chain_of[cls] == p.row_chain && (cls == ROW_CHAIN || p.row_chain != ROW_CHAIN);
+            const int c = p.chain_of[cls]; // the chain (stream) of this class in this phase
+            if (!(nj > 0 || rows_here)) continue;
+            if (c != 0 && !chain_st[c]) {
+                if (!ctx->suite_aux[c]) {
+                    int prio_lo = 0, prio_hi = 0;
+                    PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                    PQ_HIP_TRY(hipStreamCreateWithPriority(&ctx->suite_aux[c], hipStreamNonBlocking, prio_hi));
+                }
+                chain_st[c] = r.aux[c] = ctx->suite_aux[c];
+            }
+            hipStream_t st = chain_st[c];
+            if (!started[c]) { PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0)); started[c] = true; }
+            if (!chain_done[c]) // (two classes of one phase on one chain: the waits of the chain are issued once)
+                for (const auto &dep : p.deps[c]) PQ_HIP_TRY(hipStreamWaitEvent(st, r.phases[(size_t)dep.first].ev_done[dep.second], 0));
+            chain_done[c] = true;
+            if (rows_here) {
+                rows_done = true;
+                for (size_t k = 0; k < p.rows.size(); k++)
+                    if (!p.row_late[k] && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
+                if (p.n_rows[0])
+                    for (int64_t sb = 0; sb < d.n; sb += 65535) { // grid.y is limited to 65535: slice the series axis
+                        const int64_t ns = d.n - sb < 65535 ? d.n - sb : 65535;
+                        hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((d.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0, st,
+                                           (const RowJobDev *)p.d_rows[0], p.n_rows[0], d, sb);
+                    }
+            }
+            if (nj > 0) {
+                GridStat &g = p.gs[cls];
+                const bool tm = r.timing && g.runs < Recorder::MAX_TIMED_RUNS;
+                if (tm) {
+                    while (g.ev.size() < (size_t)g.runs * 2 + 2) { hipEvent_t e; PQ_HIP_TRY(hipEventCreate(&e)); g.ev.push_back(e); }
+                    PQ_HIP_TRY(hipEventRecord(g.ev[(size_t)g.runs * 2], st));
+                }
+                unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[cls] : nullptr;
+                const dim3 grid(tiles, (unsigned)nj);
+                int v = k_variant[cls];
+                if (v == 0)
+                    for (int jx = p.first[cls]; jx < p.first[cls + 1]; jx++) if (p.seq[jx].unal) v = 3;
+                if (v == 3) hipLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
+                else if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
+                else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
+                else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
+                if (tm) { PQ_HIP_TRY(hipEventRecord(g.ev[(size_t)g.runs * 2 + 1], st)); g.runs++; }
+            }
+            if (!p.ev_done[c]) PQ_HIP_TRY(hipEventCreateWithFlags(&p.ev_done[c], hipEventDisableTiming));
+            PQ_HIP_TRY(hipEventRecord(p.ev_done[c], st));
+            last_phase[c] = (int)q;
+        }
+    }
+    for (int c = 1; c < NCHAIN; c++)
+        if (last_phase[c] >= 0) PQ_HIP_TRY(hipStreamWaitEvent(ctx->stream, r.phases[(size_t)last_phase[c]].ev_done[c], 0));
+    bool dbg_any = false;
+    for (Phase &p : r.phases) dbg_any |= p.d_dbg != nullptr;
+    if (dbg_any) { // debug only: wait and print the per-job schedule (100 MHz device clock), every phase against the step's first start
+        PQ_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long t0 = ~0ULL;
+        std::vector<std::vector<unsigned long long>> ts(r.phases.size());
+        for (size_t q = 0; q < r.phases.size(); q++) {
+            Phase &p = r.phases[q];
+            if (!p.d_dbg) continue;
+            ts[q].resize(2 * p.seq.size());
+            PQ_HIP_TRY(hipMemcpy(ts[q].data(), p.d_dbg, 16 * p.seq.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < p.seq.size(); i++) t0 = ts[q][2 * i] < t0 ? ts[q][2 * i] : t0;
+        }
+        for (size_t q = 0; q < r.phases.size(); q++)
+            for (size_t i = 0; i * 2 < ts[q].size(); i++)
+                fprintf(stderr, "[pq suite] job %2zu kind=%3d class=%d lds=%6u  start %8.1f us  end %8.1f us  phase %zu\n", i, r.phases[q].seq[i].kind,
+                        r.phases[q].seq[i].cls, r.phases[q].seq[i].lds_bytes, (double)(ts[q][2 * i] - t0) / 100.0, (double)(ts[q][2 * i + 1] - t0) / 100.0, q);
+    }
+    PQ_HIP_TRY(hipGetLastError());
+    return PQ_OK;
+}
 static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
+    if (r.small) return suite_launch_small(ctx, r);
     Dims d = dims_of(&r.b);
     if (!r.ev_fork) PQ_HIP_TRY(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
     // Side streams are created when a chain first has work (an unused stream would still take its turn in the runtime's queue
@@ -707,6 +942,7 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     if (r.ev_tail) { (void)hipEventDestroy(r.ev_tail); r.ev_tail = nullptr; }
     for (Phase &p : r.phases) {
+        for (int c = 0; c < NCHAIN; c++) if (p.ev_done[c]) { (void)hipEventDestroy(p.ev_done[c]); p.ev_done[c] = nullptr; }
         if (p.d_seq) (void)hipFree(p.d_seq);
         for (int pos = 0; pos <= NCHAIN; pos++)
             if (p.d_rows[pos]) { (void)hipFree(p.d_rows[pos]); p.d_rows[pos] = nullptr; p.n_rows[pos] = 0; }
@@ -751,7 +987,7 @@ SuiteScope::SuiteScope(pq_ctx *c, const pq_batch *b) : ctx(c), owner(false), sta
     pq_suite *s = new pq_suite();
     s->rec.b = *b;
     ctx->rec = &s->rec;
-    ctx->rec_small = small_shard(ctx, b);
+    ctx->rec_small = s->rec.small = small_shard(ctx, b);
     owner = true;
 }
 SuiteScope::~SuiteScope() {
@@ -782,7 +1018,7 @@ pq_status pq_suite_begin(pq_ctx *ctx, const pq_batch *b) {
     pq_suite *s = new pq_suite();
     s->rec.b = *b;
     ctx->rec = &s->rec;
-    ctx->rec_small = small_shard(ctx, b);
+    ctx->rec_small = s->rec.small = small_shard(ctx, b);
     return PQ_OK;
 }
 pq_status pq_suite_end(pq_ctx *ctx, pq_suite **out) {

@@ -14,8 +14,14 @@ struct SeqJob { // device-visible
     int alg_cols;                  // f64 column transfers credited (per reference call)
     unsigned lds_bytes, tile_bytes; // lds_bytes 0 = run the gather body
     int tile_k;                     // rows per tile of the tiled body (SeqTile<Op>::K)
+    int ts_len, ts_skip, ts_row0;   // time-split job (pq_dev.h TsOk): the rows of its range (0: the batch's len), the leading tiles it keeps to itself,
+                                    // its first row (the job's columns are in / out / the op's own pointers + ts_row0: the recorded pointers stay the
+                                    // columns' bases, which is what the hazard tracking keys on)
+    float alg_frac;                 // share of the op's algorithmic bytes credited to this job (1 unless time-split)
     const double *in[6];
     double *out[8];
+    const void *xr[4]; // columns the job touches outside its tile path (signal / benchmark columns read; a summary table, derived columns
+    void *xw[4];       // written): what the recording's hazard tracking and the small-shard schedule's dependencies need to know
     alignas(8) unsigned char op[1024];
 };
 static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");

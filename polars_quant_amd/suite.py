@@ -44,6 +44,8 @@ class Suite:
         assert self.stride >= T
         self._housed = {}
         self.dev = torch.device(device)
+        if self.dev.type == "cuda" and self.dev.index is None:     # ("cuda" != "cuda:0" for torch: every input would read as foreign and be re-housed)
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.batch = Batch(n_series, T, self.stride)
         f64 = lambda: torch.empty((n_series, self.stride), dtype=torch.float64, device=self.dev)[:, :T]
         i32 = lambda: torch.empty((n_series, self.stride), dtype=torch.int32, device=self.dev)[:, :T]

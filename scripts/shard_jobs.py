@@ -3,7 +3,7 @@ which job bounds the step when the chip is not full.   python scripts/shard_jobs
 import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 os.environ.setdefault("PQ_SUITE_DEBUG", "1")
 import torch
 

@@ -2,7 +2,7 @@
 Environment switches of the library / of Suite apply (PQ_SUITE_UNFUSE, PQ_WT_SUITE, PQ_LIB_PATH, PQ_SMALL_SHARD ...).  One line per size."""
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 
 from polars_quant_amd.suite import Suite

@@ -92,8 +92,9 @@ def assert_same(name, got, exp, exact=True, price=None):
         g, e = got[ok], exp[ok]
         sc = np.broadcast_to(scale, exp.shape)[ok]
         both_nan = np.isnan(g) & np.isnan(e)
-        err = np.abs(g - e) / np.maximum(np.maximum(np.abs(e), sc), 1e-300)
-        err[both_nan] = 0
+        with np.errstate(invalid="ignore"):
+            err = np.abs(g - e) / np.maximum(np.maximum(np.abs(e), sc), 1e-300)
+        err[both_nan | (g == e)] = 0        # (equal infinities: inf - inf is NaN)
         assert (err <= RTOL).all(), f"{name}: max error {np.nanmax(err):.3e} (relative to max(|expected|, scale))"
 
 
