@@ -89,7 +89,16 @@ static pq_status comm_stream_make(pq_ctx *ctx) {
     if (ctx->comm_stream) return PQ_OK;
     int prio_lo = 0, prio_hi = 0;
     PQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    PQ_HIP_TRY(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, prio_hi));
+    // The stream runs at the DEFAULT priority.  Round 5 created it at the highest one ("the exchange is latency-critical") and measured
+    // 136 us per 625-symbol backtest step with the exchange overlapped against 52.5 in series -- which it booked as "a cross-stream
+    // dependency costs ~40 us on this runtime".  It does not: scripts/ubench/xstream.hip, bare HIP, puts a one-way dependency between
+    // two streams at 4.7 us per step (10 us per hop when the result gates the next step).  What cost 85 us was the PRIORITY: a kernel
+    // arriving on a higher-priority queue while the step's kernel holds the chip makes the hardware save and restore running waves.
+    // scripts/ubench/gather_cabi.cpp (C, no torch), 625 symbols: 139 us per step at the highest priority, 60.7 at the default one
+    // (kernel only 50.9, in series 52.5).  PQ_COMM_PRIO=high restores the old stream for A/B runs.
+    const char *pe = getenv("PQ_COMM_PRIO");
+    if (pe && !strcmp(pe, "high")) PQ_HIP_TRY(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, prio_hi));
+    else PQ_HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
         PQ_HIP_TRY(hipEventCreateWithFlags(&ctx->comm_ev_in[k], hipEventDisableTiming));
         PQ_HIP_TRY(hipEventCreateWithFlags(&ctx->comm_ev_done[k], hipEventDisableTiming));
@@ -157,7 +166,7 @@ pq_status pq_gather_summaries_end(pq_ctx *ctx, int32_t slot) {
     if (!ctx->comm_pending[slot]) return PQ_OK;
     PQ_HIP_TRY(hipSetDevice(ctx->device));
     // steady state: the exchange of two steps ago completed long ago -- a host-side query then saves the cross-stream wait (a barrier
-    // packet on the step's queue costs tens of microseconds on this runtime, scripts/bench_gather.py)
+    // packet on the step's queue: ~10 us, scripts/ubench/xstream.hip)
     const hipError_t q = hipEventQuery(ctx->comm_ev_done[slot]);
     if (q != hipSuccess) {
         if (q != hipErrorNotReady) PQ_HIP_TRY(q);

@@ -59,9 +59,11 @@ static pq_status mama_zero(pq_ctx *ctx, const pq_batch *b, const HtOp<4> &op, co
     const double *in[1] = {real};
     double *out[2] = {mama, fama};
     const size_t tiles = (size_t)((b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK);
-    // the general body behind the gate: tiled inside a recording on 16-byte aligned rows (the suite's shape), per lane otherwise (what a
-    // direct call of the Hilbert family runs anyway, DIRECT_LANE_MAX)
-    w.lds = (ctx->rec && seq_cols_tiling<1, 2>(b, in, out) == 0 && seq_lds_bytes(op) <= SEQ_LDS_LIMIT) ? (unsigned)seq_lds_bytes(op) : 0u;
+    // the general body behind the gate is the per-lane one (register delay lines, no LDS; what a direct call of the Hilbert family runs
+    // anyway, DIRECT_LANE_MAX): a workgroup of the tiled body asks for 20 KB of LDS just to look at its flag and return, and beside a
+    // job grid that fills the chip's LDS it waited 0.16 ms for a CU to have them (1 250 symbols); a flagged tile is rare, its speed immaterial
+    (void)in; (void)out;
+    w.lds = 0u;
     if (ctx->rec) {
         static_assert(sizeof(MamaZeroBlob) <= sizeof(RowThunk::blob), "blob too large for a recorded launch");
         w.gate = reinterpret_cast<unsigned *>(rec_alloc_zero(ctx, tiles * sizeof(unsigned)));

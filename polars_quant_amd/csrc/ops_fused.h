@@ -636,29 +636,31 @@ struct HtAll6Op : HtAllOp {
 // rounding of every candidate is the reference's); all of them are fed from one shared input ring, and the job writes the
 // rows whose clamped period falls in its range (masked, like the block op below, which keeps its states in LDS and needs
 // twice the jobs).
-struct MavpSma16Op {
+template <int NG> // NG groups of eight candidate periods per job: 2 (sixteen) on a full chip; 1 (eight) for SMALL shards, where a job's length counts
+struct MavpSmaNOp {
+    static constexpr int NC = 8 * NG;
     static constexpr bool LDS_ONLY = true;
     static constexpr bool MASKED = true;
     static constexpr int NIN = 2, NOUT = 1; // real (nulls -> 0.0), periods
-    static constexpr int SEQ_ID = 83;
-    static constexpr int COST_NS = 835; // sixteen running sums per row
+    static constexpr int SEQ_ID = NG == 2 ? 83 : 86;
+    static constexpr int COST_NS = NG == 2 ? 835 : 470; // NC running sums per row
     int lo, hi, minp, maxp, n;
     Ring w;
-    const double *tab; // 1/P for P = lo .. lo+15 (shared by the wave)
-    double s[16];
-    // the ring keeps lo + 23 values: the batched fast path pushes eight rows first and then reads the 23 values
-    // x[t-lo-15 .. t+7-lo] the sixteen candidates need for those rows (the oldest was pushed lo + 23 pushes ago)
-    __host__ __device__ int64_t ring_slots() const { return (lo > 0 ? lo : 1) + 23 + 1; }
+    const double *tab; // 1/P for P = lo .. lo+NC-1 (shared by the wave)
+    double s[NC];
+    // the ring keeps lo + NC + 7 values: the batched fast path pushes eight rows first and then reads the NC + 7 values
+    // x[t-lo-NC+1 .. t+7-lo] the NC candidates need for those rows (the oldest was pushed lo + NC + 7 pushes ago)
+    __host__ __device__ int64_t ring_slots() const { return (lo > 0 ? lo : 1) + NC + 7 + 1; }
     __device__ void init(const Row<2> &) {}
     __device__ void init_lds(const Row<2> &r, RingAlloc &ra) {
         n = (int)(r.len < 0x7fffffff ? r.len : 0x7fffffff);
-        w = ra.make((lo > 0 ? lo : 1) + 23);
-        double *t = ra.make_shared(16);
+        w = ra.make((lo > 0 ? lo : 1) + NC + 7);
+        double *t = ra.make_shared(NC);
         const int k = threadIdx.x & 63;
-        if (k < 16) t[k] = 1.0 / (double)(lo + k);
+        if (k < NC) t[k] = 1.0 / (double)(lo + k);
         tab = t;
 #pragma unroll
-        for (int u = 0; u < 16; u++) s[u] = 0.0;
+        for (int u = 0; u < NC; u++) s[u] = 0.0;
         lds_fence();
     }
     __device__ void step(const Row<2> &, int64_t, const double (&)[2], double (&y)[1]) { y[0] = pq_skip(); }
@@ -671,7 +673,7 @@ struct MavpSma16Op {
         const int c = t + 1; // every row is valid after nulls -> 0.0
         double asel = 0.0;
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < NG; g++) {
             double old[8];
             w.get8<1>(lo + 8 * g, old); // x[t - P] for the eight periods of this group
 #pragma unroll
@@ -697,14 +699,14 @@ struct MavpSma16Op {
     // longer than the series carry garbage here that is never selected (pi is clamped into [minp, maxp] and `mine` tests
     // [lo, hi]) and that the general path resets to 0.0 on its next row
     static constexpr bool HAS_FAST = true;
-    __device__ bool steady(int64_t t0) const { return t0 >= lo + 16 && t0 >= maxp - 1 && lo > 0; }
+    __device__ bool steady(int64_t t0) const { return t0 >= lo + NC && t0 >= maxp - 1 && lo > 0; }
     __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[1]) {
         const double v = n0(x[0]);
         const int64_t p64 = (int64_t)n0(x[1]);
         const int pi = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
         double asel = 0.0;
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < NG; g++) {
             double old[8];
             w.get8<1>(lo + 8 * g, old);
 #pragma unroll
@@ -726,7 +728,7 @@ struct MavpSma16Op {
     static constexpr bool FAST_BATCH = true;
     template <int N>
     __device__ void steps_fast(int64_t, const double (&x)[N][2], double (&y)[N][1]) {
-        static_assert(N == 8, "MavpSma16Op::steps_fast is written for batches of eight rows");
+        static_assert(N == 8, "MavpSmaNOp::steps_fast is written for batches of eight rows");
         double v[8];
         int pi[8];
 #pragma unroll
@@ -736,12 +738,12 @@ struct MavpSma16Op {
             pi[r] = p64 < minp ? minp : (p64 > maxp ? maxp : (int)p64);
         }
         w.push_n<8>(v);
-        double X[23];
-        {   // X[i] was pushed (23 + lo - i) pushes ago (X[22 + lo] would be the newest, v[7])
-            int k = w.pos - (23 + lo);
+        double X[NC + 7];
+        {   // X[i] was pushed (NC + 7 + lo - i) pushes ago (X[NC + 6 + lo] would be the newest, v[7])
+            int k = w.pos - (NC + 7 + lo);
             k += (k < 0) ? w.depth : 0;
 #pragma unroll
-            for (int i = 0; i < 23; i++) {
+            for (int i = 0; i < NC + 7; i++) {
                 X[i] = w.base[k * 64];
                 k = (k + 1 == w.depth) ? 0 : k + 1;
             }
@@ -752,8 +754,8 @@ struct MavpSma16Op {
 #pragma unroll
         for (int r = 0; r < 8; r++) { // row-major: sixteen independent chains advance together
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                s[u] = (s[u] + v[r]) - X[r - u + 15];
+            for (int u = 0; u < NC; u++) {
+                s[u] = (s[u] + v[r]) - X[r - u + NC - 1];
                 asel[r] = (lo + u == pi[r]) ? s[u] : asel[r];
             }
         }
@@ -766,6 +768,8 @@ struct MavpSma16Op {
         }
     }
 };
+typedef MavpSmaNOp<2> MavpSma16Op;
+typedef MavpSmaNOp<1> MavpSma8Op;
 
 // MAVP with the SMA core, up to THIRTY-TWO candidate periods [lo, hi] = [minperiod, maxperiod] in ONE job (the default 2 .. 30 is
 // 29): the job covers every period a row can ask for, so its output is an ordinary tile column -- coalesced 128-byte pieces through

@@ -149,13 +149,18 @@ pq_status pq_mavp(pq_ctx *ctx, const pq_batch *b, const double *real, const doub
         // SMA: sixteen candidate periods per job (states in registers); EMA: eight (states in LDS).  Two passes: decide
         // first whether EVERY block fits the tiled body -- nothing may be recorded before that is known, or the rows of `out`
         // would get a second writer from the per-period fallback below
-        const int64_t per_job = matype == 1 ? 8 : 16;
+        const bool sma8 = matype != 1 && !PQ_FUSE_OK(ctx); // a small-shard recording: blocks of eight candidates, jobs of half the length
+        const int64_t per_job = (matype == 1 || sma8) ? 8 : 16;
         InCols<2> in{{r0, periods}}; OutCols<1> o1{{out}};
         for (int pass = 0; pass < 2; pass++) {
             if (pass == 0) blocked = true;
             for (int64_t lo = minp; lo <= maxp && st == PQ_OK && blocked; lo += per_job) {
                 int64_t hi = lo + per_job - 1 < maxp ? lo + per_job - 1 : maxp;
-                if (matype != 1) {
+                if (matype != 1 && sma8) {
+                    MavpSma8Op op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
+                    if (pass == 0) blocked = seq_can_lds(ctx, b, op, in, o1);
+                    else st = launch_seq(ctx, b, op, in, o1);
+                } else if (matype != 1) {
                     MavpSma16Op op{}; op.lo = (int)lo; op.hi = (int)hi; op.minp = (int)minp; op.maxp = (int)maxp;
                     if (pass == 0) blocked = seq_can_lds(ctx, b, op, in, o1);
                     else st = launch_seq(ctx, b, op, in, o1);

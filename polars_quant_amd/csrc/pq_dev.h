@@ -489,31 +489,12 @@ __device__ __forceinline__ void nt_store2(double *p, const double2 &v) {
 // body these batches ran before (255 VGPRs, 92 of them spilled, one L1 tag lookup per lane and 8 bytes) and 3.9 ms at the 16-byte
 // aligned pitch 2 528.  (A form with 16-byte accesses on the 8-byte aligned addresses -- legal in the queue's unaligned access mode --
 // was built and measured the same 7.7 ms: the cost of an odd pitch is that every 64-byte piece straddles two cache lines.)
-// MJ (multi-job workgroups, suite_mj.hip): the compute wave of this job is one of several in a workgroup that share ONE storer wave.
-// There is no storer branch here and no workgroup barrier: the hand-off is a pair of counters in LDS (MjCtl) -- `ready` = tiles this
-// wave has finished, `taken` = tiles the storer has pulled out of LDS -- so every compute wave runs at its own pace.
-struct MjCtl { unsigned ready, taken, pad0, pad1; };
-typedef __attribute__((address_space(3))) unsigned pq_lds_u32;
-__device__ __forceinline__ unsigned mj_peek(const unsigned *p) { // an LDS word another wave writes: a fresh ds_read every time
-    asm volatile("" ::: "memory");
-    const unsigned v = *(volatile const pq_lds_u32 *)p;
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void mj_post(unsigned *p, unsigned v) { // after the caller's lds_fence(): data first, then the counter
-    asm volatile("" ::: "memory");
-    *(volatile pq_lds_u32 *)p = v;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-constexpr unsigned MJ_SPIN_LIMIT = 1u << 22; // polls before a waiting wave gives up (a protocol error must end the grid, not hang the GPU)
 // LENS: the batch is a re-housed ragged one (launch_seq, rg_pack): every series is walked over d.len rows of its padded row, but the op
 // is told the series' OWN length (init / init_lds read r.len for their short-series rules); rows beyond it are computed on padding
 // and never leave the padded columns.
-// NS: storer waves of the workgroup (1: the two-wave form; 2: seq_jobs_kernel<4>, suite.hip -- a job with many output columns is paced
-// by its store stream, so its columns are dealt out to two storers: storer s takes the columns s, s + 2, ...).
-template <class Op, bool UNAL = false, bool MJ = false, bool LENS = false, int NS = 1>
+template <class Op, bool UNAL = false, bool LENS = false>
 __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, double *const *outp, const Dims &d,
-                                            int64_t tile_s0, unsigned char *lds, MjCtl *ctl = nullptr, unsigned *mj_err = nullptr, int skip = 0) {
+                                            int64_t tile_s0, unsigned char *lds, int skip = 0) {
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, K = SeqTile<Op>::K, ROWB = SeqTile<Op>::ROWB;
     constexpr int TB = SeqTile<Op>::TILE_BYTES;
     constexpr int CPL = UNAL ? K : K / 2; // lanes per series segment: 16-byte chunks (UNAL: 8-byte elements)
@@ -523,10 +504,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     constexpr bool MASKED = SeqTile<Op>::DIRECT; // per-lane stores by wave 0 (row-masked outputs)
     // the store replica (an A/B build, experiments.h PQ_EXP_STOREONLY): the step's grids, addresses, piece sizes and store policy with the
     // compute wave gone -- no loads, no LDS traffic, no barriers; what the write pattern alone costs
-    constexpr bool SO = PQ_EXP_STOREONLY_ON && !MJ && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value && !UNAL;
+    constexpr bool SO = PQ_EXP_STOREONLY_ON && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value && !UNAL;
     static_assert(NTap<Op>::value == 0 || HasRings<Op>::value, "an op with lag taps needs a ring variant for the LDS body");
-    static_assert(!MJ || (!UNAL && !SeqTile<Op>::DIRECT && !HasFinish<Op>::value), "multi-job workgroups: aligned, tile-output ops without an epilogue");
-    const int lane = threadIdx.x & 63, wave = MJ ? 0 : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
     const int64_t T = d.len, nt = T / K;
     const int64_t it_first = (TsOk<Op>::value && skip > 0) ? skip - 1 : 0; // the first tile that is handed to the storer (wave-uniform; 0 unless time-split)
     const int csym = lane / CPL, cchunk = lane % CPL;
@@ -580,27 +560,14 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
     // hand-off of a finished out tile to the storer wave.  (Measured alternative: one-wave workgroups in which the compute
     // wave pulls the tile back and issues the stores itself, with the next tile's loads issued before them -- 8.2 vs 5.5 ms
     // per suite step: the wave's own stores hold up its vmcnt waits whatever the order.)
-    unsigned mj_done = 0; // MJ: tiles handed over so far
     auto hand_off = [&](int64_t) {
         if constexpr (MASKED) return;
-        if constexpr (MJ) { // this wave's LDS writes are complete (lds_fence above): publish the tile, wait until the storer has pulled it
-            mj_done++;
-            mj_post(&ctl->ready, mj_done);
-            unsigned spins = 0;
-            while (mj_peek(&ctl->taken) != mj_done) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > MJ_SPIN_LIMIT) { if (lane == 0 && mj_err) atomicExch(mj_err, 1u); __builtin_amdgcn_endpgm(); } // (ends this wave)
-            }
-            return;
-        }
         __builtin_amdgcn_s_barrier(); // A: out tile complete, wave 1 may read it
         __builtin_amdgcn_s_barrier(); // B: wave 1 holds the tile in registers, LDS is free again
     };
     // (`wave == 1` for the two-wave form, literally: with `wave >= 1` the compute branch learns that its wave index is 0 and the register
     //  allocation of the light job kernel shifts by two spilled registers under its 192 cap)
-    if (!MJ && (NS == 1 ? wave == 1 : wave >= 1)) { // -------------------------------------------- storer(s)
-        const int si = NS > 1 ? __builtin_amdgcn_readfirstlane(wave - 1) : 0; // which storer: its columns are si, si + NS, ...
-        constexpr int NOS = (NOUT + NS - 1) / NS;                             // columns per storer (at most)
+    if (wave == 1) { // -------------------------------------------------------------------------- storer
         if constexpr (!MASKED) {
             // Tunable: the storer can keep ACC consecutive out tiles in registers and issue their stores back to back (ACC * K * 8
             // contiguous bytes per series within a few cycles).  In a pure tile copy 64-byte pieces scattered over 64 series run
@@ -620,10 +587,9 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                 // step at pitch 2528 (against 64-byte pieces at the dense pitch 2520; -4 % of it from the pitch alone, which also
                 // aligns the 16-row tiles of the 1-in/1-out ops).  No extra LDS, the register count of two held tiles; columns
                 // beyond the register cap go out per tile as before.
-                // (this storer's j-th column is column kk = j * NS + si of the job; with one storer kk = j)
                 constexpr int CAP = IsHeavy<Op>::value ? 208 : PQ_PAIR_CAP;
-                constexpr int W0 = (CAP - NOS * NI * 4) / (NI * 4);
-                constexpr int W = (SO && PQ_EXP_SO_ALLPAIR_ON) ? NOS : (W0 < 0 ? 0 : (W0 > NOS ? NOS : W0)), R = NOS - W; // (replica variant: every column in 128-byte pieces)
+                constexpr int W0 = (CAP - NOUT * NI * 4) / (NI * 4);
+                constexpr int W = (SO && PQ_EXP_SO_ALLPAIR_ON) ? NOUT : (W0 < 0 ? 0 : (W0 > NOUT ? NOUT : W0)), R = NOUT - W; // (replica variant: every column in 128-byte pieces)
                 const int half = (lane >> 2) & 1, sub = lane >> 3;
                 const unsigned char *pr_row = lds + sub * ROWB + (lane & 3) * 16;
                 static_assert(!TsOk<Op>::value, "a time-split op stores per tile: its check tile and its first own tile go to different columns");
@@ -638,8 +604,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             if (half == a) {
 #pragma unroll
                                 for (int k = 0; k < W; k++) {
-                                    const int kk = k * NS + si;
-                                    if (NS > 1 && kk >= NOUT) continue;
+                                    const int kk = k;
 #pragma unroll
                                     for (int i = 0; i < 8; i++) {
                                         const double *q = reinterpret_cast<const double *>(pr_row + i * 8 * ROWB + kk * TB);
@@ -649,8 +614,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             }
 #pragma unroll
                             for (int k = 0; k < R; k++) {
-                                const int kk = (W + k) * NS + si;
-                                if (NS > 1 && kk >= NOUT) continue;
+                                const int kk = W + k;
 #pragma unroll
                                 for (int i = 0; i < NI; i++) {
                                     const double *q = reinterpret_cast<const double *>(co_row(i) + kk * TB);
@@ -662,8 +626,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                             const int64_t t0 = (it + a) * K;
 #pragma unroll
                             for (int k = 0; k < R; k++) {
-                                const int kk = (W + k) * NS + si;
-                                if (NS > 1 && kk >= NOUT) continue;
+                                const int kk = W + k;
 #pragma unroll
                                 for (int i = 0; i < NI; i++)
                                     if (live_i(i)) nt_store2(at_w(outp[kk], i, t0), v[k][i]);
@@ -674,8 +637,7 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     const unsigned pair_part = (unsigned)sub * stride_b + (unsigned)(lane & 7) * 16u; // series sub + 8 i, rows 2 (lane & 7) ..
 #pragma unroll
                     for (int k = 0; k < W; k++) {
-                        const int kk = k * NS + si;
-                        if (NS > 1 && kk >= NOUT) continue;
+                        const int kk = k;
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
                             unsigned char *const pb = reinterpret_cast<unsigned char *>(outp[kk] + tile_base + it * K); // wave-uniform
@@ -696,17 +658,14 @@ __device__ __forceinline__ void run_seq_lds(Op &op, const double *const *inp, do
                     if (it + a < nt) {
                         PQ_HOOK_STORER_BARRIER(); // A: out tile `it + a` is complete
                         lds_fence();
-                        if (NS == 1 || si == 0) { // (this per-tile form is not split over storers: a second one only keeps the barriers company)
 #pragma unroll
                         for (int k = 0; k < NOUT; k++)
 #pragma unroll
                             for (int i = 0; i < NI; i++) v[a][k][i] = PQ_HOOK_STORER_PULL_G(l_get(i, k * TB), k, i);
-                        }
                         lds_fence();
                         PQ_HOOK_STORER_BARRIER(); // B: LDS may be overwritten
                     }
                 }
-                if (NS > 1 && si != 0) continue;
                 const int64_t t0 = it * K;
                 bool check_tile = false; // time-split: the last warm-up tile goes to the op's check columns, nothing is derived from it
                 if constexpr (TsOk<Op>::value) check_tile = it < skip;
@@ -919,7 +878,7 @@ PQ_HOOK_SEQ_KERNEL_ATTR __global__ __launch_bounds__(LDS ? SEQ_LDS_BLOCK : SEQ_B
     }
     if constexpr (LDS) {
         extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
-        run_seq_lds<Op, UNAL, false, LENS>(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
+        run_seq_lds<Op, UNAL, LENS>(op, in.p, out.p, d, (int64_t)blockIdx.x * SEQ_BLOCK, seq_lds);
     } else {
         const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
         if (s >= d.n) return;

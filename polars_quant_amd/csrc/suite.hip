@@ -44,36 +44,6 @@ static const int k_variant[NCLS] = {0, 0, 1, 2};                                
 // "thin" = six workgroups fit a CU's LDS; the LONG grid places half a workgroup less per CU at t = 0 than LDS admits of its widest
 // job.  Both follow from the device's LDS size and the recorded jobs (at 5 000 x 2 520 on MI355X: 26 KB and 3.5, the values round
 // 2 had tuned as literals).
-// A/B builds (scripts/ab_build.sh mj "-DPQ_EXPERIMENTS -DPQ_EXP_MJ" all): PQ_MJ=1 runs the light tiled jobs in multi-job workgroups (measured
-// slower, EXPERIMENTS.md round 5); PQ_MJ_WIDTH=1..MJ_NC: compute waves used
-#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_MJ)
-static bool mj_enabled() { const char *e = getenv("PQ_MJ"); return e && atoi(e) > 0; }
-#else
-static bool mj_enabled() { return false; } // (the product build carries no seq_mj_kernel: suite_mj.hip compiles to two stubs)
-#endif
-#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_WIDE)
-static int wide_min_nout() { const char *e = getenv("PQ_WIDE"); return e ? atoi(e) : 0; }
-#else
-static int wide_min_nout() { return 0; } // (the product build has no seq_jobs_kernel<4>)
-#endif
-static bool wide_kind_listed(int kind) { // PQ_WIDE_KINDS=94,90: these job kinds as well (A/B runs; PQ_WIDE=99 then selects by the list alone)
-    const char *e = getenv("PQ_WIDE_KINDS");
-    while (e && *e) {
-        if (atoi(e) == kind) return true;
-        e = strchr(e, ',');
-        if (e) e++;
-    }
-    return false;
-}
-static bool wide_kind_ok(int kind) { // pair-mode ops only: 8-row tiles, no derived columns (what run_seq_lds<..., NS = 2> deals out to two storers)
-    switch (kind) {
-#define X(OP) case OP::SEQ_ID: return SeqTile<OP>::K == 8 && NDer<OP>::value == 0 && !IsMasked<OP>::value && !HasFinish<OP>::value && !IsHeavy<OP>::value;
-        SEQ_OPS_LIGHT(X)
-#undef X
-    default: return false;
-    }
-}
-static int mj_width() { const char *e = getenv("PQ_MJ_WIDTH"); const int w = e ? atoi(e) : MJ_NC; return w < 1 ? 1 : (w > MJ_NC ? MJ_NC : w); }
 static unsigned thin_lds_max(const hipDeviceProp_t &prop) { return (unsigned)(prop.maxSharedMemoryPerMultiProcessor / 6 / 1024 * 1024); }
 struct Phase {
     GridStat gs[NCLS];
@@ -91,17 +61,13 @@ struct Phase {
     unsigned wg_tiles = 0;
     int first[NCLS + 1] = {}; // job index range of each class
     unsigned lds[NCLS] = {};
-    // multi-job workgroups (suite_mj.hip): when n_mj > 0 the jobs of class LONG run as n_mj groups of up to MJ_NC jobs in ONE grid of
-    // (MJ_NC + 1)-wave workgroups instead of one two-wave workgroup per job and tile
-    MjGroup *d_mj = nullptr;
-    int n_mj = 0;
-    unsigned mj_lds = 0;
-    unsigned *d_mj_err = nullptr;
-    bool wide = false; // class HEAVY holds light jobs with many output columns and runs seq_jobs_kernel<4> (two storers per workgroup)
     // small-shard schedule (Recorder::small): what chain c of this phase waits for -- (phase, chain) pairs of earlier phases whose launches
     // wrote a column it touches or read a column it writes -- and the event recorded behind its launches
+    // (slot NCHAIN = the HEADS of the phase's ROW chain: the ROW launches that feed later phases are issued first and get an event of
+    //  their own, so that a link waiting for the fast-k column does not wait for the patterns and the backtest behind it)
     std::vector<std::pair<int, int>> deps[NCHAIN];
-    hipEvent_t ev_done[NCHAIN] = {};
+    hipEvent_t ev_done[NCHAIN + 1] = {};
+    int n_heads = 0; // leading ROW launches on the phase's ROW chain that feed a later phase
     bool work[NCHAIN] = {};
     int chain_of[NCLS] = {0, 1, 2, 3}; // small-shard schedule: the chain (stream) the grid of class c runs on in this phase
     int row_chain = ROW_CHAIN;         // ... and the chain of its ROW launches
@@ -140,7 +106,7 @@ struct TiledJob<OP, true> {
 #pragma unroll
         for (int k = 0; k < OP::NOUT; k++) outj[k] = job.out[k] + job.ts_row0;
         op.ts_shift(job.ts_row0);
-        run_seq_lds<OP, false>(op, inj, outj, dj, s0, lds, nullptr, nullptr, job.ts_skip);
+        run_seq_lds<OP, false>(op, inj, outj, dj, s0, lds, job.ts_skip);
     }
 };
 template <int V>
@@ -165,7 +131,6 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
         OP op;                                                                                                       \
         __builtin_memcpy(&op, job.op, sizeof(OP));                                                                   \
         if constexpr (V == 2) run_seq(op, job.in, job.out, d, s);                                                    \
-        else if constexpr (V == 4) run_seq_lds<OP, false, false, false, 2>(op, job.in, job.out, d, s0, jobs_lds);    \
         else if constexpr (V == 0) TiledJob<OP>::run(op, job, d, s0, jobs_lds);                                      \
         else                                                                                                         \
             run_seq_lds<OP, V == 3>(op, job.in, job.out, d, s0, jobs_lds); \
@@ -207,11 +172,9 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
     if (dbg && threadIdx.x == 0) atomicMax(&dbg[2 * blockIdx.y + 1], wall_clock64());
     if (wg && threadIdx.x == 0) wg[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
-// 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 3: light ops, tiled, rows only 8-byte aligned (UNAL);
-// 4: light ops, tiled, THREE waves per workgroup: one compute wave and two storers (PQ_WIDE: jobs with many output columns)
-constexpr int SEQ_WIDE_BLOCK = 192;
+// 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 3: light ops, tiled, rows only 8-byte aligned (UNAL)
 template <int V>
-__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : V == 4 ? SEQ_WIDE_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<V>(jobs, d, dbg, wg);
 }
 #if PQ_NV0 > 0
@@ -219,12 +182,6 @@ template <>
 __global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_LDS_BLOCK, PQ_LB0) void seq_jobs_kernel<0>(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<0>(jobs, d, dbg, wg);
 }
-#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_WIDE) // A/B builds only (EXPERIMENTS.md, round 5): a second storer wave for the jobs with many output columns
-template <>
-__global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_WIDE_BLOCK, PQ_LB0) void seq_jobs_kernel<4>(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
-    seq_jobs_body<4>(jobs, d, dbg, wg);
-}
-#endif
 #endif
 
 // A recording covers a SMALL shard when one job is at most cus / 8 workgroups (32 tiles = 2 048 series on MI355X): with the ~40 jobs of
@@ -398,44 +355,57 @@ static void small_deps(Recorder &r) {
         std::vector<RowThunk> rows2; std::vector<char> late2, fused2;
         for (size_t k : idx) { rows2.push_back(p.rows[k]); late2.push_back(p.row_late[k]); fused2.push_back(p.row_fused[k]); }
         p.rows.swap(rows2); p.row_late.swap(late2); p.row_fused.swap(fused2);
+        p.n_heads = 0;
+        while ((size_t)p.n_heads < p.rows.size() && feeds(p.rows[(size_t)p.n_heads]) && !p.row_late[(size_t)p.n_heads] && !p.row_fused[(size_t)p.n_heads]) p.n_heads++;
     }
     std::map<const void *, std::vector<std::pair<int, int>>> last_w, readers; // (several jobs of ONE phase may write disjoint rows of a column: MAVP's blocks)
     for (size_t q = 0; q < r.phases.size(); q++) {
         Phase &p = r.phases[q];
-        std::set<const void *> R[NCHAIN], W[NCHAIN];
+        // R / W: what the launches of chain c touch (its waits); RP / WP: the same per SLOT that later phases wait for -- the chain, or
+        // slot NCHAIN for the heads of the ROW chain
+        std::set<const void *> R[NCHAIN], W[NCHAIN], RP[NCHAIN + 1], WP[NCHAIN + 1];
         for (int c = 0; c < NCHAIN; c++) { p.deps[c].clear(); p.work[c] = false; }
         for (const SeqJob &j : p.seq) {
             const int c = p.chain_of[j.cls];
             p.work[c] = true;
-            for (int k = 0; k < j.nin; k++) R[c].insert(j.in[k]);
-            for (int k = 0; k < j.nout; k++) W[c].insert(j.out[k]);
-            for (int k = 0; k < 4; k++) { if (j.xr[k]) R[c].insert(j.xr[k]); if (j.xw[k]) W[c].insert(j.xw[k]); }
+            for (int k = 0; k < j.nin; k++) { R[c].insert(j.in[k]); RP[c].insert(j.in[k]); }
+            for (int k = 0; k < j.nout; k++) { W[c].insert(j.out[k]); WP[c].insert(j.out[k]); }
+            for (int k = 0; k < 4; k++) {
+                if (j.xr[k]) { R[c].insert(j.xr[k]); RP[c].insert(j.xr[k]); }
+                if (j.xw[k]) { W[c].insert(j.xw[k]); WP[c].insert(j.xw[k]); }
+            }
         }
         for (size_t k = 0; k < p.rows.size(); k++) {
             const int c = chain_of_row(p, k);
             p.work[c] = true;
-            for (int i = 0; i < p.rows[k].n_reads; i++) R[c].insert(p.rows[k].reads[i]);
-            for (int i = 0; i < p.rows[k].n_writes; i++) if (p.rows[k].writes[i]) W[c].insert(p.rows[k].writes[i]);
+            const int slot = (int)k < p.n_heads ? NCHAIN : c;
+            for (int i = 0; i < p.rows[k].n_reads; i++) { R[c].insert(p.rows[k].reads[i]); RP[slot].insert(p.rows[k].reads[i]); }
+            for (int i = 0; i < p.rows[k].n_writes; i++) if (p.rows[k].writes[i]) { W[c].insert(p.rows[k].writes[i]); WP[slot].insert(p.rows[k].writes[i]); }
         }
         for (int c = 0; c < NCHAIN; c++) {
-            int latest[NCHAIN];
-            for (int x = 0; x < NCHAIN; x++) latest[x] = -1;
-            auto need = [&](const std::pair<int, int> &d) { if (d.second != c && d.first > latest[d.second]) latest[d.second] = d.first; };
+            int latest[NCHAIN + 1];
+            for (int x = 0; x <= NCHAIN; x++) latest[x] = -1;
+            auto need = [&](const std::pair<int, int> &d) { // (an earlier phase of the same stream is ordered by the stream)
+                const int stream_of = d.second == NCHAIN ? r.phases[(size_t)d.first].row_chain : d.second;
+                if (stream_of != c && d.first > latest[d.second]) latest[d.second] = d.first;
+            };
             for (const void *col : R[c]) { auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d); }
             for (const void *col : W[c]) {
                 auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d);
                 auto ir = readers.find(col); if (ir != readers.end()) for (const auto &d : ir->second) need(d);
             }
-            for (int x = 0; x < NCHAIN; x++) if (latest[x] >= 0) p.deps[c].push_back({latest[x], x});
+            // (a wait for the whole ROW chain of a phase covers its heads)
+            if (latest[NCHAIN] >= 0 && latest[r.phases[(size_t)latest[NCHAIN]].row_chain] >= latest[NCHAIN]) latest[NCHAIN] = -1;
+            for (int x = 0; x <= NCHAIN; x++) if (latest[x] >= 0) p.deps[c].push_back({latest[x], x});
         }
-        for (int c = 0; c < NCHAIN; c++) {
-            for (const void *col : W[c]) {
+        for (int c = 0; c <= NCHAIN; c++) {
+            for (const void *col : WP[c]) {
                 auto &lw = last_w[col];
                 if (!lw.empty() && lw.front().first != (int)q) lw.clear();
                 lw.push_back({(int)q, c});
                 readers.erase(col);
             }
-            for (const void *col : R[c]) readers[col].push_back({(int)q, c});
+            for (const void *col : RP[c]) readers[col].push_back({(int)q, c});
         }
     }
 }
@@ -468,7 +438,18 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // behind the LONG grid, A/B in one session).  Measured alternatives: all ROW launches on one chain (that chain becomes the
         // critical path), the light half behind the HEAVY grid, early fractions of 0 / 0.3 / 0.7: 2 - 8 % slower per step.
         p.row_late.assign(p.rows.size(), 0);
-        if (!p.seq.empty() && !r.small) { // (a small shard: every ROW launch on the ROW chain from t = 0 -- nothing there is a tail)
+        if (r.small && pi > 0) {
+            // Small shard, later phases: a ROW launch that feeds a sequential job further on (MACD = fast - slow under MACDEXT) is a LINK and
+            // runs on the chain of the links; one that feeds nobody (ADXR from the ADX column, the hand-over check of the time-split Hilbert
+            // job, MACDEXT's histogram) is a TAIL: it goes behind the LONG grid on the caller's stream -- in front of the links, waiting for
+            // a job of the LONG grid, it would hold up the whole chain.
+            for (size_t k = 0; k < p.rows.size(); k++) {
+                bool feeds = false;
+                for (int i = 0; i < p.rows[k].n_writes; i++) feeds |= r.feeds_seq.count(p.rows[k].writes[i]) > 0;
+                if (!feeds) p.row_late[k] = 1 + CLS_LONG;
+            }
+        }
+        if (!p.seq.empty() && !r.small) { // (a small shard: every ROW launch of phase 0 on the ROW chain from t = 0 -- nothing there is a tail)
             double total = 0, early = 0;
             auto weight = [](const RowThunk &t) { return (double)(t.n_reads + t.n_writes); };
             for (const RowThunk &t : p.rows) total += weight(t);
@@ -522,23 +503,6 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
         // the longest jobs are the critical path of a step: their waves win the issue arbitration against shorter jobs on the same
         // SIMD.  Relative to the longest job of the phase (>= 0.8 / 0.58 / 0.4 of it), not to absolute microseconds.
         for (SeqJob &j : p.seq) j.prio = j.cost >= 0.8 * cmax ? 3 : j.cost >= 0.58 * cmax ? 2 : j.cost >= 0.4 * cmax ? 1 : 0;
-        // multi-job workgroups (PQ_MJ=1; suite_jobs.h): every tiled light job whose op the storer of such a workgroup can serve goes to
-        // class LONG, which then runs as ONE grid of (MJ_NC + 1)-wave workgroups; the others (row-masked outputs, epilogues) to SHORT
-        bool mj = mj_enabled() && !r.b.offsets;
-        auto mj_job = [&](const SeqJob &j) {
-            return !j.heavy && !j.masked && j.lds_bytes > 0 && !j.unal && j.summary_bytes == 0.0 && mj_kind_supported(j.kind) &&
-                   j.lds_bytes + MJ_CTL_BYTES <= prop.maxSharedMemoryPerMultiProcessor / 2;
-        };
-        for (const SeqJob &j : p.seq) if (!j.heavy && j.lds_bytes > 0 && j.unal) mj = false; // (the 8-byte form has no multi-job kernel)
-        // PQ_WIDE=<n>: light tiled jobs with at least n output columns get a SECOND storer wave (three-wave workgroups, seq_jobs_kernel<4>) on
-        // the chain of the register-heavy class, which no op uses at present -- off if the phase has a job of that class or 8-byte rows
-        int wide_min = wide_min_nout();
-        for (const SeqJob &j : p.seq) {
-            const bool bt = j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1;
-            if ((j.heavy && (j.lds_bytes > 0 || bt)) || (!j.heavy && j.lds_bytes > 0 && j.unal)) wide_min = 0;
-        }
-        if (mj || r.b.offsets) wide_min = 0;
-        p.wide = false;
         // Small shard: the chip is mostly idle, a grid ends with its longest job, and a stream runs its grids one after the other.  So the
         // jobs whose columns a LATER phase reads (the first links of the chains a composite function was taken apart into: RSI under
         // STOCHRSI, the two averages of MACDEXT) form the SHORT grid of phase 0, every job of a later phase follows on the same chain, and
@@ -556,8 +520,6 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             else if (j.lds_bytes == 0) j.cls = CLS_GATHER;
             // (the chunks of a time-split job are read by their hand-over check only -- a few microseconds behind the LONG grid: no producer)
             else if (r.small) j.cls = (pi > 0 || feeds_later(j)) ? CLS_SHORT : CLS_LONG;
-            else if (wide_min > 0 && (j.nout >= wide_min || wide_kind_listed(j.kind)) && !j.masked && j.summary_bytes == 0.0 && wide_kind_ok(j.kind)) { j.cls = CLS_HEAVY; p.wide = true; }
-            else if (mj) j.cls = mj_job(j) ? CLS_LONG : CLS_SHORT;
             else if (j.lds_bytes > THIN_LDS_MAX) j.cls = CLS_LONG;
             else if (long_wgs + tiles <= long_budget) { j.cls = CLS_LONG; long_wgs += tiles; }
             else j.cls = CLS_SHORT;
@@ -614,44 +576,6 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             }
         }
         for (int c = 0; c < NCLS; c++) { p.first[c + 1] += p.first[c]; p.gs[c].lds = p.lds[c]; }
-        if (mj && p.first[CLS_LONG + 1] > p.first[CLS_LONG]) {
-            // Groups: the jobs in order of decreasing cost (the order of the class), each into the first group that has a free compute
-            // wave and LDS left -- neighbours in cost share a workgroup, whose resources are held until its longest job ends.
-            const unsigned budget = (unsigned)(prop.maxSharedMemoryPerMultiProcessor / 2) - 1024u;
-            std::vector<MjGroup> groups;
-            std::vector<unsigned> used;
-            for (int jx = p.first[CLS_LONG]; jx < p.first[CLS_LONG + 1]; jx++) {
-                const unsigned need = (p.seq[jx].lds_bytes + 15u) & ~15u;
-                size_t gi = 0;
-                for (; gi < groups.size(); gi++)
-                    if (groups[gi].njobs < mj_width() && used[gi] + need <= budget) break;
-                if (gi == groups.size()) {
-                    MjGroup g;
-                    memset(&g, 0, sizeof g);
-                    groups.push_back(g);
-                    used.push_back(MJ_CTL_BYTES);
-                }
-                MjGroup &g = groups[gi];
-                g.job[g.njobs] = jx - p.first[CLS_LONG];
-                g.lds_off[g.njobs] = used[gi];
-                g.njobs++;
-                used[gi] += need;
-            }
-            p.n_mj = (int)groups.size();
-            p.mj_lds = 0;
-            for (unsigned u : used) p.mj_lds = std::max(p.mj_lds, u);
-            p.gs[CLS_LONG].lds = p.mj_lds;
-            PQ_HIP_TRY(hipMalloc((void **)&p.d_mj, sizeof(MjGroup) * groups.size()));
-            PQ_HIP_TRY(hipMemcpy(p.d_mj, groups.data(), sizeof(MjGroup) * groups.size(), hipMemcpyHostToDevice));
-            PQ_HIP_TRY(hipMalloc((void **)&p.d_mj_err, sizeof(unsigned)));
-            PQ_HIP_TRY(hipMemset(p.d_mj_err, 0, sizeof(unsigned)));
-            if (getenv("PQ_SUITE_DEBUG"))
-                for (size_t gi = 0; gi < groups.size(); gi++) {
-                    fprintf(stderr, "[pq suite] mj group %zu: lds %u, jobs", gi, used[gi]);
-                    for (int k = 0; k < groups[gi].njobs; k++) fprintf(stderr, " %d(kind %d)", groups[gi].job[k], p.seq[p.first[CLS_LONG] + groups[gi].job[k]].kind);
-                    fprintf(stderr, "\n");
-                }
-        }
         if (getenv("PQ_SUITE_DEBUG"))
             for (const SeqJob &j : p.seq) fprintf(stderr, "[pq suite] job kind=%d nin=%d nout=%d lds=%u cost=%d class=%d\n", j.kind, j.nin, j.nout, j.lds_bytes, j.cost, j.cls);
         PQ_HIP_TRY(hipMalloc((void **)&p.d_seq, sizeof(SeqJob) * p.seq.size()));
@@ -686,15 +610,17 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
             for (size_t i = 0; i < p.seq.size(); i++) { init[2 * i] = ~0ULL; init[2 * i + 1] = 0; }
             PQ_HIP_TRY(hipMemcpy(p.d_dbg, init.data(), 16 * p.seq.size(), hipMemcpyHostToDevice));
         }
-        bool chain_done[NCHAIN] = {};
-        bool rows_done = false;
+        auto launch_row_grid = [&](int pos, hipStream_t st) { // the fused ROW grid of a position (0: early on the phase's ROW chain; 1 + c: late on chain c)
+            if (!p.n_rows[pos]) return;
+            for (int64_t sb = 0; sb < d.n; sb += 65535) { // grid.y is limited to 65535: slice the series axis
+                const int64_t ns = d.n - sb < 65535 ? d.n - sb : 65535;
+                hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((d.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0, st,
+                                   (const RowJobDev *)p.d_rows[pos], p.n_rows[pos], d, sb);
+            }
+        };
         for (int oi = 0; oi < NCHAIN; oi++) {
-            const int cls = k_chain_order[oi];
-            const int nj = p.first[cls + 1] - p.first[cls];
-            // the ROW launches of the phase are issued with the class whose chain they share, in front of its grid
-            const bool rows_here = !rows_done && !p.rows.empty() && p.chain_of[cls] == p.row_chain && (cls == ROW_CHAIN || p.row_chain != ROW_CHAIN);
-            const int c = p.chain_of[cls]; // the chain (stream) of this class in this phase
-            if (!(nj > 0 || rows_here)) continue;
+            const int c = k_chain_order[oi]; // a CHAIN (stream) here: its early ROW launches, the grids of the classes mapped to it, its late ROW launches
+            if (!p.work[c]) continue;
             if (c != 0 && !chain_st[c]) {
                 if (!ctx->suite_aux[c]) {
                     int prio_lo = 0, prio_hi = 0;
@@ -705,21 +631,20 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
             }
             hipStream_t st = chain_st[c];
             if (!started[c]) { PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0)); started[c] = true; }
-            if (!chain_done[c]) // (two classes of one phase on one chain: the waits of the chain are issued once)
-                for (const auto &dep : p.deps[c]) PQ_HIP_TRY(hipStreamWaitEvent(st, r.phases[(size_t)dep.first].ev_done[dep.second], 0));
-            chain_done[c] = true;
-            if (rows_here) {
-                rows_done = true;
-                for (size_t k = 0; k < p.rows.size(); k++)
+            for (const auto &dep : p.deps[c]) PQ_HIP_TRY(hipStreamWaitEvent(st, r.phases[(size_t)dep.first].ev_done[dep.second], 0));
+            if (p.row_chain == c) {
+                for (size_t k = 0; k < p.rows.size(); k++) {
                     if (!p.row_late[k] && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
-                if (p.n_rows[0])
-                    for (int64_t sb = 0; sb < d.n; sb += 65535) { // grid.y is limited to 65535: slice the series axis
-                        const int64_t ns = d.n - sb < 65535 ? d.n - sb : 65535;
-                        hipLaunchKernelGGL(row_jobs_kernel, dim3((unsigned)((d.len + ROW_BLOCK - 1) / ROW_BLOCK), (unsigned)ns), dim3(ROW_BLOCK), 0, st,
-                                           (const RowJobDev *)p.d_rows[0], p.n_rows[0], d, sb);
+                    if ((int)k + 1 == p.n_heads) { // the heads of the chain are out: what waits for them need not wait for the rest
+                        if (!p.ev_done[NCHAIN]) PQ_HIP_TRY(hipEventCreateWithFlags(&p.ev_done[NCHAIN], hipEventDisableTiming));
+                        PQ_HIP_TRY(hipEventRecord(p.ev_done[NCHAIN], st));
                     }
+                }
+                launch_row_grid(0, st);
             }
-            if (nj > 0) {
+            for (int cls = 0; cls < NCLS; cls++) {
+                const int nj = p.first[cls + 1] - p.first[cls];
+                if (p.chain_of[cls] != c || nj <= 0) continue;
                 GridStat &g = p.gs[cls];
                 const bool tm = r.timing && g.runs < Recorder::MAX_TIMED_RUNS;
                 if (tm) {
@@ -737,6 +662,9 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
                 else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
                 if (tm) { PQ_HIP_TRY(hipEventRecord(g.ev[(size_t)g.runs * 2 + 1], st)); g.runs++; }
             }
+            for (size_t k = 0; k < p.rows.size(); k++)
+                if (p.row_late[k] == 1 + c && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
+            launch_row_grid(1 + c, st);
             if (!p.ev_done[c]) PQ_HIP_TRY(hipEventCreateWithFlags(&p.ev_done[c], hipEventDisableTiming));
             PQ_HIP_TRY(hipEventRecord(p.ev_done[c], st));
             last_phase[c] = (int)q;
@@ -827,19 +755,10 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
             if (nj <= 0) return PQ_OK;
             PQ_HIP_TRY(timed(p.gs[c], st, true));
             unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
-            if (c == CLS_LONG && p.n_mj > 0) {
-                PQ_TRY(mj_launch(ctx, st, p.d_seq + p.first[c], p.d_mj, p.n_mj, tiles, p.mj_lds, d, p.d_mj_err, dbg));
-                PQ_HIP_TRY(timed(p.gs[c], st, false));
-                return PQ_OK;
-            }
             const dim3 grid(tiles, (unsigned)nj);
             int v = k_variant[c];
             if (v == 0) // one job with 8-byte rows: the whole grid runs the 8-byte form (it handles aligned columns as well)
                 for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) v = 3;
-#if defined(PQ_EXPERIMENTS) && defined(PQ_EXP_WIDE)
-            if (c == CLS_HEAVY && p.wide) hipLaunchKernelGGL(seq_jobs_kernel<4>, grid, dim3(SEQ_WIDE_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
-            else
-#endif
             if (v == 3) hipLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
             else if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
             else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
@@ -942,19 +861,12 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     if (r.ev_tail) { (void)hipEventDestroy(r.ev_tail); r.ev_tail = nullptr; }
     for (Phase &p : r.phases) {
-        for (int c = 0; c < NCHAIN; c++) if (p.ev_done[c]) { (void)hipEventDestroy(p.ev_done[c]); p.ev_done[c] = nullptr; }
+        for (int c = 0; c <= NCHAIN; c++) if (p.ev_done[c]) { (void)hipEventDestroy(p.ev_done[c]); p.ev_done[c] = nullptr; }
         if (p.d_seq) (void)hipFree(p.d_seq);
         for (int pos = 0; pos <= NCHAIN; pos++)
             if (p.d_rows[pos]) { (void)hipFree(p.d_rows[pos]); p.d_rows[pos] = nullptr; p.n_rows[pos] = 0; }
         if (p.d_dbg) (void)hipFree(p.d_dbg);
         if (p.d_wg) (void)hipFree(p.d_wg);
-        if (p.d_mj) { (void)hipFree(p.d_mj); p.d_mj = nullptr; p.n_mj = 0; }
-        if (p.d_mj_err) {
-            unsigned e = 0; // (the stream was drained above) a hand-off that timed out ended its waves instead of hanging the GPU: say so
-            if (hipMemcpy(&e, p.d_mj_err, sizeof e, hipMemcpyDeviceToHost) == hipSuccess && e)
-                fprintf(stderr, "[pq] ERROR: a multi-job workgroup's hand-off timed out (code %u): the columns of this suite are incomplete\n", e);
-            (void)hipFree(p.d_mj_err); p.d_mj_err = nullptr;
-        }
         for (GridStat &g : p.gs) { for (hipEvent_t e : g.ev) (void)hipEventDestroy(e); g.ev.clear(); g.runs = 0; }
         for (hipEvent_t e : p.gs_row.ev) (void)hipEventDestroy(e);
         p.gs_row.ev.clear(); p.gs_row.runs = 0;
@@ -1120,8 +1032,6 @@ pq_status pq_suite_grid_variant(pq_suite *s, int32_t k, int32_t *variant) {
             if ((c < NCLS ? p.gs[c] : p.gs_row).n_jobs == 0) continue;
             if (idx++ != k) continue;
             *variant = c < NCLS ? k_variant[c] : 3; // 3 = the chain of ROW launches
-            if (c == CLS_LONG && p.n_mj > 0) { *variant = 5; return PQ_OK; } // 5 = seq_mj_kernel (multi-job workgroups)
-            if (c == CLS_HEAVY && p.wide) { *variant = 6; return PQ_OK; }    // 6 = seq_jobs_kernel<4> (two storers per workgroup)
             if (c < NCLS && k_variant[c] == 0)
                 for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) *variant = 4; // 4 = seq_jobs_kernel<3>: the 8-byte form of the tiled body
             return PQ_OK;

@@ -1,5 +1,4 @@
-// suite_jobs.h -- what the job-grid translation units share (suite.hip: recording, scheduling, the classic two-wave job kernels;
-// suite_mj.hip: the multi-job workgroups): the device-visible job record, the list of recordable ops, the register cap.
+// suite_jobs.h -- the device-visible job record of the job grids (suite.hip), the list of recordable ops, the register cap.
 #pragma once
 #include "ops_backtest.h"
 #include "ops_fused.h"
@@ -36,7 +35,7 @@ static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma32Op)                                          \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma8Op) X(MavpSma32Op) X(RollSum6Op)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(HtAll6Op) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp) X(SmaDupOp)
 #if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
@@ -59,26 +58,3 @@ static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
 #ifndef PQ_NV0
 #define PQ_NV0 96
 #endif
-
-// ---- multi-job workgroups (suite_mj.hip) -------------------------------------------------------------------------------------------
-// A workgroup of MJ_NC + 1 wavefronts takes up to MJ_NC different jobs through the SAME 64-symbol tile: MJ_NC compute waves (each loads
-// its own input tiles and walks its op exactly as in the two-wave form) and ONE storer wave that drains the finished out tiles of all of
-// them.  Why: in the two-wave form every job owns a storer, all 192 registers of it; a CU holds four jobs = four compute waves (one per
-// SIMD) and four storers.  The wide cheap jobs (MACD pair, EMA x 4, the DM system) keep their storer busy and their compute wave idle,
-// the narrow expensive ones (MAMA, the Hilbert pipeline, KAMA) the other way round, and neither can lend the other its idle wave:
-// measured at HEAD, a step without arithmetic takes 3.45 ms, without input loads 3.52, without either 2.78, with both 3.95
-// (profiles/r05_ab_noload_nocompute.txt) -- the parts add up instead of overlapping.  With one storer per three jobs a CU holds SIX
-// compute waves (two workgroups of 4 x 192 registers), and a storer is busy whenever ANY of its three jobs has a tile ready.
-// Hand-off: per compute wave a pair of counters in LDS (MjCtl, pq_dev.h), no workgroup barrier after the first.
-constexpr int MJ_NC = 3;
-struct MjGroup {
-    int njobs;
-    int job[MJ_NC];           // indices into the phase's job array
-    unsigned lds_off[MJ_NC];  // byte offset of the job's LDS region (tiles, then rings) inside the workgroup's allocation
-};
-constexpr unsigned MJ_CTL_BYTES = 256; // MjCtl[MJ_NC] at the start of the allocation
-template <class Op>
-struct MjOk { static constexpr bool value = !IsMasked<Op>::value && !HasFinish<Op>::value && !IsHeavy<Op>::value && NDer<Op>::value <= 3; };
-bool mj_kind_supported(int kind);
-pq_status mj_launch(pq_ctx *ctx, hipStream_t st, const SeqJob *d_jobs, const MjGroup *d_groups, int n_groups, unsigned tiles, unsigned lds_bytes,
-                    Dims d, unsigned *d_err, unsigned long long *dbg);

@@ -319,9 +319,7 @@ class Suite:
             var = C.c_int32()
             check(lib().pq_suite_grid_variant(self._suite, k, C.byref(var)))
             out.append({"avg_ms": ms.value, "alg_bytes": by.value, "n_jobs": nj.value, "lds_bytes": lds.value, "runs": runs.value,
-                        "kernel": f"seq_jobs_kernel<{var.value}>" if var.value < 3 else ("seq_jobs_kernel<3>" if var.value == 4 else
-                                                                                          "seq_mj_kernel" if var.value == 5 else
-                                                                                          "seq_jobs_kernel<4>" if var.value == 6 else "row_chain")})
+                        "kernel": f"seq_jobs_kernel<{var.value}>" if var.value < 3 else ("seq_jobs_kernel<3>" if var.value == 4 else "row_chain")})
             k += 1
         return out
 

@@ -8,11 +8,11 @@ cd /root/repo/polars_quant_amd/csrc
 mkdir -p /root/repo/ab /tmp/ab_$1
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -Wno-parentheses"
 if [ "$3" = all ]; then
-  for f in runtime wt overlap momentum misc pattern backtest fused suite suite_mj factor plugin comm strategy; do /opt/rocm/bin/hipcc $F $2 -c $f.hip -o /tmp/ab_$1/$f.o & done; wait
+  for f in runtime wt overlap momentum misc pattern backtest fused suite factor plugin comm strategy; do /opt/rocm/bin/hipcc $F $2 -c $f.hip -o /tmp/ab_$1/$f.o & done; wait
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o /root/repo/ab/libpq_$1.so /tmp/ab_$1/*.o -ldl
 else
   TU=${3:-suite}   # the one TU to rebuild with the flags (default: suite.hip)
   /opt/rocm/bin/hipcc $F $2 -c $TU.hip -o /tmp/ab_$1/$TU.o
-  OBJS=""; for f in runtime wt overlap momentum misc pattern backtest fused factor plugin suite suite_mj comm strategy; do if [ $f = $TU ]; then OBJS="$OBJS /tmp/ab_$1/$TU.o"; else OBJS="$OBJS $f.o"; fi; done
+  OBJS=""; for f in runtime wt overlap momentum misc pattern backtest fused factor plugin suite comm strategy; do if [ $f = $TU ]; then OBJS="$OBJS /tmp/ab_$1/$TU.o"; else OBJS="$OBJS $f.o"; fi; done
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o /root/repo/ab/libpq_$1.so $OBJS -ldl
 fi

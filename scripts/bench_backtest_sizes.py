@@ -1,7 +1,7 @@
 """One-wave against four-wave form of pq_backtest_macd_cross over batch sizes (PQ_BT_WAVES forced per run): where the library's
 choice of the form comes from (csrc/backtest.hip, bt_wave)."""
 import os, sys, ctypes as C
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from polars_quant_amd import api
 from polars_quant_amd._lib import Batch, BtParams, check, lib

@@ -3,7 +3,7 @@ run with PQ_LIB_PATH=ab/libpq_btwprof.so).  Prints mean microseconds per wave: l
 import ctypes as C
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 
 from polars_quant_amd import api

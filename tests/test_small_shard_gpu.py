@@ -40,8 +40,10 @@ def _compare_everything(pq, oracle, d, st, ch=320):
             hi = lo + sub["close"].shape[0]
             for name in pq.SPEC:
                 for (oname, _), got in zip(pq.SPEC[name][2], st.out[name]):
+                    # (the price level is the scale of the phasor components: rows whose price is NaN / inf are judged against |expected| alone --
+                    #  the pipeline's outputs lag its input by three rows, so such rows can still hold finite values)
                     assert_same(f"{name}.{oname}{{{lo}:{hi}}}", got[lo:hi].cpu().numpy(), res[(name, oname)],
-                                exact=name not in TRANSCENDENTAL, price=sub["close"])
+                                exact=name not in TRANSCENDENTAL, price=np.nan_to_num(sub["close"], nan=0.0, posinf=0.0, neginf=0.0))
                     compared += 1
             for nm in pq.PATTERN_NAMES:
                 assert (st.pat[nm][lo:hi].cpu().numpy() == res[("pattern", nm)]).all(), (nm, lo)
@@ -94,8 +96,10 @@ def test_small_shard_suite_every_output_of_every_symbol(pq, oracle, N):
 
 def test_small_shard_fallbacks_nulls_nans_infinities_and_flat_series(pq, oracle):
     """series that the fast forms must hand to their gated general paths: a NaN that a later Hilbert chunk never sees (row 100), one
-    inside a warm-up (row 1 000), an infinity, a NULL, values beyond MAMA's finiteness bound, a flat series (the period recurrence sits
-    on its clamps), a series that is flat until row 1 300 -- on tiles 0, 1, 2 and the last, partial one; tile 3 stays clean"""
+    inside a warm-up (row 1 000), an infinity, a run of NaNs as long as a chunk, values beyond MAMA's finiteness bound, a flat series (the
+    period recurrence sits on its clamps), a series that is flat until row 1 300 -- on tiles 0, 1, 2 and the last, partial one; tile 3
+    stays clean.  (NaN VALUES, not NULLs: the momentum / cycle family of the reference refuses a column with nulls -- `cont_slice()?`,
+    momentum.rs:141-143 -- so a NULL is outside the domain of half of the suite; MAMA's null rule has its own test below.)"""
     from polars_quant_amd.suite import Suite
     N = 330
     d = oracle.gen_ohlcv(0x5EED0601, N, TT, 0)
@@ -106,13 +110,13 @@ def test_small_shard_fallbacks_nulls_nans_infinities_and_flat_series(pq, oracle)
     poke(3, 100, np.nan)
     poke(70, 1000, np.nan)
     poke(71, 1500, np.inf)
-    poke(130, 900, NULL)
+    poke(130, 900, np.nan, cols=("high",))
     poke(131, 2519, np.nan)
     for c in ("open", "high", "low", "close"):
         d[c][140] *= 1e200          # beyond MAMA's finiteness bound: the pipeline overflows, the walk decides
         d[c][5] = 100.0             # flat
         d[c][329, :1300] = 50.0     # flat, then moving
-    d["close"][328, 640:1280] = NULL  # a chunk's worth of NULL rows
+    d["close"][328, 640:1280] = np.nan  # a chunk's worth of NaN rows
     g = _pitched(d, STRIDE)
     st = Suite(N, TT, "cuda:0", stride=STRIDE)
     st.record(g)
@@ -131,7 +135,7 @@ def test_mama_at_the_wrappers_default_limits_is_the_walks_result(pq, oracle):
     for n, T in ((130, 400), (70, 31), (70, 32), (3, 2520)):
         d = oracle.gen_ohlcv(0x5EED0602 + T, n, T, 0)
         x = d["close"].copy()
-        if T >= 400:
+        if T >= 400 and n > 66:
             x[1, 50] = np.nan; x[64, 399] = np.inf; x[65, 0] = NULL; x[2] *= 1e150; x[66] *= 1e139
         for fl, sl in ((0.0, 0.0), (0.0, 0.05), (-0.0, 0.0), (0.0, float("nan"))):
             exp = oracle.call("mama", x, fastlimit=fl, slowlimit=sl)
