@@ -107,19 +107,10 @@ pq_status pq_ultosc(pq_ctx *ctx, const pq_batch *b, const double *h, const doubl
                     int64_t p2, int64_t p3, double *out) {
     CHK("pq_ultosc", h && l && c && out);
     UltoscOp op{}; op.p1 = p1; op.p2 = p2; op.p3 = p3;
-    if (ctx->rec && ctx->rec_small && p1 > 0 && p2 > 0 && p3 > 0 && !getenv("PQ_NO_ULTOSC_CHAIN")) {
-        // a small-shard recording: bp / tr by a ROW kernel, the six running sums by one short job, the quotients by a ROW kernel (ops_momentum.h)
-        RollSum6Op rs{}; rs.p1 = p1; rs.p2 = p2; rs.p3 = p3;
-        PQ_WS_COL(bp, ctx, b, 0); PQ_WS_COL(tr, ctx, b, 1);
-        InCols<2> in{{bp, tr}};
-        OutCols<6> sums{};
-        for (int k = 0; k < 6; k++) { sums.p[k] = pq_ws_col(ctx, b, 2 + k); if (!sums.p[k]) { pq_set_error("out of device memory for a scratch column"); return PQ_ERR_NOMEM; } }
-        if (seq_can_lds(ctx, b, rs, in, sums)) {
-            PQ_TRY(launch_row(ctx, b, UltBpTrOp{}, InCols<3>{{h, l, c}}, OutColsT<UltBpTrOp, double>{{bp, tr}}));
-            PQ_TRY(launch_seq(ctx, b, rs, in, sums));
-            UltCombineOp cb{}; cb.p1 = p1; cb.p2 = p2; cb.p3 = p3;
-            return launch_row(ctx, b, cb, InCols<6>{{sums.p[0], sums.p[1], sums.p[2], sums.p[3], sums.p[4], sums.p[5]}}, OutColsT<UltCombineOp, double>{{out}});
-        }
+    if (ctx->rec && ctx->rec_small) { // a small-shard recording: 8-row tiles (LDS is free there; half the per-tile fills and hand-offs of the longest job)
+        UltoscOp8 op8{}; op8.p1 = p1; op8.p2 = p2; op8.p3 = p3;
+        InCols<3> in{{h, l, c}}; OutCols<1> o{{out}};
+        if (seq_can_lds(ctx, b, op8, in, o)) return launch_seq(ctx, b, op8, in, o);
     }
     return launch_seq(ctx, b, op, InCols<3>{{h, l, c}}, OutCols<1>{{out}});
 }

@@ -332,11 +332,12 @@ struct TrixOp { // momentum.rs:544-569 (quirk Q-TRIX)
     }
 };
 
-struct UltoscOp { // momentum.rs:572-627
+template <int TK> // rows per tile: 4 on a full chip (LDS: four workgroups per CU); 8 for SMALL shards, where LDS is free and the per-tile costs count
+struct UltoscOpK { // momentum.rs:572-627
     static constexpr int NIN = 3, NOUT = 1; // high, low, close
-    static constexpr int SEQ_ID = 24;
+    static constexpr int SEQ_ID = TK == 4 ? 24 : 87;
     static constexpr int COST_NS = 517;
-    static constexpr int TILE_K = 4; // 4-row tiles: 36.4 KB instead of 42.5 KB with the default periods, i.e. 4 workgroups per CU
+    static constexpr int TILE_K = TK; // 4-row tiles: 36.4 KB instead of 42.5 KB with the default periods, i.e. 4 workgroups per CU
     static constexpr int NTAP = 12; // per window: high, low, close at i-p and close at i-p-1
     static constexpr int TAP_COL[12] = {0, 1, 2, 2, 0, 1, 2, 2, 0, 1, 2, 2};
     int64_t p1, p2, p3;
@@ -423,76 +424,8 @@ struct UltoscOp { // momentum.rs:572-627
     }
 };
 
-// ULTOSC taken apart for SMALL shards (momentum.hip pq_ultosc): the fused op above is 1.2 ms of a lone wavefront there, four IEEE divisions
-// per row among its ~140 instructions; only its six running sums are a recurrence.  So: a ROW kernel writes the buying pressure and the
-// true range (row-wise functions of high / low / close and the previous close), ONE sequential job advances the six sums -- the same
-// add-new / subtract-old sequence as UltoscOp, from the same ring taps --, a ROW kernel forms the quotients.  Same operations on the same
-// values in the same order: bit-identical to UltoscOp.
-struct UltBpTrOp {
-    static constexpr int NIN = 3, NOUT = 2; // high, low, close -> bp, tr (row 0: 0.0, 0.0 as in UltoscOp)
-    typedef double OutT;
-    __device__ void eval(const Row<3> &r, int64_t i, double (&y)[2]) {
-        y[0] = y[1] = 0.0;
-        if (i >= 1) UltoscOp::bptr(r.in[0][i], r.in[1][i], r.in[2][i], r.in[2][i - 1], y[0], y[1]);
-    }
-};
-struct RollSum6Op {
-    static constexpr bool LDS_ONLY = true;
-    static constexpr int NIN = 2, NOUT = 6; // bp, tr -> sum_bp(p1), sum_tr(p1), sum_bp(p2), sum_tr(p2), sum_bp(p3), sum_tr(p3)
-    static constexpr int SEQ_ID = 87;
-    static constexpr int COST_NS = 160;
-    int64_t p1, p2, p3;
-    double sb[3], st[3];
-    Ring wb, wt;
-    __host__ __device__ int64_t pmax() const { int64_t a = p1 > p2 ? p1 : p2; return a > p3 ? a : p3; }
-    __host__ __device__ int64_t ring_slots() const { return pmax() > 0 ? 2 * pmax() : 2; }
-    __device__ void init(const Row<2> &) {}
-    __device__ void init_lds(const Row<2> &, RingAlloc &ra) {
-        for (int k = 0; k < 3; k++) sb[k] = st[k] = 0.0;
-        wb = ra.make(pmax()); wt = ra.make(pmax());
-    }
-    __device__ void step(const Row<2> &, int64_t, const double (&)[2], double (&y)[6]) { for (int k = 0; k < 6; k++) y[k] = pq_null(); }
-    __device__ void step_lds(int64_t i, const double (&x)[2], double (&y)[6]) {
-        const int64_t ps[3] = {p1, p2, p3};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            sb[k] += x[0]; st[k] += x[1];
-            if (i >= ps[k]) { sb[k] -= wb.get((int)ps[k]); st[k] -= wt.get((int)ps[k]); } // bp / tr of row i - p
-            y[2 * k] = sb[k]; y[2 * k + 1] = st[k];
-        }
-        wb.push(x[0]); wt.push(x[1]);
-    }
-    static constexpr bool FAST_NULL_OK = true; // N-B
-    static constexpr bool HAS_FAST = true;
-    __device__ bool steady(int64_t t0) const { return t0 >= pmax(); }
-    __device__ void step_fast(int64_t, const double (&x)[2], double (&y)[6]) {
-        const int64_t ps[3] = {p1, p2, p3};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            sb[k] += x[0]; st[k] += x[1];
-            sb[k] -= wb.get((int)ps[k]); st[k] -= wt.get((int)ps[k]);
-            y[2 * k] = sb[k]; y[2 * k + 1] = st[k];
-        }
-        wb.push(x[0]); wt.push(x[1]);
-    }
-};
-struct UltCombineOp {
-    static constexpr int NIN = 6, NOUT = 1;
-    typedef double OutT;
-    int64_t p1, p2, p3;
-    __device__ void eval(const Row<6> &r, int64_t i, double (&y)[1]) {
-        y[0] = pq_null();
-        const int64_t ps[3] = {p1, p2, p3};
-        double a[3];
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double sbk = r.in[2 * k][i], stk = r.in[2 * k + 1][i];
-            if (i >= ps[k] - 1 && stk != 0.0) a[k] = sbk / stk; else { a[k] = 0.0; ok = false; }
-        }
-        if (ok) y[0] = 100.0 * (4.0 * a[0] + 2.0 * a[1] + a[2]) / 7.0;
-    }
-};
+typedef UltoscOpK<4> UltoscOp;
+typedef UltoscOpK<8> UltoscOp8;
 
 struct MfiOp { // momentum.rs:286-342
     static constexpr int NIN = 4, NOUT = 1; // high, low, close, volume

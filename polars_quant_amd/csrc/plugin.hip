@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -255,15 +256,48 @@ static pq_status plan_layout(pq_ctx *ctx, const pq_series_export *key, int64_t n
     L->n = n; L->groups = 1; L->glen = n; L->pitch = n; L->pitched = false; L->d_off = nullptr;
     L->b = pq_batch{1, n, n, nullptr};
     if (!key) return PQ_OK;
-    std::vector<KeyRef> k;
-    if (!key_refs(*key, n, k)) { pq_set_error("plugin: the key column of an _over call must be an integer, float, string or dictionary column of the frame's length"); return PQ_ERR_ARG; }
     std::vector<int64_t> off;
     off.push_back(0);
     int64_t longest = 0;
-    for (int64_t i = 1; i <= n; i++) {
-        const bool same = i < n && k[(size_t)i].null == k[(size_t)i - 1].null &&
-                          (k[(size_t)i].null || (k[(size_t)i].len == k[(size_t)i - 1].len && !memcmp(k[(size_t)i].p, k[(size_t)i - 1].p, (size_t)k[(size_t)i].len)));
-        if (!same) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
+    // The usual key -- ONE chunk of a fixed-width type without nulls (an integer symbol id, a date) -- is scanned in place: neighbours
+    // compared as raw words, 12.6 M rows in a few milliseconds.  (Through the general KeyRef list below the same scan builds a 300 MB
+    // vector first and memcmp()s every row: ~100 ms of a 120 ms `_over` call on a 5 000 x 2 520 frame, scripts/bench_plugin.py.)
+    bool scanned = false;
+    if (key->len == 1 && key->field && key->field->format && key->field->format[0] && !key->field->format[1] && key->arrays && key->arrays[0]) {
+        const ArrowArray *a = key->arrays[0];
+        int width = 0;
+        switch (key->field->format[0]) {
+        case 'c': case 'C': width = 1; break;
+        case 's': case 'S': width = 2; break;
+        case 'i': case 'I': case 'f': width = 4; break;
+        case 'l': case 'L': case 'g': width = 8; break;
+        default: break;
+        }
+        if (width && a->length == n && a->n_buffers >= 2 && a->buffers[1] && (a->null_count == 0 || !a->buffers[0])) {
+            auto scan = [&](auto *p) {
+                for (int64_t i = 1; i < n; i++)
+                    if (p[i] != p[i - 1]) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
+            };
+            const uint8_t *base = (const uint8_t *)a->buffers[1] + (size_t)a->offset * (size_t)width;
+            switch (width) { // (floats too are compared as words: the general path compares their bytes)
+            case 1: scan((const uint8_t *)base); break;
+            case 2: scan((const uint16_t *)base); break;
+            case 4: scan((const uint32_t *)base); break;
+            default: scan((const uint64_t *)base); break;
+            }
+            longest = std::max<int64_t>(longest, n - off.back());
+            off.push_back(n);
+            scanned = true;
+        }
+    }
+    if (!scanned) {
+        std::vector<KeyRef> k;
+        if (!key_refs(*key, n, k)) { pq_set_error("plugin: the key column of an _over call must be an integer, float, string or dictionary column of the frame's length"); return PQ_ERR_ARG; }
+        for (int64_t i = 1; i <= n; i++) {
+            const bool same = i < n && k[(size_t)i].null == k[(size_t)i - 1].null &&
+                              (k[(size_t)i].null || (k[(size_t)i].len == k[(size_t)i - 1].len && !memcmp(k[(size_t)i].p, k[(size_t)i - 1].p, (size_t)k[(size_t)i].len)));
+            if (!same) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
+        }
     }
     bool uniform = off.size() >= 2;
     for (size_t i = 1; uniform && i < off.size(); i++) uniform = off[i] - off[i - 1] == longest;
@@ -287,6 +321,107 @@ static pq_status upload_col(pq_ctx *ctx, const Layout &L, const void *host, size
     if (L.pitched) PQ_HIP_TRY(hipMemsetAsync(*d, 0, L.dev_elems() * elem, ctx->stream));
     if (L.pitched) return pq_memcpy_h2d_pitched(ctx, *d, (size_t)L.pitch * elem, host, (size_t)L.glen * elem, (size_t)L.glen * elem, (size_t)L.groups);
     return pq_memcpy_h2d(ctx, *d, host, (size_t)L.n * elem);
+}
+// ---- input-column cache ------------------------------------------------------------------------------------------------------------
+// Polars evaluates the sixty expressions of one `with_columns` one plugin call each, and every call that reads `close` hands over the
+// SAME Arrow buffer (python/polars_quant/talib/momentum.py:13-16): gathered and uploaded again each time, 100 MB per column of a
+// 5 000 x 2 520 frame.  A Float64 column that arrives as one chunk without nulls is therefore (i) uploaded straight from its Arrow
+// buffer -- no host copy -- and (ii) kept: the device copy is remembered under (buffer address, rows, layout of the call) together with a
+// 64-bit hash of the WHOLE buffer, and a later call with the same key and the same hash uses it.  The hash is recomputed on every call
+// (memory-bound, ~10 ms per 100 MB against ~40 ms for gather + pageable upload), so a freed-and-reused address with other content can
+// not alias: other bytes, other hash, a miss.  Shared by the host threads Polars calls from (a mutex; an entry is published after its
+// creator's stream has been drained, is never freed while a call uses it, least recently used entries go when PQ_PLUGIN_CACHE_MB --
+// default 2 048, 0 = no cache -- is exceeded).
+struct CacheEntry {
+    const void *addr; int64_t n, groups, glen, pitch; uint64_t hash;
+    void *d; size_t bytes; int in_use; uint64_t tick;
+};
+static std::mutex g_cache_mu;
+static std::vector<CacheEntry> g_cache;
+static size_t g_cache_bytes = 0;
+static uint64_t g_cache_tick = 0;
+static int64_t g_cache_hits = 0, g_cache_misses = 0;
+static size_t cache_limit() {
+    const char *e = getenv("PQ_PLUGIN_CACHE_MB");
+    return (size_t)(e ? atoll(e) : 2048) << 20;
+}
+static uint64_t hash_bytes(const void *p, size_t nbytes) { // four interleaved multiply-rotate lanes over 8-byte words, then a mix
+    const uint64_t K = 0x9E3779B97F4A7C15ULL;
+    uint64_t h[4] = {0x243F6A8885A308D3ULL, 0x13198A2E03707344ULL, 0xA4093822299F31D0ULL, 0x082EFA98EC4E6C89ULL};
+    const uint8_t *b = (const uint8_t *)p;
+    size_t i = 0;
+    for (; i + 32 <= nbytes; i += 32) {
+        uint64_t w[4];
+        memcpy(w, b + i, 32);
+        for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * K; h[k] = (h[k] << 29) | (h[k] >> 35); }
+    }
+    uint64_t tail[4] = {0, 0, 0, 0};
+    memcpy(tail, b + i, nbytes - i);
+    for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ tail[k]) * K; h[k] ^= h[k] >> 32; }
+    uint64_t r = (uint64_t)nbytes * K;
+    for (int k = 0; k < 4; k++) { r = (r ^ h[k]) * K; r ^= r >> 29; }
+    return r;
+}
+struct InCol { void *d = nullptr; bool owned = false, publish = false; int hit = 0; CacheEntry key{}; };
+// one chunk of Float64 without nulls: its values buffer IS the flat host column
+static const double *flat_f64(const pq_series_export &in, int64_t n) {
+    if (in.len != 1 || !in.field || !in.field->format || strcmp(in.field->format, "g")) return nullptr;
+    const ArrowArray *a = in.arrays[0];
+    if (!a || a->length != n || a->n_buffers < 2 || !a->buffers[1]) return nullptr;
+    if (a->null_count != 0 && a->buffers[0]) return nullptr;
+    return (const double *)a->buffers[1] + a->offset;
+}
+static pq_status cached_input(pq_ctx *ctx, const Layout &L, const double *src, int64_t n, InCol *ic) {
+    CacheEntry &k = ic->key;
+    k.addr = src; k.n = n;
+    k.groups = L.pitched ? L.groups : 1; k.glen = L.pitched ? L.glen : n; k.pitch = L.pitched ? L.pitch : n;
+    const size_t limit = cache_limit();
+    if (limit) {
+        k.hash = hash_bytes(src, (size_t)n * 8);
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        for (CacheEntry &e : g_cache)
+            if (e.addr == k.addr && e.n == k.n && e.groups == k.groups && e.glen == k.glen && e.pitch == k.pitch && e.hash == k.hash) {
+                e.in_use++; e.tick = ++g_cache_tick; g_cache_hits++;
+                ic->d = e.d; ic->hit = 1;
+                return PQ_OK;
+            }
+        g_cache_misses++;
+    }
+    PQ_TRY(upload_col(ctx, L, src, 8, &ic->d)); // straight from the Arrow buffer
+    ic->owned = true;
+    ic->publish = limit && L.dev_elems() * 8 <= limit;
+    return PQ_OK;
+}
+// after the call's stream has been drained (`synced`): publish / release / free the device copies of the inputs
+static void inputs_done(pq_ctx *ctx, InCol *ic, int n_in, const Layout &L, bool synced) {
+    for (int k = 0; k < n_in; k++) {
+        InCol &c = ic[k];
+        if (c.hit) {
+            std::lock_guard<std::mutex> g(g_cache_mu);
+            for (CacheEntry &e : g_cache) if (e.d == c.d) { e.in_use--; break; }
+        } else if (c.owned && c.publish && synced && c.d) {
+            std::vector<void *> drop;
+            {
+                std::lock_guard<std::mutex> g(g_cache_mu);
+                CacheEntry e = c.key;
+                e.d = c.d; e.bytes = L.dev_elems() * 8; e.in_use = 0; e.tick = ++g_cache_tick;
+                g_cache.push_back(e);
+                g_cache_bytes += e.bytes;
+                const size_t limit = cache_limit();
+                while (g_cache_bytes > limit) { // least recently used entry that no call holds
+                    int victim = -1;
+                    for (size_t i = 0; i < g_cache.size(); i++)
+                        if (!g_cache[i].in_use && g_cache[i].d != c.d && (victim < 0 || g_cache[i].tick < g_cache[(size_t)victim].tick)) victim = (int)i;
+                    if (victim < 0) break;
+                    drop.push_back(g_cache[(size_t)victim].d);
+                    g_cache_bytes -= g_cache[(size_t)victim].bytes;
+                    g_cache.erase(g_cache.begin() + victim);
+                }
+            }
+            for (void *q : drop) (void)pq_free(ctx, q);
+        } else if (c.owned && c.d) (void)pq_free(ctx, c.d);
+        c = InCol{};
+    }
 }
 static pq_status download_col(pq_ctx *ctx, const Layout &L, const void *d, size_t elem, void *host) {
     if (L.pitched) return pq_memcpy_d2h_pitched(ctx, host, (size_t)L.glen * elem, d, (size_t)L.pitch * elem, (size_t)L.glen * elem, (size_t)L.groups);
@@ -327,7 +462,9 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
     std::vector<double> host[4];
     std::vector<uint8_t> valid[4];
     bool nulls[4] = {false, false, false, false}, any_null = false;
+    const double *flat[4] = {nullptr, nullptr, nullptr, nullptr}; // one Float64 chunk without nulls: used in place (and cached), no gather
     for (int k = 0; k < f.nin; k++) {
+        if ((flat[k] = flat_f64(inputs[k], n))) continue;
         if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed input chunk"); return; }
         any_null |= nulls[k];
     }
@@ -341,12 +478,18 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
         void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
+        InCol ic[4];
         Layout lay;
         pq_status st = plan_layout(ctx, over ? &inputs[f.nin] : nullptr, n, &lay);
         if (st == PQ_OK) st = pq_malloc(ctx, lay.dev_elems() * 8, &d_out);
         for (int k = 0; k < f.nin && st == PQ_OK; k++) {
-            if (nulls[k]) nulls_into_host(host[k], valid[k], n);
-            st = upload_col(ctx, lay, host[k].data(), 8, &d_in[k]);
+            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k]);
+            else {
+                if (nulls[k]) nulls_into_host(host[k], valid[k], n);
+                st = upload_col(ctx, lay, host[k].data(), 8, &ic[k].d);
+                ic[k].owned = true;
+            }
+            d_in[k] = ic[k].d;
         }
         const double *cols[4] = {(const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3]};
         if (st == PQ_OK) st = f.call(ctx, &lay.b, cols, pv, d_out);
@@ -362,7 +505,8 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
             if (st == PQ_OK) null_count = validity_from_host(op->values, n, op->validity);
         }
         if (st == PQ_OK) st = pq_ctx_sync(ctx);
-        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, lay.d_off}) if (q) (void)pq_free(ctx, q);
+        inputs_done(ctx, ic, 4, lay, st == PQ_OK);
+        for (void *q : {d_out, lay.d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail(f.name); return; }
     }
     ArrowArray *arr = new ArrowArray();
@@ -449,8 +593,10 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
     std::vector<double> host[2];
     std::vector<uint8_t> valid[2];
     bool nulls[2] = {false, false}, any_null = false;
+    const double *flat[2] = {nullptr, nullptr};
     for (int k = 0; k < f.nin; k++) {
         if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
+        if ((flat[k] = flat_f64(inputs[k], n))) continue;
         if (!gather_f64(inputs[k], n, host[k], valid[k], nulls[k])) { plugin_fail("plugin: malformed input chunk"); return; }
         any_null |= nulls[k];
     }
@@ -467,12 +613,18 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { drop(); plugin_fail("plugin: no HIP device / context"); return; }
         void *d_in[2] = {nullptr, nullptr}, *d_out[3] = {nullptr, nullptr, nullptr};
+        InCol ic[2];
         Layout lay;
         pq_status st = plan_layout(ctx, over ? &inputs[f.nin] : nullptr, n, &lay);
         for (int k = 0; k < f.nout && st == PQ_OK; k++) st = pq_malloc(ctx, lay.dev_elems() * 8, &d_out[k]);
         for (int k = 0; k < f.nin && st == PQ_OK; k++) {
-            if (nulls[k]) nulls_into_host(host[k], valid[k], n);
-            st = upload_col(ctx, lay, host[k].data(), 8, &d_in[k]);
+            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k]);
+            else {
+                if (nulls[k]) nulls_into_host(host[k], valid[k], n);
+                st = upload_col(ctx, lay, host[k].data(), 8, &ic[k].d);
+                ic[k].owned = true;
+            }
+            d_in[k] = ic[k].d;
         }
         const double *cols[2] = {(const double *)d_in[0], (const double *)d_in[1]};
         double *outs[3] = {(double *)d_out[0], (double *)d_out[1], (double *)d_out[2]};
@@ -480,7 +632,8 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
         for (int k = 0; k < f.nout && st == PQ_OK; k++) st = download_col(ctx, lay, d_out[k], 8, op[k]->values.data());
         if (st == PQ_OK) st = pq_ctx_sync(ctx);
         for (int k = 0; k < f.nout && st == PQ_OK; k++) null_count[k] = validity_from_host(op[k]->values, n, op[k]->validity);
-        for (void *q : {d_in[0], d_in[1], d_out[0], d_out[1], d_out[2], lay.d_off}) if (q) (void)pq_free(ctx, q);
+        inputs_done(ctx, ic, 2, lay, st == PQ_OK);
+        for (void *q : {d_out[0], d_out[1], d_out[2], lay.d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { drop(); plugin_fail(f.name); return; }
     }
     StructPriv *sp = new StructPriv();
@@ -526,8 +679,10 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
     std::vector<double> host[4];
     std::vector<uint8_t> valid;
     bool any_null = false;
+    const double *flat[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int k = 0; k < 4; k++) {
         if (series_len(inputs[k]) != n) { plugin_fail("plugin: the input Series differ in length"); return; }
+        if ((flat[k] = flat_f64(inputs[k], n))) continue;
         if (!gather_f64(inputs[k], n, host[k], valid, any_null)) { plugin_fail("plugin: malformed input chunk"); return; }
     }
     if (any_null) { plugin_fail("plugin: the input contains nulls (this function rejects them, as the reference's cont_slice() does)"); return; }
@@ -537,14 +692,20 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
         pq_ctx *ctx = plugin_ctx();
         if (!ctx) { delete op; plugin_fail("plugin: no HIP device / context"); return; }
         void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
+        InCol ic[4];
         Layout lay;
         pq_status st = plan_layout(ctx, over ? &inputs[4] : nullptr, n, &lay);
         if (st == PQ_OK) st = pq_malloc(ctx, lay.dev_elems() * 4, &d_out);
-        for (int k = 0; k < 4 && st == PQ_OK; k++) st = upload_col(ctx, lay, host[k].data(), 8, &d_in[k]);
+        for (int k = 0; k < 4 && st == PQ_OK; k++) {
+            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k]);
+            else { st = upload_col(ctx, lay, host[k].data(), 8, &ic[k].d); ic[k].owned = true; }
+            d_in[k] = ic[k].d;
+        }
         if (st == PQ_OK) st = pq_cdl(ctx, &lay.b, id, (const double *)d_in[0], (const double *)d_in[1], (const double *)d_in[2], (const double *)d_in[3], pen, (int32_t *)d_out);
         if (st == PQ_OK) st = download_col(ctx, lay, d_out, 4, op->ivalues.data());
         if (st == PQ_OK) st = pq_ctx_sync(ctx);
-        for (void *q : {d_in[0], d_in[1], d_in[2], d_in[3], d_out, lay.d_off}) if (q) (void)pq_free(ctx, q);
+        inputs_done(ctx, ic, 4, lay, st == PQ_OK);
+        for (void *q : {d_out, lay.d_off}) if (q) (void)pq_free(ctx, q);
         if (st != PQ_OK) { delete op; plugin_fail("pq_cdl"); return; }
     }
     ArrowArray *arr = new ArrowArray();
@@ -570,6 +731,25 @@ void field_f64(ArrowSchema *fields, size_t n_fields, ArrowSchema *ret) {
 } // namespace
 
 extern "C" {
+// the input-column cache (above): counters since the library was loaded / the last clear; clear = free every entry no call holds
+void pq_plugin_cache_stats(int64_t *hits, int64_t *misses, int64_t *bytes, int64_t *entries) {
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    if (hits) *hits = g_cache_hits;
+    if (misses) *misses = g_cache_misses;
+    if (bytes) *bytes = (int64_t)g_cache_bytes;
+    if (entries) *entries = (int64_t)g_cache.size();
+}
+void pq_plugin_cache_clear(void) {
+    pq_ctx *ctx = plugin_ctx();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        for (size_t i = g_cache.size(); i-- > 0;)
+            if (!g_cache[i].in_use) { drop.push_back(g_cache[i].d); g_cache_bytes -= g_cache[i].bytes; g_cache.erase(g_cache.begin() + (long)i); }
+        g_cache_hits = g_cache_misses = 0;
+    }
+    if (ctx) for (void *q : drop) (void)pq_free(ctx, q);
+}
 uint32_t _polars_plugin_get_version(void) { return (0u << 16) | 1u; }
 const char *_polars_plugin_get_last_error_message(void) { return g_plugin_err.c_str(); }
 // Every reference function of the shape (1..4 Float64 columns[, timeperiod]) -> Float64.  overlap.rs takes the period as pickled

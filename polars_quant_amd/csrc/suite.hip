@@ -174,7 +174,7 @@ __device__ __forceinline__ void seq_jobs_body(const SeqJob *jobs, Dims d, unsign
 }
 // 0: light ops, tiled; 1: heavy ops, tiled; 2: gather bodies; 3: light ops, tiled, rows only 8-byte aligned (UNAL)
 template <int V>
-__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
+__global__ __launch_bounds__(V == 2 ? SEQ_BLOCK : SEQ_LDS_BLOCK, V == 0 ? PQ_LB0 : V == 2 ? PQ_LB2 : 2) void seq_jobs_kernel(const SeqJob *jobs, Dims d, unsigned long long *dbg, unsigned long long *wg) {
     seq_jobs_body<V>(jobs, d, dbg, wg);
 }
 #if PQ_NV0 > 0

@@ -35,7 +35,7 @@ static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
     X(CmoOp) X(RsiOp) X(MacdOp) X(TrixOp) X(UltoscOp) X(MfiOp) X(DmOp<0>) X(DmOp<1>) X(DmOp<2>) X(DmRawOp<true>)      \
     X(DmRawOp<false>) X(SmaTpOp)                                                                                     \
     X(TrimaOp) X(MaDiffOp<0>) X(MaDiffOp<1>) X(MacdextOp) X(StochOp<0>) X(StochOp<1>) X(StochAllOp) X(StochRsiOp) X(CciOp)       \
-    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma8Op) X(MavpSma32Op) X(RollSum6Op)                                          \
+    X(DmAllOp<true>) X(DmAllOp<false>) X(MavpBlockOp<1>) X(MavpSma16Op) X(MavpSma8Op) X(MavpSma32Op) X(UltoscOp8)                                          \
     X(AtrOp<false>) X(AtrOp<true>) X(ObvOp) X(AdOp<false>) X(AdOp<true>) X(HtOp<0>) X(HtOp<1>) X(HtOp<2>) X(HtOp<3>) X(HtOp<4>) X(HtAllOp) X(HtAll6Op) X(BtMacdOp) X(LevOp)                                     \
     X(EmaAllOp) X(AtrAllOp) X(DmPairOp) X(AdAllOp) X(MacdPairOp) X(ApoPpoOp) X(SarPairOp) X(VolumeAllOp) X(DmiAtrOp) X(CmoRsiOp) X(SmaDupOp)
 #if defined(PQ_EXPERIMENTS) && defined(PQ_ANALYZE_LIGHT) // analysis builds (never linked): the light job kernel with a subset of its ops (experiments.h)
@@ -55,6 +55,13 @@ static_assert(sizeof(BtArgs) <= 1024, "BtArgs must fit a job slot");
 // of a SIMD's 512 registers free, which is what one wave of the pattern kernel (118) or of the wave-per-symbol backtest (122) needs:
 // at the uncapped 199 (200 allocated) neither fits beside two job waves and the pattern kernel -- the last chain of a step to finish --
 // only advances where a job workgroup has retired.  A/B in one session: 4.60 -> 4.53 ms per step.  PQ_NV0=0: no cap.
+// The gather kernel (seq_jobs_kernel<2>: the per-lane bodies of every op in one switch -- ragged batches inside a recording, windows
+// beyond 64 KB of LDS) is compiled for ONE wave per SIMD: its workgroups are single waves, the widest bodies (the Hilbert family's register
+// delay lines, MAVP's candidate sums) need ~300 registers, and under the 256 of two waves per SIMD the kernel spilled 90 of them to
+// scratch (176 B per lane) for EVERY op of the switch.  A per-lane walk is bound by its L1 accesses, not by occupancy.
+#ifndef PQ_LB2
+#define PQ_LB2 1
+#endif
 #ifndef PQ_NV0
 #define PQ_NV0 96
 #endif

@@ -77,7 +77,33 @@ for name, (cols, params, outs, _fam) in SPEC.items():
     del os.environ["PQ_NO_RG_PACK"], os.environ["PQ_NO_WT"]
     r["ragged_over_regular"] = r["ragged"] / r["regular"]
     res[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+# a RECORDED suite on the ragged batch: every sequential function of the list in one recording.  Inside a recording a ragged batch runs
+# the per-lane gather bodies of the job kernel (seq_jobs_kernel<2>: one grid, blockIdx.y = job); the same calls made directly take the
+# re-housed tiled path / the wave-per-group forms one after the other.
+SUITE = [nm for nm in SPEC if nm not in ROW_FUNCS and nm != "mavp"]
+outs_suite = {nm: [torch.empty((R,), dtype=torch.float64, device="cuda") for _ in SPEC[nm][2]] for nm in SUITE}
+calls = []
+for nm in SUITE:
+    cols, params, outs, _fam = SPEC[nm]
+    pv = [C.c_int64(int(dv)) if k == I else C.c_double(float(dv)) for _, k, dv in params]
+    calls.append((getattr(L, "pq_" + nm), [C.c_void_p(rag[c].data_ptr()) for c in cols], pv, [C.c_void_p(t.data_ptr()) for t in outs_suite[nm]]))
+
+
+def all_calls():
+    for fn, ins, pv, os_ in calls:
+        check(fn(h, C.byref(b_rag), *ins, *pv, *os_))
+    return 0
+
+
+check(L.pq_suite_begin(h, C.byref(b_rag)))
+all_calls()
+suite = C.c_void_p()
+check(L.pq_suite_end(h, C.byref(suite)))
+recorded = {"functions": len(SUITE), "recorded_replay_ms": round(timed(lambda: L.pq_suite_run(h, suite), reps=5), 4),
+            "same_calls_direct_ms": round(timed(all_calls, reps=3), 4)}
+check(L.pq_suite_destroy(h, suite))
 worst = max(res, key=lambda k: res[k]["ragged_over_regular"])
 print(json.dumps({"groups": N, "rows": R, "group_len": [int(lens.min()), int(lens.max())], "ms": res,
+                  "recorded_ragged_suite": recorded,
                   "worst_ragged_over_regular": {worst: res[worst]["ragged_over_regular"]},
                   "geomean_speedup_over_gather": float(np.exp(np.mean([np.log(v["ragged_gather"] / v["ragged"]) for v in res.values()])))}, indent=1))

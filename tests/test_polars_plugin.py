@@ -727,3 +727,75 @@ def test_batched_over_balanced_panel(oracle, n_groups, glen):
     got = _import(ret)
     exp = np.concatenate([oracle.pattern("cdlengulfing", *[d[c][g * glen:(g + 1) * glen] for c in ("open", "high", "low", "close")]).reshape(-1) for g in range(n_groups)])
     assert got.type == pa.int32() and (got.to_numpy() == exp).all()
+
+
+@pytest.mark.gpu
+def test_input_column_cache_never_aliases_a_reused_address(oracle):
+    """The plugin keeps the device copy of a one-chunk Float64 input under (buffer address, rows, layout) + a hash of the WHOLE buffer
+    (csrc/plugin.hip): the sixty expressions of one `with_columns` upload `close` once.  A freed-and-reused address must not alias: the
+    same numpy buffer is handed over with other content -- one element changed in the middle of it -- and the result must follow."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L = _lib()
+    L.pq_plugin_cache_stats.argtypes = [C.POINTER(C.c_int64)] * 4
+    L.pq_plugin_cache_stats.restype = None
+    L.pq_plugin_cache_clear.restype = None
+
+    def stats():
+        v = [C.c_int64() for _ in range(4)]
+        L.pq_plugin_cache_stats(*[C.byref(x) for x in v])
+        return tuple(x.value for x in v)     # hits, misses, bytes, entries
+    L.pq_plugin_cache_clear()
+    n = 40_000
+    buf = np.empty(n)                                             # ONE host buffer for the whole test: the address never changes
+    x0 = oracle.gen_ohlcv(0x5EED0C01, 1, n, 0)["close"][0]
+    buf[:] = x0
+    arr = pa.Array.from_buffers(pa.float64(), n, [None, pa.py_buffer(buf)])     # zero-copy view of buf
+    assert arr.buffers()[1].address == buf.ctypes.data
+
+    def call(name, **kw):
+        return _plugin_call(L, name, [([arr], "close")], kwargs=kw or None)
+
+    def check(got, name, x, **kw):
+        (exp,) = oracle.call(name, x.copy(), **kw)
+        en = exp.view(np.uint64) == np.uint64(oracle.NULL_BITS)
+        assert (np.asarray(got.is_null()) == en).all()
+        assert (got.to_numpy(zero_copy_only=False)[~en].view(np.uint64) == exp[~en].view(np.uint64)).all()
+    check(call("ema", timeperiod=20), "ema", x0, timeperiod=20)
+    h, m, by, ent = stats()
+    assert (h, m, ent) == (0, 1, 1) and by == n * 8
+    check(call("sma", timeperiod=10), "sma", x0, timeperiod=10)    # another function, the same column: a hit
+    check(call("ema", timeperiod=5), "ema", x0, timeperiod=5)
+    assert stats()[:2] == (2, 1)
+    # the same address, other content (one value in the middle: a sample of the ends would not see it)
+    buf[n // 2 + 17] *= 1.25
+    x1 = buf.copy()
+    check(call("ema", timeperiod=20), "ema", x1, timeperiod=20)
+    h, m, by, ent = stats()
+    assert (h, m) == (2, 2) and ent == 2
+    check(call("sma", timeperiod=10), "sma", x1, timeperiod=10)
+    assert stats()[:2] == (3, 2)
+    # back to the first content: its copy is still there
+    buf[:] = x0
+    check(call("sma", timeperiod=10), "sma", x0, timeperiod=10)
+    assert stats()[:2] == (4, 2)
+    # a multi-input function, a Struct-valued one and a recogniser share the cache; an `_over` call has its own layout (own entry)
+    d = oracle.gen_ohlcv(0x5EED0C02, 1, n, 0)
+    cols = {k: pa.array(d[k][0]) for k in ("open", "high", "low", "close")}
+    a1 = _plugin_call(L, "atr", [([cols[k]], k) for k in ("high", "low", "close")], kwargs={"timeperiod": 14})
+    a2 = _plugin_call(L, "atr", [([cols[k]], k) for k in ("high", "low", "close")], kwargs={"timeperiod": 14})
+    _same_array(a1, a2)
+    p1 = _plugin_call(L, "cdlengulfing", [([cols[k]], k) for k in ("open", "high", "low", "close")])
+    p2 = _plugin_call(L, "cdlengulfing", [([cols[k]], k) for k in ("open", "high", "low", "close")])
+    _same_array(p1, p2)
+    hits_before = stats()[0]
+    _plugin_call(L, "natr", [([cols[k]], k) for k in ("high", "low", "close")], kwargs={"timeperiod": 14})
+    assert stats()[0] == hits_before + 3
+    # chunked or null-bearing columns are not cached (and still right): the counters do not move
+    before = stats()
+    whole = pa.array(x0, mask=np.arange(n) == 5)
+    _plugin_call(L, "ema", [([whole.slice(0, 100), whole.slice(100)], "close")], kwargs={"timeperiod": 20})
+    assert stats() == before
+    L.pq_plugin_cache_clear()
+    assert stats() == (0, 0, 0, 0)
