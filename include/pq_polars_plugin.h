@@ -136,6 +136,16 @@ PQ_PLUGIN_DECL(cdlupsidegap2crows) PQ_PLUGIN_DECL(cdlxsidegap3methods)
  * returns 1 found, 0 absent or None, -1 malformed / unsupported pickle */
 int32_t pq_plugin_kwargs_i64(const uint8_t *pickle, size_t len, const char *key, int64_t *out);
 
+/* The input-column cache (csrc/plugin.hip).  A Float64 column that arrives as ONE chunk without nulls is uploaded straight from its Arrow
+ * buffer and its device copy is kept under (buffer address, rows, layout of the call) + a 64-bit hash of the WHOLE buffer, recomputed on
+ * every call: the sixty expressions of one `with_columns` (python/polars_quant/talib/momentum.py:13-16: one plugin call per expression)
+ * upload `close` once, and a freed-and-reused address with other content is a miss.  PQ_PLUGIN_CACHE_MB (default 2048; 0 = no cache) bounds
+ * the device memory it holds; least recently used entries that no call holds go first.  No reference counterpart.
+ *   pq_plugin_cache_stats   hits / misses / bytes held / entries since load (or the last clear); any pointer may be NULL
+ *   pq_plugin_cache_clear   frees every entry no call holds, zeroes the counters */
+void pq_plugin_cache_stats(int64_t *hits, int64_t *misses, int64_t *bytes, int64_t *entries);
+void pq_plugin_cache_clear(void);
+
 #ifdef __cplusplus
 }
 #endif

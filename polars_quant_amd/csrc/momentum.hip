@@ -107,7 +107,7 @@ pq_status pq_ultosc(pq_ctx *ctx, const pq_batch *b, const double *h, const doubl
                     int64_t p2, int64_t p3, double *out) {
     CHK("pq_ultosc", h && l && c && out);
     UltoscOp op{}; op.p1 = p1; op.p2 = p2; op.p3 = p3;
-    if (ctx->rec && ctx->rec_small) { // a small-shard recording: 8-row tiles (LDS is free there; half the per-tile fills and hand-offs of the longest job)
+    if (ctx->rec && ctx->rec_small) { // a small-shard recording: 8-row tiles (half the per-tile fills and hand-offs of the longest job; measured better at 625 AND 1 250 symbols)
         UltoscOp8 op8{}; op8.p1 = p1; op8.p2 = p2; op8.p3 = p3;
         InCols<3> in{{h, l, c}}; OutCols<1> o{{out}};
         if (seq_can_lds(ctx, b, op8, in, o)) return launch_seq(ctx, b, op8, in, o);

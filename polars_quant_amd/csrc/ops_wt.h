@@ -423,7 +423,8 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
     // wave-per-symbol job holds 21 KB of LDS per column and symbol (measured at 5 000 x 2 520: the step takes 6.6 ms with these
     // kernels recorded in place of their jobs against 4.0 ms).  PQ_WT_SUITE=1 records them anyway (A/B runs).
     if (ctx->rec && !getenv("PQ_WT_SUITE") &&
-        !(ctx->rec_small && ctx->chain_head && WtSmallSuite<WtOp>::value && b->n_series <= 12 * SEQ_BLOCK && !getenv("PQ_NO_WT_SMALL")))
+        !(ctx->rec_small && ctx->chain_head && WtSmallSuite<WtOp>::value && b->n_series <= (getenv("PQ_WT_SMALL_TILES") ? atoll(getenv("PQ_WT_SMALL_TILES")) : 12) * SEQ_BLOCK &&
+          !getenv("PQ_NO_WT_SMALL")))
         return false;
     if (!wt_on() || !wt_op_on(WtOp::NAME) || b->len > WT_MAX_LEN || b->n_series <= 0 || b->n_series > 0x7fffffffLL) return false;
     const bool ragged = b->offsets != nullptr;

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -362,6 +363,27 @@ static uint64_t hash_bytes(const void *p, size_t nbytes) { // four interleaved m
     for (int k = 0; k < 4; k++) { r = (r ^ h[k]) * K; r ^= r >> 29; }
     return r;
 }
+// the hash of a large buffer on several host threads (one core hashes ~15 GB/s, about what the runtime's pageable upload moves -- a hit
+// would cost what it saves; eight threads leave the validation at a fifth of the upload): chunk hashes combined in order
+static uint64_t hash_buffer(const void *p, size_t nbytes) {
+    const size_t CH = (size_t)8 << 20;
+    const size_t nch = (nbytes + CH - 1) / CH;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+    if (nch < 2 || nt < 2) return hash_bytes(p, nbytes);
+    std::vector<uint64_t> hs(nch);
+    std::vector<std::thread> th;
+    const unsigned use = nt < nch ? nt : (unsigned)nch;
+    for (unsigned t = 0; t < use; t++)
+        th.emplace_back([&, t]() {
+            for (size_t c = t; c < nch; c += use) {
+                const size_t lo = c * CH, len = lo + CH <= nbytes ? CH : nbytes - lo;
+                hs[c] = hash_bytes((const uint8_t *)p + lo, len);
+            }
+        });
+    for (auto &x : th) x.join();
+    return hash_bytes(hs.data(), hs.size() * 8) ^ (uint64_t)nbytes;
+}
 struct InCol { void *d = nullptr; bool owned = false, publish = false; int hit = 0; CacheEntry key{}; };
 // one chunk of Float64 without nulls: its values buffer IS the flat host column
 static const double *flat_f64(const pq_series_export &in, int64_t n) {
@@ -377,7 +399,7 @@ static pq_status cached_input(pq_ctx *ctx, const Layout &L, const double *src, i
     k.groups = L.pitched ? L.groups : 1; k.glen = L.pitched ? L.glen : n; k.pitch = L.pitched ? L.pitch : n;
     const size_t limit = cache_limit();
     if (limit) {
-        k.hash = hash_bytes(src, (size_t)n * 8);
+        k.hash = hash_buffer(src, (size_t)n * 8);
         std::lock_guard<std::mutex> g(g_cache_mu);
         for (CacheEntry &e : g_cache)
             if (e.addr == k.addr && e.n == k.n && e.groups == k.groups && e.glen == k.glen && e.pitch == k.pitch && e.hash == k.hash) {

@@ -65,7 +65,7 @@ struct Phase {
     // wrote a column it touches or read a column it writes -- and the event recorded behind its launches
     // (slot NCHAIN = the HEADS of the phase's ROW chain: the ROW launches that feed later phases are issued first and get an event of
     //  their own, so that a link waiting for the fast-k column does not wait for the patterns and the backtest behind it)
-    std::vector<std::pair<int, int>> deps[NCHAIN];
+    std::vector<std::pair<int, int>> deps[NCHAIN][2]; // [chain][0: its job grids, 1: its ROW launches] -- waited for right in front of each part
     hipEvent_t ev_done[NCHAIN + 1] = {};
     int n_heads = 0; // leading ROW launches on the phase's ROW chain that feed a later phase
     bool work[NCHAIN] = {};
@@ -82,6 +82,7 @@ struct Recorder {
     bool shared_out = false;
     bool small = false; // the recording covers a small shard (small_shard): chains ordered by data dependencies instead of phase barriers
     std::set<const void *> feeds_seq; // small: columns that a sequential job of a LATER phase reads, directly or through ROW launches
+    bool grids_first = false;         // small: on the chain of the links, a phase's job grid is issued before its ROW launches (small_deps)
     bool timing = false;
     static constexpr int MAX_TIMED_RUNS = 64;
 };
@@ -184,12 +185,12 @@ __global__ __attribute__((amdgpu_num_vgpr(PQ_NV0))) __launch_bounds__(SEQ_LDS_BL
 }
 #endif
 
-// A recording covers a SMALL shard when one job is at most cus / 8 workgroups (32 tiles = 2 048 series on MI355X): with the ~40 jobs of
-// an un-fused indicator suite that is at most ~5 workgroups per CU, i.e. at most about one compute wave per SIMD -- every wave then runs
-// at its own instruction rate and the step ends with its longest job.  PQ_SMALL_SHARD_TILES=<n> moves the bound (0: never small).
+// A recording covers a SMALL shard when one job is at most cus / 12 workgroups (21 tiles = 1 344 series on MI355X): with the ~45 jobs of
+// an un-fused indicator suite that is at most ~4 workgroups per CU, i.e. about one compute wave per SIMD -- every wave then runs at its
+// own instruction rate and the step ends with its longest job.  PQ_SMALL_SHARD_TILES=<n> moves the bound (0: never small).
 static bool small_shard(const pq_ctx *ctx, const pq_batch *b) {
     if (b->offsets) return false;
-    int64_t bound = (ctx->cus > 0 ? ctx->cus : 256) / 8;
+    int64_t bound = (ctx->cus > 0 ? ctx->cus : 256) / 12; // (measured: the small-shard plan wins at 1 250 symbols, 1.78 against 1.93 ms, and loses at 1 875, 2.18 against 1.99)
     if (const char *e = getenv("PQ_SMALL_SHARD_TILES")) bound = atoll(e);
     return (b->n_series + SEQ_BLOCK - 1) / SEQ_BLOCK <= bound;
 }
@@ -358,45 +359,60 @@ static void small_deps(Recorder &r) {
         p.n_heads = 0;
         while ((size_t)p.n_heads < p.rows.size() && feeds(p.rows[(size_t)p.n_heads]) && !p.row_late[(size_t)p.n_heads] && !p.row_fused[(size_t)p.n_heads]) p.n_heads++;
     }
+    // The chain of the links runs a phase's ROW launches and its job grid one after the other.  The ROW launches of phase 1 wait for the
+    // phase-0 PRODUCERS (MACD = fast - slow for MACDEXT's two averages, fast-k of RSI for RSI), its job grid for links that finished long
+    // ago (STOCH's averages for the fast-k kernel): if the producers outlast a link, the grid goes first (1 250 symbols, RSI as a job: 1.58
+    // against 1.79 ms per step); if they do not, the ROW launches do (625 symbols, RSI in its wave form: 1.25 against 1.28).
+    {
+        int producers = 0, links = 0;
+        if (!r.phases.empty()) for (const SeqJob &j : r.phases[0].seq) if (j.cls == CLS_SHORT) producers = std::max(producers, j.cost);
+        if (r.phases.size() > 1) for (const SeqJob &j : r.phases[1].seq) links = std::max(links, j.cost);
+        r.grids_first = 2 * producers > 3 * links;
+        if (const char *e = getenv("PQ_SMALL_GRIDS_FIRST")) r.grids_first = atoi(e) != 0;
+    }
     std::map<const void *, std::vector<std::pair<int, int>>> last_w, readers; // (several jobs of ONE phase may write disjoint rows of a column: MAVP's blocks)
     for (size_t q = 0; q < r.phases.size(); q++) {
         Phase &p = r.phases[q];
         // R / W: what the launches of chain c touch (its waits); RP / WP: the same per SLOT that later phases wait for -- the chain, or
         // slot NCHAIN for the heads of the ROW chain
-        std::set<const void *> R[NCHAIN], W[NCHAIN], RP[NCHAIN + 1], WP[NCHAIN + 1];
-        for (int c = 0; c < NCHAIN; c++) { p.deps[c].clear(); p.work[c] = false; }
+        // (the waits of a chain are split by part: its job grids [0] and its ROW launches [1] are independent of each other within a phase,
+        //  and the grid of a phase must not wait for what only the ROW launches behind it need -- STOCH's averages for MACDEXT's producers)
+        std::set<const void *> R2[NCHAIN][2], W2[NCHAIN][2], RP[NCHAIN + 1], WP[NCHAIN + 1];
+        for (int c = 0; c < NCHAIN; c++) { p.deps[c][0].clear(); p.deps[c][1].clear(); p.work[c] = false; }
         for (const SeqJob &j : p.seq) {
             const int c = p.chain_of[j.cls];
             p.work[c] = true;
-            for (int k = 0; k < j.nin; k++) { R[c].insert(j.in[k]); RP[c].insert(j.in[k]); }
-            for (int k = 0; k < j.nout; k++) { W[c].insert(j.out[k]); WP[c].insert(j.out[k]); }
+            for (int k = 0; k < j.nin; k++) { R2[c][0].insert(j.in[k]); RP[c].insert(j.in[k]); }
+            for (int k = 0; k < j.nout; k++) { W2[c][0].insert(j.out[k]); WP[c].insert(j.out[k]); }
             for (int k = 0; k < 4; k++) {
-                if (j.xr[k]) { R[c].insert(j.xr[k]); RP[c].insert(j.xr[k]); }
-                if (j.xw[k]) { W[c].insert(j.xw[k]); WP[c].insert(j.xw[k]); }
+                if (j.xr[k]) { R2[c][0].insert(j.xr[k]); RP[c].insert(j.xr[k]); }
+                if (j.xw[k]) { W2[c][0].insert(j.xw[k]); WP[c].insert(j.xw[k]); }
             }
         }
         for (size_t k = 0; k < p.rows.size(); k++) {
             const int c = chain_of_row(p, k);
             p.work[c] = true;
             const int slot = (int)k < p.n_heads ? NCHAIN : c;
-            for (int i = 0; i < p.rows[k].n_reads; i++) { R[c].insert(p.rows[k].reads[i]); RP[slot].insert(p.rows[k].reads[i]); }
-            for (int i = 0; i < p.rows[k].n_writes; i++) if (p.rows[k].writes[i]) { W[c].insert(p.rows[k].writes[i]); WP[slot].insert(p.rows[k].writes[i]); }
+            for (int i = 0; i < p.rows[k].n_reads; i++) { R2[c][1].insert(p.rows[k].reads[i]); RP[slot].insert(p.rows[k].reads[i]); }
+            for (int i = 0; i < p.rows[k].n_writes; i++) if (p.rows[k].writes[i]) { W2[c][1].insert(p.rows[k].writes[i]); WP[slot].insert(p.rows[k].writes[i]); }
         }
-        for (int c = 0; c < NCHAIN; c++) {
+        for (int cp = 0; cp < 2 * NCHAIN; cp++) {
+            const int c = cp / 2, part = cp % 2;
+            const std::set<const void *> &R = R2[c][part], &W = W2[c][part];
             int latest[NCHAIN + 1];
             for (int x = 0; x <= NCHAIN; x++) latest[x] = -1;
             auto need = [&](const std::pair<int, int> &d) { // (an earlier phase of the same stream is ordered by the stream)
                 const int stream_of = d.second == NCHAIN ? r.phases[(size_t)d.first].row_chain : d.second;
                 if (stream_of != c && d.first > latest[d.second]) latest[d.second] = d.first;
             };
-            for (const void *col : R[c]) { auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d); }
-            for (const void *col : W[c]) {
+            for (const void *col : R) { auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d); }
+            for (const void *col : W) {
                 auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d);
                 auto ir = readers.find(col); if (ir != readers.end()) for (const auto &d : ir->second) need(d);
             }
             // (a wait for the whole ROW chain of a phase covers its heads)
             if (latest[NCHAIN] >= 0 && latest[r.phases[(size_t)latest[NCHAIN]].row_chain] >= latest[NCHAIN]) latest[NCHAIN] = -1;
-            for (int x = 0; x <= NCHAIN; x++) if (latest[x] >= 0) p.deps[c].push_back({latest[x], x});
+            for (int x = 0; x <= NCHAIN; x++) if (latest[x] >= 0) p.deps[c][part].push_back({latest[x], x});
         }
         for (int c = 0; c <= NCHAIN; c++) {
             for (const void *col : WP[c]) {
@@ -631,8 +647,19 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
             }
             hipStream_t st = chain_st[c];
             if (!started[c]) { PQ_HIP_TRY(hipStreamWaitEvent(st, r.ev_fork, 0)); started[c] = true; }
-            for (const auto &dep : p.deps[c]) PQ_HIP_TRY(hipStreamWaitEvent(st, r.phases[(size_t)dep.first].ev_done[dep.second], 0));
-            if (p.row_chain == c) {
+            auto wait_part = [&](int part) -> hipError_t {
+                for (const auto &dep : p.deps[c][part]) {
+                    const hipError_t e = hipStreamWaitEvent(st, r.phases[(size_t)dep.first].ev_done[dep.second], 0);
+                    if (e != hipSuccess) return e;
+                }
+                return hipSuccess;
+            };
+            // Phase 0: the ROW launches first (the heads of the chains are among them), then the grid.  Later phases (the chain of the
+            // links): whichever part has its inputs first (small_deps) -- a stream runs in order.
+            const bool grids_first = q > 0 && r.grids_first;
+            auto launch_early_rows = [&]() -> pq_status {
+                if (p.row_chain != c) return PQ_OK;
+                PQ_HIP_TRY(wait_part(1));
                 for (size_t k = 0; k < p.rows.size(); k++) {
                     if (!p.row_late[k] && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
                     if ((int)k + 1 == p.n_heads) { // the heads of the chain are out: what waits for them need not wait for the rest
@@ -641,7 +668,10 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
                     }
                 }
                 launch_row_grid(0, st);
-            }
+                return PQ_OK;
+            };
+            if (!grids_first) PQ_TRY(launch_early_rows());
+            PQ_HIP_TRY(wait_part(0));
             for (int cls = 0; cls < NCLS; cls++) {
                 const int nj = p.first[cls + 1] - p.first[cls];
                 if (p.chain_of[cls] != c || nj <= 0) continue;
@@ -662,6 +692,10 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
                 else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
                 if (tm) { PQ_HIP_TRY(hipEventRecord(g.ev[(size_t)g.runs * 2 + 1], st)); g.runs++; }
             }
+            if (grids_first) PQ_TRY(launch_early_rows());
+            bool late_any = false;
+            for (size_t k = 0; k < p.rows.size(); k++) late_any |= p.row_late[k] == 1 + c;
+            if (late_any && p.row_chain != c) PQ_HIP_TRY(wait_part(1)); // (tails on a chain that has no early ROW launches of this phase)
             for (size_t k = 0; k < p.rows.size(); k++)
                 if (p.row_late[k] == 1 + c && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
             launch_row_grid(1 + c, st);

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh'): regenerates every artifact under profiles/ from the
-# current build.  rocprofv3 gets the program itself after `--` (no env / shell hop), counters in their own passes.
+# Run on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh'): regenerates the step's own evidence under profiles/ from the
+# current build (kernel stats, PMC traffic, residency, bench lines, SQ counters); scripts/collect_profiles2.sh the side benchmarks
+# (shards, exchange, plugin, ragged, wave forms, microbenchmarks) -- two gpurun calls at ONE commit, each inside the 20-minute limit.  rocprofv3 gets the program itself after `--` (no env / shell hop), counters in their own passes.
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
@@ -17,7 +18,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 ( cd "$R" && python scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r06" 23 > "$OUT/pmc_summary.txt" )
 cp "$OUT/r06_pmc_traffic.json" "$R/profiles/r06_pmc_traffic.json"   # (on the box: the bench runs below quote it; it carries this build's source hash)
 # 3. workgroup residency of one step (device timestamps)
-( cd "$R" && PQ_SUITE_DEBUG=2 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/wg.log" 2>&1; python scripts/wg_residency.py "$OUT/wg.log" > "$OUT/wg_residency.txt" )
+( cd "$R" && PQ_SUITE_DEBUG=2 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/wg.log" 2>&1; python scripts/wg_residency.py "$OUT/wg.log" > "$OUT/wg_residency.txt" )
 # 4. the plain bench line (with the CPU baseline) for reference, the end-to-end figures, the backtest alone on shards (strong scaling
 #    projection), the phase profile of the wave backtest is a separate build (scripts/prof_backtest.py)
 ( cd "$R" && python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" )
@@ -26,18 +27,9 @@ cp "$OUT/r06_pmc_traffic.json" "$R/profiles/r06_pmc_traffic.json"   # (on the bo
 ( cd "$R" && python3 scripts/bench_backtest.py > "$OUT/bench_backtest.json" 2>> "$OUT/bench.err" )
 ( cd "$R" && python3 scripts/bench_strategy.py > "$OUT/bench_strategy.json" 2>> "$OUT/bench.err" )
 ( cd "$R" && python3 scripts/measure_tolerance.py > "$OUT/tolerance.json" 2>> "$OUT/bench.err" )
-# 4b. the wave-per-symbol indicator kernels alone against the lane-per-symbol bodies (direct C-ABI calls), their per-phase device time
-#     (a PQ_WT_PROF build made on the CPU box: scripts/ab_build.sh wtprof -DPQ_WT_PROF wt) and the in-suite A/B
-( cd "$R" && timeout -k 10 300 python3 scripts/bench_wt.py 2>> "$OUT/bench.err" | tail -1 > "$OUT/bench_wt.json" )
-if [ -f "$R/ab/libpq_wtprof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_wtprof.so PQ_WT_ALL=1 PQ_MIDPRICE_SEQ=1 timeout -k 10 200 python3 scripts/prof_wt.py > "$OUT/wt_phase_profile.txt" 2>> "$OUT/bench.err" || true ); fi
-( cd "$R" && for v in "PQ_NO_WT=1" "PQ_WT_SUITE=1 PQ_WT_ALL=1" "PQ_WT_SUITE=1 PQ_WT_OPS=atr,midpoint" "PQ_MIDPRICE_ROW=1"; do
-    echo "$v: $(env $v python3 bench.py --steps 30 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; print(round(json.loads(sys.stdin.readline())['ms_per_step'],3))") ms per step"; done > "$OUT/wt_in_suite_ab.txt" )
 # 4c. per-job accounting of the compute wave inside a step (a PQ_PROFILE_WAVES build made on the CPU box: scripts/ab_build.sh prof
 #     "-DPQ_EXPERIMENTS -DPQ_PROFILE_WAVES" suite)
-if [ -f "$R/ab/libpq_prof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_prof.so PQ_SUITE_DEBUG=1 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>&1 | grep "pq prof" | tail -40 > "$OUT/wave_profile.txt" ); fi
-# 4d. round 5: ragged batches (re-housed tiled path / wave forms against the gather forms), the exchange modes at a world of one
-( cd "$R" && timeout -k 10 300 python3 scripts/bench_ragged.py > "$OUT/bench_ragged.json" 2>> "$OUT/bench.err" )
-( cd "$R" && timeout -k 10 200 python3 scripts/bench_gather.py 2>> "$OUT/bench.err" | sed -n '/^{/,$p' > "$OUT/bench_gather.json" )
+if [ -f "$R/ab/libpq_prof.so" ]; then ( cd "$R" && PQ_LIB_PATH=ab/libpq_prof.so PQ_SUITE_DEBUG=1 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary 2>&1 | grep "pq prof" | tail -40 > "$OUT/wave_profile.txt" ); fi
 cp "$R/polars_quant_amd/csrc/suite.resources.txt" "$OUT/kernel_resources.txt" 2>/dev/null || true
 # 5. rocprofv3 kernel stats of the config-3 backtest alone
 cd /tmp

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 
 from polars_quant_amd import api

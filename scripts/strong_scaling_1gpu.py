@@ -8,7 +8,7 @@ import json
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ctypes as C
 
 import torch
@@ -52,6 +52,7 @@ for n in (5000, 2500, 1250, 625):
                                                                                           *[_vp(t) for t in _o], _vp(_sm))), 20)
     st = Suite(n, T, "cuda", stride=PITCH)
     st.record(g)
+    out.setdefault("suite_plan", {})[n] = st.info()      # phases / jobs / ROW launches of the plan this shard size records
     out["suite_step_ms"][n] = t_event(lambda: st.run(), 20)
     st.close()
 for key in ("backtest_macd_cross_ms", "suite_step_ms"):
