@@ -1378,9 +1378,10 @@ static inline bool btw_plan(const pq_batch *b, int64_t fast, int64_t slow, int64
         a.nW = (int32_t)(nW > 64 ? 64 : nW);
         // with seeds from the affine prefix scan (null-free series) only the last ulps have to merge.  Measured at 5 000 x 2 520,
         // MACD(12, 26, 9), of 315 000 chunks: 80 rows of warm-up leave 4 454 unmerged, 120 rows 195, 160 rows 13, 200 rows none;
-        // a chunk that has not merged costs one re-run of its C rows, a warm-up chunk costs C rows on every wave: 160 rows
-        // (PQ_BT_WARM_CHUNKS2 = 4 at this shape) is the fastest setting, 0.305 ms against 0.323 at 200
-        double rows2 = 8.5 / af + 8.5 / ag;
+        // a chunk that has not merged costs one re-run of its C rows, a warm-up chunk costs C rows on every wave.  Round 6 re-measured
+        // the sweep on the four-wave form (PQ_BT_WARM_CHUNKS2 = 1 .. 5, us per call at 625 / 5 000 symbols): 126 / 566, 57.2 / 274, **49.8 /
+        // 264.9**, 50.9 / 270.5, 52.0 / 276.7 -- 120 rows (3 chunks at this shape; round 4 planned 160) are the fastest setting at both sizes
+        double rows2 = 6.4 / af + 6.4 / ag;
         if (!(rows2 < 1e9)) rows2 = 1e9;
         int64_t nW2 = ((int64_t)rows2 + C - 1) / C;
         if (const char *e = getenv("PQ_BT_WARM_CHUNKS2")) nW2 = atoll(e);
