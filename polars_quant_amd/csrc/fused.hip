@@ -45,9 +45,12 @@ struct HtTsBlob {
     unsigned *gate;
     unsigned lds;
 };
+struct HtTsRows { int own_row[HT_TS_MAX_CHUNKS]; };
+// (one launch for every hand-over of the batch: blockIdx.y + 1 = the chunk whose first own tile is compared)
 __global__ __launch_bounds__(SEQ_BLOCK) void ht_ts_check_kernel(const double *real, const double *o0, const double *o1, const double *o2, const double *c0,
-                                                               const double *c1, const double *c2, Dims d, int own_row, int tile_rows, unsigned *gate) {
+                                                               const double *c1, const double *c2, Dims d, HtTsRows rows, int tile_rows, unsigned *gate) {
     const int64_t s = (int64_t)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    const int own_row = rows.own_row[blockIdx.y + 1];
     bool bad = false;
     if (s < d.n) {
         const double *o[3] = {o0, o1, o2}, *c[3] = {c0, c1, c2};
@@ -70,9 +73,12 @@ static void ht_ts_launch(const void *blob, hipStream_t stream) {
     const HtTsBlob &w = *reinterpret_cast<const HtTsBlob *>(blob);
     const Dims d = dims_of(&w.b);
     const dim3 tiles((unsigned)((w.b.n_series + SEQ_BLOCK - 1) / SEQ_BLOCK));
-    for (int c = 1; c < w.n_chunks; c++)
-        hipLaunchKernelGGL(ht_ts_check_kernel, tiles, dim3(SEQ_BLOCK), 0, stream, w.real, w.out[0], w.out[1], w.out[2], w.chk[0], w.chk[1], w.chk[2], d,
-                           w.own_row[c], w.tile_rows, w.gate);
+    if (w.n_chunks > 1) {
+        HtTsRows rows;
+        for (int c = 0; c < HT_TS_MAX_CHUNKS; c++) rows.own_row[c] = w.own_row[c];
+        hipLaunchKernelGGL(ht_ts_check_kernel, dim3(tiles.x, (unsigned)(w.n_chunks - 1)), dim3(SEQ_BLOCK), 0, stream, w.real, w.out[0], w.out[1], w.out[2],
+                           w.chk[0], w.chk[1], w.chk[2], d, rows, w.tile_rows, w.gate);
+    }
     InCols<1> in{{w.real}};
     OutCols<3> out{{w.out[0], w.out[1], w.out[2]}};
     hipLaunchKernelGGL((seq_kernel<HtAll6Op, true>), tiles, dim3(SEQ_LDS_BLOCK), w.lds, stream, w.op, in, out, d, w.gate);

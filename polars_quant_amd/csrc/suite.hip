@@ -9,6 +9,7 @@
 // besides the launches.  Composite functions (MAVP = one job per candidate period) use the same machinery
 // internally through SuiteScope.
 #include "suite_jobs.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
@@ -424,6 +425,29 @@ static void small_deps(Recorder &r) {
             for (const void *col : RP[c]) readers[col].push_back({(int)q, c});
         }
     }
+    if (getenv("PQ_SUITE_PLAN")) { // debug: the schedule as text -- per phase and chain its launches and what each part waits for
+        fprintf(stderr, "[pq plan] small-shard schedule: %zu phases, grids_first=%d\n", r.phases.size(), (int)r.grids_first);
+        for (size_t q = 0; q < r.phases.size(); q++) {
+            const Phase &p = r.phases[q];
+            for (int c = 0; c < NCHAIN; c++) {
+                if (!p.work[c]) continue;
+                fprintf(stderr, "[pq plan] phase %zu chain %d%s:", q, c, p.row_chain == c ? " (ROW chain)" : "");
+                for (int part = 0; part < 2; part++) {
+                    fprintf(stderr, " %s waits {", part ? "rows" : "grid");
+                    for (const auto &d : p.deps[c][part]) fprintf(stderr, " (phase %d, %s)", d.first, d.second == NCHAIN ? "heads" : std::to_string(d.second).c_str());
+                    fprintf(stderr, " }");
+                }
+                fprintf(stderr, "\n[pq plan]     jobs:");
+                for (const SeqJob &j : p.seq) if (p.chain_of[j.cls] == c) fprintf(stderr, " %d(cost %d)", j.kind, j.cost);
+                fprintf(stderr, "\n[pq plan]     rows:");
+                for (size_t k = 0; k < p.rows.size(); k++)
+                    if (chain_of_row(p, k) == c)
+                        fprintf(stderr, " [id %d r%d w%d%s%s%s]", p.rows[k].row_id, p.rows[k].n_reads, p.rows[k].n_writes, (int)k < p.n_heads ? " head" : "",
+                                p.row_late[k] ? " late" : "", p.row_fused[k] ? " fused" : "");
+                fprintf(stderr, "\n");
+            }
+        }
+    }
 }
 static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
     if (r.small) { // columns that feed a sequential job of a later phase: from the last phase back, through the ROW launches
@@ -621,6 +645,11 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
     if (any_side) PQ_HIP_TRY(hipEventRecord(r.ev_fork, ctx->stream));
     for (size_t q = 0; q < r.phases.size(); q++) {
         Phase &p = r.phases[q];
+        if (p.d_dbg && atoi(getenv("PQ_SUITE_DEBUG")) >= 2 && !p.d_wg && !p.seq.empty()) {
+            p.wg_tiles = tiles;
+            PQ_HIP_TRY(hipMalloc((void **)&p.d_wg, 24 * (size_t)tiles * p.seq.size()));
+        }
+        if (p.d_wg) PQ_HIP_TRY(hipMemset(p.d_wg, 0, 24 * (size_t)tiles * p.seq.size()));
         if (p.d_dbg) { // min slots start at ~0, max slots at 0
             std::vector<unsigned long long> init(2 * p.seq.size());
             for (size_t i = 0; i < p.seq.size(); i++) { init[2 * i] = ~0ULL; init[2 * i + 1] = 0; }
@@ -676,21 +705,25 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
                 const int nj = p.first[cls + 1] - p.first[cls];
                 if (p.chain_of[cls] != c || nj <= 0) continue;
                 GridStat &g = p.gs[cls];
+                // timed runs (pq_suite_set_timing): the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL) --
+                // two hipEventRecord markers around every grid cost a 625-symbol step 0.1 ms of its 1.25
                 const bool tm = r.timing && g.runs < Recorder::MAX_TIMED_RUNS;
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 if (tm) {
                     while (g.ev.size() < (size_t)g.runs * 2 + 2) { hipEvent_t e; PQ_HIP_TRY(hipEventCreate(&e)); g.ev.push_back(e); }
-                    PQ_HIP_TRY(hipEventRecord(g.ev[(size_t)g.runs * 2], st));
+                    ev0 = g.ev[(size_t)g.runs * 2]; ev1 = g.ev[(size_t)g.runs * 2 + 1];
+                    g.runs++;
                 }
-                unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[cls] : nullptr;
+                unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[cls] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[cls] : nullptr;
                 const dim3 grid(tiles, (unsigned)nj);
                 int v = k_variant[cls];
                 if (v == 0)
                     for (int jx = p.first[cls]; jx < p.first[cls + 1]; jx++) if (p.seq[jx].unal) v = 3;
-                if (v == 3) hipLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
-                else if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
-                else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
-                else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, p.d_seq + p.first[cls], d, dbg, (unsigned long long *)nullptr);
-                if (tm) { PQ_HIP_TRY(hipEventRecord(g.ev[(size_t)g.runs * 2 + 1], st)); g.runs++; }
+                const SeqJob *jobs = p.d_seq + p.first[cls];
+                if (v == 3) hipExtLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, ev0, ev1, 0, jobs, d, dbg, wg);
+                else if (v == 2) hipExtLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, ev0, ev1, 0, jobs, d, dbg, wg);
+                else if (v == 1) hipExtLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, ev0, ev1, 0, jobs, d, dbg, wg);
+                else hipExtLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[cls], st, ev0, ev1, 0, jobs, d, dbg, wg);
             }
             if (grids_first) PQ_TRY(launch_early_rows());
             bool late_any = false;
@@ -723,6 +756,18 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
             for (size_t i = 0; i * 2 < ts[q].size(); i++)
                 fprintf(stderr, "[pq suite] job %2zu kind=%3d class=%d lds=%6u  start %8.1f us  end %8.1f us  phase %zu\n", i, r.phases[q].seq[i].kind,
                         r.phases[q].seq[i].cls, r.phases[q].seq[i].lds_bytes, (double)(ts[q][2 * i] - t0) / 100.0, (double)(ts[q][2 * i + 1] - t0) / 100.0, q);
+        for (size_t q = 0; q < r.phases.size(); q++) {
+            Phase &p = r.phases[q];
+            if (!p.d_wg) continue;
+            std::vector<unsigned long long> w(3 * (size_t)tiles * p.seq.size());
+            PQ_HIP_TRY(hipMemcpy(w.data(), p.d_wg, 8 * w.size(), hipMemcpyDeviceToHost));
+            for (size_t j = 0; j < p.seq.size(); j++)
+                for (unsigned x = 0; x < tiles; x++) {
+                    const unsigned long long *e = &w[3 * (j * tiles + x)];
+                    if (e[1]) fprintf(stderr, "[pq wg] %zu.%zu %u %.2f %.2f %llu %llu %u\n", q, j, x, (double)(e[0] - t0) / 100.0, (double)(e[1] - t0) / 100.0,
+                                      e[2] >> 32, e[2] & 0xffffffffULL, p.seq[j].lds_bytes);
+                }
+        }
     }
     PQ_HIP_TRY(hipGetLastError());
     return PQ_OK;
@@ -787,17 +832,24 @@ static pq_status suite_launch(pq_ctx *ctx, Recorder &r) {
         auto launch_class = [&](int c, hipStream_t st) -> pq_status {
             const int nj = njobs(c);
             if (nj <= 0) return PQ_OK;
-            PQ_HIP_TRY(timed(p.gs[c], st, true));
+            // (timed runs: the events ride on the grid's own dispatch packet, no marker packets around it)
+            GridStat &g = p.gs[c];
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (r.timing && g.runs < Recorder::MAX_TIMED_RUNS) {
+                while (g.ev.size() < (size_t)g.runs * 2 + 2) { hipEvent_t e; PQ_HIP_TRY(hipEventCreate(&e)); g.ev.push_back(e); }
+                ev0 = g.ev[(size_t)g.runs * 2]; ev1 = g.ev[(size_t)g.runs * 2 + 1];
+                g.runs++;
+            }
             unsigned long long *dbg = p.d_dbg ? p.d_dbg + 2 * p.first[c] : nullptr, *wg = p.d_wg ? p.d_wg + 3 * (size_t)tiles * p.first[c] : nullptr;
             const dim3 grid(tiles, (unsigned)nj);
             int v = k_variant[c];
             if (v == 0) // one job with 8-byte rows: the whole grid runs the 8-byte form (it handles aligned columns as well)
                 for (int jx = p.first[c]; jx < p.first[c + 1]; jx++) if (p.seq[jx].unal) v = 3;
-            if (v == 3) hipLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
-            else if (v == 2) hipLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, p.d_seq + p.first[c], d, dbg, wg);
-            else if (v == 1) hipLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
-            else hipLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, p.d_seq + p.first[c], d, dbg, wg);
-            PQ_HIP_TRY(timed(p.gs[c], st, false));
+            const SeqJob *jobs = p.d_seq + p.first[c];
+            if (v == 3) hipExtLaunchKernelGGL(seq_jobs_kernel<3>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, ev0, ev1, 0, jobs, d, dbg, wg);
+            else if (v == 2) hipExtLaunchKernelGGL(seq_jobs_kernel<2>, grid, dim3(SEQ_BLOCK), 0, st, ev0, ev1, 0, jobs, d, dbg, wg);
+            else if (v == 1) hipExtLaunchKernelGGL(seq_jobs_kernel<1>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, ev0, ev1, 0, jobs, d, dbg, wg);
+            else hipExtLaunchKernelGGL(seq_jobs_kernel<0>, grid, dim3(SEQ_LDS_BLOCK), p.lds[c], st, ev0, ev1, 0, jobs, d, dbg, wg);
             return PQ_OK;
         };
         auto launch_rows = [&](int pos, hipStream_t st) { // the fused ROW grid of a chain position

@@ -11,6 +11,17 @@ from polars_quant_amd.synthetic import gen_ohlcv
 T = 2520
 PITCH = (T + 15) // 16 * 16
 sizes = [int(a) for a in sys.argv[1:]] or [625]
+_mode = __import__("os").environ.get("PQ_STEP_STREAM")   # A/B: the step on a stream of its own instead of the null stream
+if _mode in ("ext-nb", "ext-b"):   # a stream created with the HIP API itself (non-blocking / blocking), wrapped for torch
+    import ctypes
+    torch.cuda.init()
+    path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+    hip = ctypes.CDLL(path)
+    h = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1 if _mode == "ext-nb" else 0) == 0
+    torch.cuda.set_stream(torch.cuda.ExternalStream(h.value))
+elif _mode:
+    torch.cuda.set_stream(torch.cuda.Stream(priority=int(__import__("os").environ.get("PQ_STEP_STREAM_PRIO", "0"))))
 full = gen_ohlcv(0x5EED0002, max(sizes), T, 0)
 for n in sizes:
     g = {}

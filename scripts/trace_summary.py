@@ -22,7 +22,8 @@ tot = defaultdict(float)
 for r in c:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     nm = short(r["Kernel_Name"])
-    print(f"{s/1e3:9.1f} us  +{(e-s)/1e3:8.1f} us  grid=({r['Grid_Size_X']},{r['Grid_Size_Y']}) vgpr={r['VGPR_Count']} scratch={r['Scratch_Size']}  {nm}")
+    q = f" q={r['Queue_Id']}" if "Queue_Id" in r else ""
+    print(f"{s/1e3:9.1f} us  +{(e-s)/1e3:8.1f} us ={e/1e3:8.1f}{q}  grid=({r['Grid_Size_X']},{r['Grid_Size_Y']}) vgpr={r['VGPR_Count']} scratch={r['Scratch_Size']}  {nm}")
     tot[nm] += (e - s) / 1e3
 span = (max(int(r["End_Timestamp"]) for r in c) - t0) / 1e3
 print(f"step span {span:.1f} us (launches of one step overlap on 4 streams)")
