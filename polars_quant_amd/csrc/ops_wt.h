@@ -461,6 +461,7 @@ static inline bool wt_try(pq_ctx *ctx, const pq_batch *b, const WtOp &wop, const
         RowThunk t{};
         t.launch = &wt_launch_blob<WtOp, SeqOp>;
         t.row_id = 0;
+        t.long_launch = 1;
         t.blob_bytes = (int)sizeof w;
         t.dims = dims_of(b);
         memcpy(t.blob, &w, sizeof w);

@@ -912,6 +912,7 @@ pq_status rec_add_seq(pq_ctx *ctx, const pq_batch *b, const SeqTraits &tr, const
 struct RowThunk { // type-erased ROW launch for replay
     void (*launch)(const void *blob, hipStream_t stream);
     int row_id;     // Op::ROW_ID if the suite may run it inside its fused ROW grid (row_jobs_kernel), else 0
+    int long_launch = 0; // 1: takes a good part of a small-shard step (a wave-per-symbol form): the heads of the ROW chain that are short go first
     int blob_bytes; // sizeof(RowBlob<Op>)
     Dims dims;      // of the batch the call was made on
     unsigned char blob[1200];

@@ -66,9 +66,12 @@ struct Phase {
     // wrote a column it touches or read a column it writes -- and the event recorded behind its launches
     // (slot NCHAIN = the HEADS of the phase's ROW chain: the ROW launches that feed later phases are issued first and get an event of
     //  their own, so that a link waiting for the fast-k column does not wait for the patterns and the backtest behind it)
+    // (slot NCHAIN: the SHORT heads -- plain ROW kernels; slot NCHAIN + 1: every head, i.e. the long launches among them too -- a wave-per-
+    //  symbol RSI in front of STOCHRSI: STOCH's averages wait for the fast-k kernel, not for it)
     std::vector<std::pair<int, int>> deps[NCHAIN][2]; // [chain][0: its job grids, 1: its ROW launches] -- waited for right in front of each part
-    hipEvent_t ev_done[NCHAIN + 1] = {};
-    int n_heads = 0; // leading ROW launches on the phase's ROW chain that feed a later phase
+    hipEvent_t ev_done[NCHAIN + 2] = {};
+    int n_heads = 0, n_heads_short = 0; // leading ROW launches on the phase's ROW chain that feed a later phase; the short ones of them come first
+    bool grid_first = false;            // later phases: the job grid is issued before the ROW launches of the chain (small_deps)
     bool work[NCHAIN] = {};
     int chain_of[NCLS] = {0, 1, 2, 3}; // small-shard schedule: the chain (stream) the grid of class c runs on in this phase
     int row_chain = ROW_CHAIN;         // ... and the chain of its ROW launches
@@ -353,12 +356,15 @@ static void small_deps(Recorder &r) {
             for (int i = 0; i < t.n_writes; i++) if (r.feeds_seq.count(t.writes[i])) return true;
             return false;
         };
-        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return feeds(p.rows[a]) > feeds(p.rows[b]); });
+        auto rank = [&](const RowThunk &t) { return !feeds(t) ? 2 : t.long_launch ? 1 : 0; }; // short heads, long heads, the rest
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return rank(p.rows[a]) < rank(p.rows[b]); });
         std::vector<RowThunk> rows2; std::vector<char> late2, fused2;
         for (size_t k : idx) { rows2.push_back(p.rows[k]); late2.push_back(p.row_late[k]); fused2.push_back(p.row_fused[k]); }
         p.rows.swap(rows2); p.row_late.swap(late2); p.row_fused.swap(fused2);
         p.n_heads = 0;
         while ((size_t)p.n_heads < p.rows.size() && feeds(p.rows[(size_t)p.n_heads]) && !p.row_late[(size_t)p.n_heads] && !p.row_fused[(size_t)p.n_heads]) p.n_heads++;
+        p.n_heads_short = 0;
+        while (p.n_heads_short < p.n_heads && !p.rows[(size_t)p.n_heads_short].long_launch) p.n_heads_short++;
     }
     // The chain of the links runs a phase's ROW launches and its job grid one after the other.  The ROW launches of phase 1 wait for the
     // phase-0 PRODUCERS (MACD = fast - slow for MACDEXT's two averages, fast-k of RSI for RSI), its job grid for links that finished long
@@ -378,7 +384,7 @@ static void small_deps(Recorder &r) {
         // slot NCHAIN for the heads of the ROW chain
         // (the waits of a chain are split by part: its job grids [0] and its ROW launches [1] are independent of each other within a phase,
         //  and the grid of a phase must not wait for what only the ROW launches behind it need -- STOCH's averages for MACDEXT's producers)
-        std::set<const void *> R2[NCHAIN][2], W2[NCHAIN][2], RP[NCHAIN + 1], WP[NCHAIN + 1];
+        std::set<const void *> R2[NCHAIN][2], W2[NCHAIN][2], RP[NCHAIN + 2], WP[NCHAIN + 2];
         for (int c = 0; c < NCHAIN; c++) { p.deps[c][0].clear(); p.deps[c][1].clear(); p.work[c] = false; }
         for (const SeqJob &j : p.seq) {
             const int c = p.chain_of[j.cls];
@@ -393,17 +399,17 @@ static void small_deps(Recorder &r) {
         for (size_t k = 0; k < p.rows.size(); k++) {
             const int c = chain_of_row(p, k);
             p.work[c] = true;
-            const int slot = (int)k < p.n_heads ? NCHAIN : c;
+            const int slot = (int)k < p.n_heads_short ? NCHAIN : (int)k < p.n_heads ? NCHAIN + 1 : c;
             for (int i = 0; i < p.rows[k].n_reads; i++) { R2[c][1].insert(p.rows[k].reads[i]); RP[slot].insert(p.rows[k].reads[i]); }
             for (int i = 0; i < p.rows[k].n_writes; i++) if (p.rows[k].writes[i]) { W2[c][1].insert(p.rows[k].writes[i]); WP[slot].insert(p.rows[k].writes[i]); }
         }
         for (int cp = 0; cp < 2 * NCHAIN; cp++) {
             const int c = cp / 2, part = cp % 2;
             const std::set<const void *> &R = R2[c][part], &W = W2[c][part];
-            int latest[NCHAIN + 1];
-            for (int x = 0; x <= NCHAIN; x++) latest[x] = -1;
+            int latest[NCHAIN + 2];
+            for (int x = 0; x <= NCHAIN + 1; x++) latest[x] = -1;
             auto need = [&](const std::pair<int, int> &d) { // (an earlier phase of the same stream is ordered by the stream)
-                const int stream_of = d.second == NCHAIN ? r.phases[(size_t)d.first].row_chain : d.second;
+                const int stream_of = d.second >= NCHAIN ? r.phases[(size_t)d.first].row_chain : d.second;
                 if (stream_of != c && d.first > latest[d.second]) latest[d.second] = d.first;
             };
             for (const void *col : R) { auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d); }
@@ -411,11 +417,30 @@ static void small_deps(Recorder &r) {
                 auto it = last_w.find(col); if (it != last_w.end()) for (const auto &d : it->second) need(d);
                 auto ir = readers.find(col); if (ir != readers.end()) for (const auto &d : ir->second) need(d);
             }
-            // (a wait for the whole ROW chain of a phase covers its heads)
-            if (latest[NCHAIN] >= 0 && latest[r.phases[(size_t)latest[NCHAIN]].row_chain] >= latest[NCHAIN]) latest[NCHAIN] = -1;
-            for (int x = 0; x <= NCHAIN; x++) if (latest[x] >= 0) p.deps[c][part].push_back({latest[x], x});
+            // (a wait for the whole ROW chain of a phase covers its heads, one for all heads the short ones)
+            for (int x = NCHAIN; x <= NCHAIN + 1; x++)
+                if (latest[x] >= 0 && latest[r.phases[(size_t)latest[x]].row_chain] >= latest[x]) latest[x] = -1;
+            if (latest[NCHAIN] >= 0 && latest[NCHAIN + 1] >= latest[NCHAIN]) latest[NCHAIN] = -1;
+            for (int x = 0; x <= NCHAIN + 1; x++) if (latest[x] >= 0) p.deps[c][part].push_back({latest[x], x});
         }
-        for (int c = 0; c <= NCHAIN; c++) {
+        // The chain of the links runs a phase's job grid and its ROW launches one after the other: the part whose inputs are there first goes
+        // first.  If everything the grid waits for the ROW launches wait for as well (STOCH's averages: the fast-k kernel; the ROW launches
+        // of the phase: RSI in its wave form behind it), the grid does; else the cost rule above decides.
+        if (q > 0) {
+            const int c = p.row_chain;
+            auto implied = [&](const std::pair<int, int> &a) {
+                for (const auto &b : p.deps[c][1]) {
+                    if (b.second == a.second && b.first >= a.first) return true;
+                    if (b.first == a.first && a.second >= NCHAIN && (b.second == NCHAIN + 1 || b.second == r.phases[(size_t)a.first].row_chain)) return true;
+                }
+                return false;
+            };
+            bool subset = !p.deps[c][1].empty();
+            for (const auto &a : p.deps[c][0]) subset &= implied(a);
+            p.grid_first = r.grids_first || (subset && p.deps[c][0].size() < p.deps[c][1].size());
+            if (const char *e = getenv("PQ_SMALL_GRIDS_FIRST")) p.grid_first = atoi(e) != 0;
+        }
+        for (int c = 0; c <= NCHAIN + 1; c++) {
             for (const void *col : WP[c]) {
                 auto &lw = last_w[col];
                 if (!lw.empty() && lw.front().first != (int)q) lw.clear();
@@ -426,7 +451,9 @@ static void small_deps(Recorder &r) {
         }
     }
     if (getenv("PQ_SUITE_PLAN")) { // debug: the schedule as text -- per phase and chain its launches and what each part waits for
-        fprintf(stderr, "[pq plan] small-shard schedule: %zu phases, grids_first=%d\n", r.phases.size(), (int)r.grids_first);
+        fprintf(stderr, "[pq plan] small-shard schedule: %zu phases, grids first:", r.phases.size());
+        for (const Phase &p : r.phases) fprintf(stderr, " %d", (int)p.grid_first);
+        fprintf(stderr, "\n");
         for (size_t q = 0; q < r.phases.size(); q++) {
             const Phase &p = r.phases[q];
             for (int c = 0; c < NCHAIN; c++) {
@@ -434,7 +461,7 @@ static void small_deps(Recorder &r) {
                 fprintf(stderr, "[pq plan] phase %zu chain %d%s:", q, c, p.row_chain == c ? " (ROW chain)" : "");
                 for (int part = 0; part < 2; part++) {
                     fprintf(stderr, " %s waits {", part ? "rows" : "grid");
-                    for (const auto &d : p.deps[c][part]) fprintf(stderr, " (phase %d, %s)", d.first, d.second == NCHAIN ? "heads" : std::to_string(d.second).c_str());
+                    for (const auto &d : p.deps[c][part]) fprintf(stderr, " (phase %d, %s)", d.first, d.second == NCHAIN ? "short heads" : d.second == NCHAIN + 1 ? "heads" : std::to_string(d.second).c_str());
                     fprintf(stderr, " }");
                 }
                 fprintf(stderr, "\n[pq plan]     jobs:");
@@ -483,10 +510,21 @@ static pq_status suite_finalize(pq_ctx *ctx, Recorder &r) {
             // runs on the chain of the links; one that feeds nobody (ADXR from the ADX column, the hand-over check of the time-split Hilbert
             // job, MACDEXT's histogram) is a TAIL: it goes behind the LONG grid on the caller's stream -- in front of the links, waiting for
             // a job of the LONG grid, it would hold up the whole chain.
+            // (a tail of the links themselves -- MACDEXT's histogram reads the signal line, a job of phase 2 -- follows them on THEIR chain: on
+            //  the caller's stream it would cost the step's end one more dependency between two streams)
+            bool heavy_any = false;
+            for (const Phase &q : r.phases) for (const SeqJob &j : q.seq) heavy_any |= j.heavy && (j.lds_bytes > 0 || j.kind == SEQ_ID_BACKTEST || j.kind == SEQ_ID_BACKTEST + 1);
+            const int links_chain = heavy_any ? CLS_SHORT : CLS_HEAVY; // (as small_deps maps the later phases)
             for (size_t k = 0; k < p.rows.size(); k++) {
-                bool feeds = false;
+                bool feeds = false, of_links = false;
                 for (int i = 0; i < p.rows[k].n_writes; i++) feeds |= r.feeds_seq.count(p.rows[k].writes[i]) > 0;
-                if (!feeds) p.row_late[k] = 1 + CLS_LONG;
+                for (int i = 0; i < p.rows[k].n_reads; i++) {
+                    bool own = false; // (a column the launch also writes -- the Hilbert hand-over check repairs its columns in place -- says nothing)
+                    for (int w = 0; w < p.rows[k].n_writes; w++) own |= p.rows[k].writes[w] == p.rows[k].reads[i];
+                    auto it = r.writer_phase.find(p.rows[k].reads[i]);
+                    of_links |= !own && it != r.writer_phase.end() && it->second >= 1;
+                }
+                if (!feeds) p.row_late[k] = (char)(1 + (of_links ? links_chain : CLS_LONG));
             }
         }
         if (!p.seq.empty() && !r.small) { // (a small shard: every ROW launch of phase 0 on the ROW chain from t = 0 -- nothing there is a tail)
@@ -685,16 +723,18 @@ static pq_status suite_launch_small(pq_ctx *ctx, Recorder &r) {
             };
             // Phase 0: the ROW launches first (the heads of the chains are among them), then the grid.  Later phases (the chain of the
             // links): whichever part has its inputs first (small_deps) -- a stream runs in order.
-            const bool grids_first = q > 0 && r.grids_first;
+            const bool grids_first = q > 0 && p.grid_first;
             auto launch_early_rows = [&]() -> pq_status {
                 if (p.row_chain != c) return PQ_OK;
                 PQ_HIP_TRY(wait_part(1));
                 for (size_t k = 0; k < p.rows.size(); k++) {
                     if (!p.row_late[k] && !p.row_fused[k]) p.rows[k].launch(p.rows[k].blob, st);
-                    if ((int)k + 1 == p.n_heads) { // the heads of the chain are out: what waits for them need not wait for the rest
-                        if (!p.ev_done[NCHAIN]) PQ_HIP_TRY(hipEventCreateWithFlags(&p.ev_done[NCHAIN], hipEventDisableTiming));
-                        PQ_HIP_TRY(hipEventRecord(p.ev_done[NCHAIN], st));
-                    }
+                    // the (short) heads of the chain are out: what waits for them need not wait for the rest
+                    for (int hs = 0; hs < 2; hs++)
+                        if ((int)k + 1 == (hs ? p.n_heads : p.n_heads_short) && (hs == 0 || p.n_heads > p.n_heads_short)) {
+                            if (!p.ev_done[NCHAIN + hs]) PQ_HIP_TRY(hipEventCreateWithFlags(&p.ev_done[NCHAIN + hs], hipEventDisableTiming));
+                            PQ_HIP_TRY(hipEventRecord(p.ev_done[NCHAIN + hs], st));
+                        }
                 }
                 launch_row_grid(0, st);
                 return PQ_OK;
@@ -947,7 +987,7 @@ static void suite_free(pq_ctx *ctx, Recorder &r) {
     if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
     if (r.ev_tail) { (void)hipEventDestroy(r.ev_tail); r.ev_tail = nullptr; }
     for (Phase &p : r.phases) {
-        for (int c = 0; c <= NCHAIN; c++) if (p.ev_done[c]) { (void)hipEventDestroy(p.ev_done[c]); p.ev_done[c] = nullptr; }
+        for (int c = 0; c <= NCHAIN + 1; c++) if (p.ev_done[c]) { (void)hipEventDestroy(p.ev_done[c]); p.ev_done[c] = nullptr; }
         if (p.d_seq) (void)hipFree(p.d_seq);
         for (int pos = 0; pos <= NCHAIN; pos++)
             if (p.d_rows[pos]) { (void)hipFree(p.d_rows[pos]); p.d_rows[pos] = nullptr; p.n_rows[pos] = 0; }
