@@ -15,10 +15,13 @@ rm -rf "$OUT/trace625"
 # b. the exchange: through Python / torch streams, from C through the C ABI alone (default and highest priority of the exchange stream), the runtime alone
 timeout -k 10 200 python3 scripts/bench_gather.py 2>> "$OUT/err.txt" | sed -n '/^{/,$p' > "$OUT/bench_gather.json"
 ( cd scripts/ubench && /opt/rocm/bin/hipcc -O2 -std=c++17 gather_cabi.cpp -o gather_cabi -I../../include -L../../polars_quant_amd -lpolars_quant_hip -Wl,-rpath,"$R/polars_quant_amd" \
-  && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 xstream.hip -o xstream && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 halfwave.hip -o halfwave )
+  && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 xstream.hip -o xstream && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 halfwave.hip -o halfwave \
+  && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 stepshape.hip -o stepshape && /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 pipes.hip -o pipes )
 { echo '{"default_priority":'; timeout -k 10 100 scripts/ubench/gather_cabi 625 400 | sed -n '/^{/,$p'; echo ', "highest_priority":'; PQ_COMM_PRIO=high timeout -k 10 100 scripts/ubench/gather_cabi 625 400 | sed -n '/^{/,$p'; echo '}'; } > "$OUT/gather_cabi.json" 2>> "$OUT/err.txt"
 timeout -k 10 200 scripts/ubench/xstream > "$OUT/ubench_xstream.json" 2>> "$OUT/err.txt"
 timeout -k 10 100 scripts/ubench/halfwave > "$OUT/ubench_halfwave.txt" 2>> "$OUT/err.txt"
+timeout -k 10 100 scripts/ubench/stepshape 50 > "$OUT/ubench_stepshape.json" 2>> "$OUT/err.txt"   # the step's launch shape by stream / compute pipe
+timeout -k 10 60 scripts/ubench/pipes > "$OUT/ubench_pipes.txt" 2>> "$OUT/err.txt"
 # c. the plugin end to end from host Arrow buffers; ragged batches (incl. a recorded ragged suite)
 timeout -k 10 400 python3 scripts/bench_plugin.py > "$OUT/bench_plugin.json" 2>> "$OUT/err.txt"
 timeout -k 10 400 python3 scripts/bench_ragged.py > "$OUT/bench_ragged.json" 2>> "$OUT/err.txt"

@@ -15,7 +15,7 @@ N_SIMD = 1024   # 256 CUs x 4
 steps = {c: len(v) for c, v in disp.get("cdl_all_kernel<true, true>", {}).items()}
 tot_valu = 0.0
 for k in sorted(tot):
-    if not any(x in k for x in ("seq_jobs", "seq_mj", "cdl", "row_jobs", "bt_wave")): continue
+    if not any(x in k for x in ("seq_jobs", "cdl", "row_jobs", "bt_wave")): continue
     m = {c: v / max(steps.get(c, 1), 1) for c, v in tot[k].items()}            # per step
     per_step = {c: len(disp[k][c]) / max(steps.get(c, 1), 1) for c in tot[k]}
     n_launch = max(per_step.values()) if per_step else 1

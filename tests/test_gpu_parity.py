@@ -630,10 +630,7 @@ def _check_suite_replay(pq, oracle, data, stride):
     # an even row pitch must run the tiled bodies bench.py times; an odd one (rows only 8-byte aligned) their 8-byte form
     # seq_jobs_kernel<3> -- until round 4 it fell to the per-lane gather bodies seq_jobs_kernel<2>, 2.6 x slower at full size.
     # (no job of the suite needs the register-heavy kernel seq_jobs_kernel<1> since the Hilbert pipeline keeps its delay lines in LDS)
-    import os
-    aligned = "seq_mj_kernel" if os.environ.get("PQ_MJ", "0") not in ("", "0") else "seq_jobs_kernel<0>"   # (PQ_MJ=1: multi-job workgroups, suite_mj.hip)
-    if os.environ.get("PQ_WIDE", "0") not in ("", "0") and pitch % 2 == 0:
-        assert "seq_jobs_kernel<4>" in kernels, kernels      # (PQ_WIDE=n: the jobs with >= n output columns get a second storer wave)
+    aligned = "seq_jobs_kernel<0>"
     assert "seq_jobs_kernel<2>" not in kernels and (aligned if pitch % 2 == 0 else "seq_jobs_kernel<3>") in kernels, kernels
     for t in [x for ts in st.out.values() for x in ts] + list(st.pat.values()) + st.bt:
         t.fill_(-7)                      # poison: every row must be produced by the replay
