@@ -5,7 +5,7 @@ played by pyarrow as in tests/test_polars_plugin.py.
   per_group   5 000 calls of `_polars_plugin_<f>`, one per group                              (what `.over("symbol")` does, momentum.py:13-16)
   oracle      the CPU restatement of the reference on the same host, ONE thread (a baseline, not a target; the suite-level figure on all cores is bench.py's cpu_baseline)
 for ema / macd / cdlengulfing; `over` twice -- the first call uploads the columns, the second finds them in the input-column cache
-(csrc/plugin.hip) -- and with PQ_PLUGIN_CACHE_MB=0.   Prints one JSON object (profiles/<round>_bench_plugin.json)."""
+(csrc/plugin.hip) --, with PQ_PLUGIN_CACHE_MB=0 and with PQ_PLUGIN_HOSTPOOL_MB=0 (every call's result in fresh host memory).   Prints one JSON object (profiles/<round>_bench_plugin.json)."""
 import ctypes as C
 import json
 import os
@@ -62,6 +62,11 @@ for name, names, kw, ocall in (("ema", ("close",), {"timeperiod": 30}, lambda x:
     os.environ["PQ_PLUGIN_CACHE_MB"] = "0"
     r["over_no_cache_ms"] = t_of(lambda: over(name, names, **kw)) * 1e3
     del os.environ["PQ_PLUGIN_CACHE_MB"]
+    # the host side of the result columns comes from a pool of released blocks (csrc/plugin.hip HostBuf): a caller that KEEPS every result --
+    # sixty expressions of one with_columns -- finds the pool empty and pays the page faults of fresh memory; that case:
+    os.environ["PQ_PLUGIN_HOSTPOOL_MB"] = "0"
+    r["over_cached_no_host_pool_ms"] = t_of(lambda: over(name, names, **kw)) * 1e3
+    del os.environ["PQ_PLUGIN_HOSTPOOL_MB"]
     L.pq_plugin_cache_clear()
     t = t_of(lambda: per_group(name, names, SAMPLE, **kw), reps=2)
     r["per_group_ms"] = t / SAMPLE * N * 1e3
@@ -69,7 +74,7 @@ for name, names, kw, ocall in (("ema", ("close",), {"timeperiod": 30}, lambda x:
     L.pq_plugin_cache_clear()
     sub = {k: d[k] for k in names}
     r["oracle_one_thread_ms"] = t_of(lambda: ocall(sub), reps=2) * 1e3 if hasattr(oracle, "call") else None
-    for k in ("over_first_call_ms", "over_cached_ms", "over_no_cache_ms", "per_group_ms", "oracle_one_thread_ms"):
+    for k in ("over_first_call_ms", "over_cached_ms", "over_no_cache_ms", "over_cached_no_host_pool_ms", "per_group_ms", "oracle_one_thread_ms"):
         if r.get(k):
             r[k.replace("_ms", "_rows_per_s")] = rows / (r[k] * 1e-3)
     out["functions"][name] = r
