@@ -799,3 +799,57 @@ def test_input_column_cache_never_aliases_a_reused_address(oracle):
     assert stats() == before
     L.pq_plugin_cache_clear()
     assert stats() == (0, 0, 0, 0)
+
+
+@pytest.mark.gpu
+def test_result_host_pool_never_hands_out_a_block_that_is_still_alive(oracle):
+    """The host side of a result column comes from a bounded pool of RELEASED blocks (csrc/plugin.hip HostBuf; blocks of >= 1 MB): a result
+    the caller still holds must keep its bytes while later calls run; after its release a later call of about that size may take the
+    block over -- and must fill every element of it; PQ_PLUGIN_HOSTPOOL_MB=0 switches the pool off."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    L = _lib()
+    n = 300_000                                     # 2.4 MB per Float64 column: pooled
+    d = oracle.gen_ohlcv(0x5EED0D01, 2, n, 0)
+    xa, xb = pa.array(d["close"][0]), pa.array(d["close"][1])
+
+    def bits(arr):
+        return arr.to_numpy(zero_copy_only=False).view(np.uint64).copy()
+
+    def expect(x, p):
+        (e,) = oracle.call("ema", np.asarray(x), timeperiod=p)
+        return e.view(np.uint64)
+    ra = _plugin_call(L, "ema", [([xa], "close")], kwargs={"timeperiod": 9})
+    keep = bits(ra)
+    addr_a = ra.buffers()[1].address
+    rb = _plugin_call(L, "ema", [([xb], "close")], kwargs={"timeperiod": 21})      # ra is alive: another block
+    assert rb.buffers()[1].address != addr_a
+    en = expect(xa, 9) == np.uint64(oracle.NULL_BITS)
+    assert (bits(ra) == keep).all() and (keep[~en] == expect(xa, 9)[~en]).all()
+    eb = expect(xb, 21)
+    assert (bits(rb)[eb != np.uint64(oracle.NULL_BITS)] == eb[eb != np.uint64(oracle.NULL_BITS)]).all()
+    del ra                                                                         # released: its block goes to the pool
+    rc = _plugin_call(L, "sma", [([xb], "close")], kwargs={"timeperiod": 5})       # same size: may take it over
+    (ec,) = oracle.call("sma", np.asarray(xb), timeperiod=5)
+    ecb = ec.view(np.uint64)
+    got = bits(rc)
+    nn = ecb != np.uint64(oracle.NULL_BITS)
+    assert (got[nn] == ecb[nn]).all() and (np.asarray(rc.is_null()) == ~nn).all()
+    assert (bits(rb)[eb != np.uint64(oracle.NULL_BITS)] == eb[eb != np.uint64(oracle.NULL_BITS)]).all()    # rb untouched by the reuse
+    # a three-column Struct result and an Int32 result draw from the same pool
+    m1 = _plugin_call(L, "macd", [([xa], "close")])
+    del rc, m1
+    m2 = _plugin_call(L, "macd", [([xa], "close")])
+    em = oracle.call("macd", np.asarray(xa))
+    for k, child in enumerate(m2.flatten()):
+        e = em[k].view(np.uint64)
+        ok = e != np.uint64(oracle.NULL_BITS)
+        assert (bits(child)[ok] == e[ok]).all()
+    os.environ["PQ_PLUGIN_HOSTPOOL_MB"] = "0"
+    try:
+        r0 = _plugin_call(L, "ema", [([xa], "close")], kwargs={"timeperiod": 9})
+        assert (bits(r0) == keep).all()
+    finally:
+        del os.environ["PQ_PLUGIN_HOSTPOOL_MB"]
