@@ -351,9 +351,21 @@ static pq_status plan_layout(pq_ctx *ctx, const pq_series_export *key, int64_t n
         default: break;
         }
         if (width && a->length == n && a->n_buffers >= 2 && a->buffers[1] && (a->null_count == 0 || !a->buffers[0])) {
-            auto scan = [&](auto *p) {
-                for (int64_t i = 1; i < n; i++)
-                    if (p[i] != p[i - 1]) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
+            auto scan = [&](auto *p) { // (several host threads, each over its own range of rows; the boundaries joined in order)
+                const unsigned nt = host_threads((size_t)n, (size_t)1 << 20);
+                std::vector<std::vector<int64_t>> part(nt);
+                auto range = [&](unsigned t) {
+                    const int64_t lo = std::max<int64_t>(1, n * t / nt), hi = n * (t + 1) / nt;
+                    for (int64_t i = lo; i < hi; i++) if (p[i] != p[i - 1]) part[t].push_back(i);
+                };
+                if (nt < 2) range(0);
+                else {
+                    std::vector<std::thread> th;
+                    for (unsigned t = 0; t < nt; t++) th.emplace_back(range, t);
+                    for (auto &x : th) x.join();
+                }
+                for (const auto &v : part)
+                    for (int64_t i : v) { longest = std::max<int64_t>(longest, i - off.back()); off.push_back(i); }
             };
             const uint8_t *base = (const uint8_t *)a->buffers[1] + (size_t)a->offset * (size_t)width;
             switch (width) { // (floats too are compared as words: the general path compares their bytes)
