@@ -143,7 +143,7 @@ int32_t pq_plugin_kwargs_i64(const uint8_t *pickle, size_t len, const char *key,
  * the device memory it holds; least recently used entries that no call holds go first.  No reference counterpart.
  * Host side of the results: an exported column owns uninitialised, page-touched host memory; its release hands blocks of >= 1 MB to a
  * bounded pool (PQ_PLUGIN_HOSTPOOL_MB, default 1024; 0 = off) that later calls of about that size draw from instead of faulting in fresh
- * pages.  PQ_PLUGIN_TIMING=1 prints the host time of every phase of a call on stderr.
+ * pages (fresh blocks of >= 4 MB are 2 MB-aligned and ask for transparent huge pages).  PQ_PLUGIN_TIMING=1 prints the host time of every phase of a call on stderr.
  *   pq_plugin_cache_stats   hits / misses / bytes held / entries since load (or the last clear); any pointer may be NULL
  *   pq_plugin_cache_clear   frees every entry no call holds, zeroes the counters */
 void pq_plugin_cache_stats(int64_t *hits, int64_t *misses, int64_t *bytes, int64_t *entries);
