@@ -490,13 +490,29 @@ static const double *flat_f64(const pq_series_export &in, int64_t n) {
     if (a->null_count != 0 && a->buffers[0]) return nullptr;
     return (const double *)a->buffers[1] + a->offset;
 }
-static pq_status cached_input(pq_ctx *ctx, const Layout &L, const double *src, int64_t n, InCol *ic) {
+// the hashes of a call's flat inputs on a helper thread, started before the key column is scanned (plan_layout) and joined behind it:
+// the two passes over host memory are independent
+struct HashAhead {
+    uint64_t h[4] = {0, 0, 0, 0};
+    bool have[4] = {false, false, false, false};
+    std::thread th;
+    void start(const double *const *flat, int nin, int64_t n) {
+        if (!cache_limit() || (size_t)n * 8 < ((size_t)8 << 20)) return;
+        const double *f[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < nin && k < 4; k++) f[k] = flat[k];
+        th = std::thread([this, f, n]() { for (int k = 0; k < 4; k++) if (f[k]) { h[k] = hash_buffer(f[k], (size_t)n * 8); have[k] = true; } });
+    }
+    void join() { if (th.joinable()) th.join(); }
+    const uint64_t *get(int k) const { return have[k] ? &h[k] : nullptr; }
+    ~HashAhead() { join(); }
+};
+static pq_status cached_input(pq_ctx *ctx, const Layout &L, const double *src, int64_t n, InCol *ic, const uint64_t *hash = nullptr) {
     CacheEntry &k = ic->key;
     k.addr = src; k.n = n;
     k.groups = L.pitched ? L.groups : 1; k.glen = L.pitched ? L.glen : n; k.pitch = L.pitched ? L.pitch : n;
     const size_t limit = cache_limit();
     if (limit) {
-        k.hash = hash_buffer(src, (size_t)n * 8);
+        k.hash = hash ? *hash : hash_buffer(src, (size_t)n * 8);
         std::lock_guard<std::mutex> g(g_cache_mu);
         for (CacheEntry &e : g_cache)
             if (e.addr == k.addr && e.n == k.n && e.groups == k.groups && e.glen == k.glen && e.pitch == k.pitch && e.hash == k.hash) {
@@ -629,12 +645,15 @@ void run_cols(const PlugFn &f, pq_series_export *inputs, size_t n_inputs, const 
         void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
         InCol ic[4];
         Layout lay;
+        HashAhead ha;
+        if (over) ha.start(flat, f.nin, n);
         pq_status st = plan_layout(ctx, over ? &inputs[f.nin] : nullptr, n, &lay);
+        ha.join();
         clk.mark("layout");
         if (st == PQ_OK) st = pq_malloc(ctx, lay.dev_elems() * 8, &d_out);
         clk.mark("dev-alloc");
         for (int k = 0; k < f.nin && st == PQ_OK; k++) {
-            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k]);
+            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k], ha.get(k));
             else {
                 if (nulls[k]) nulls_into_host(host[k], valid[k], n);
                 st = upload_col(ctx, lay, host[k].data(), 8, &ic[k].d);
@@ -772,10 +791,13 @@ void run_struct(const StructFn &f, pq_series_export *inputs, size_t n_inputs, co
         void *d_in[2] = {nullptr, nullptr}, *d_out[3] = {nullptr, nullptr, nullptr};
         InCol ic[2];
         Layout lay;
+        HashAhead ha;
+        if (over) ha.start(flat, f.nin, n);
         pq_status st = plan_layout(ctx, over ? &inputs[f.nin] : nullptr, n, &lay);
+        ha.join();
         for (int k = 0; k < f.nout && st == PQ_OK; k++) st = pq_malloc(ctx, lay.dev_elems() * 8, &d_out[k]);
         for (int k = 0; k < f.nin && st == PQ_OK; k++) {
-            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k]);
+            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k], ha.get(k));
             else {
                 if (nulls[k]) nulls_into_host(host[k], valid[k], n);
                 st = upload_col(ctx, lay, host[k].data(), 8, &ic[k].d);
@@ -851,10 +873,13 @@ void run_pattern(int32_t id, pq_series_export *inputs, size_t n_inputs, pq_serie
         void *d_in[4] = {nullptr, nullptr, nullptr, nullptr}, *d_out = nullptr;
         InCol ic[4];
         Layout lay;
+        HashAhead ha;
+        if (over) ha.start(flat, 4, n);
         pq_status st = plan_layout(ctx, over ? &inputs[4] : nullptr, n, &lay);
+        ha.join();
         if (st == PQ_OK) st = pq_malloc(ctx, lay.dev_elems() * 4, &d_out);
         for (int k = 0; k < 4 && st == PQ_OK; k++) {
-            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k]);
+            if (flat[k]) st = cached_input(ctx, lay, flat[k], n, &ic[k], ha.get(k));
             else { st = upload_col(ctx, lay, host[k].data(), 8, &ic[k].d); ic[k].owned = true; }
             d_in[k] = ic[k].d;
         }
