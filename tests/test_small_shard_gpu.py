@@ -152,3 +152,40 @@ def test_mama_at_the_wrappers_default_limits_is_the_walks_result(pq, oracle):
                 clean = np.isfinite(x).all(axis=1) & (np.abs(np.where(bits(x) == bits(np.array([NULL]))[0], 0.0, x)).max(axis=1) <= 1e140)
                 if T >= 32:
                     assert (bits(a[clean][:, 31:]) == 0).all()      # +0.0, not -0.0
+
+
+def test_small_shard_schedule_variants_write_the_same_columns(pq, oracle):
+    """The small-shard schedule orders its launches by data dependencies (csrc/suite.hip small_deps): whatever ORDER a stream issues its
+    parts in -- the links' job grid before or after their ROW launches, RSI under STOCHRSI as a wave-per-symbol launch or as a job -- every
+    column must come out bit-identical (a missing dependency would show as a column computed from stale inputs under one of the orders)."""
+    import os
+    from polars_quant_amd.suite import Suite
+    N = 330
+    d = oracle.gen_ohlcv(0x5EED0603, N, TT, 0)
+    g = _pitched(d, STRIDE)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            st = Suite(N, TT, "cuda:0", stride=STRIDE)
+            st.record(g)
+            assert st.info()["phases"] >= 3
+            for t in [x for ts in st.out.values() for x in ts]:
+                t.fill_(-7)                       # poison: every row must be produced by the replay
+            st.run(); st.run(); st.run()
+            torch.cuda.synchronize()
+            cols = {name: [t.clone() for t in ts] for name, ts in st.out.items()}
+            cols["__bt"] = [t.clone() for t in st.bt] + [st.summary.clone()]
+            st.close()
+            return cols
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    base = run({})
+    for env in ({"PQ_SMALL_GRIDS_FIRST": "0"}, {"PQ_SMALL_GRIDS_FIRST": "1"}, {"PQ_NO_WT_SMALL": "1"}, {"PQ_NO_WT_SMALL": "1", "PQ_SMALL_GRIDS_FIRST": "0"}):
+        other = run(env)
+        for name, ts in base.items():
+            for k, (a, b) in enumerate(zip(ts, other[name])):
+                assert torch.equal(a.view(torch.int64), b.view(torch.int64)), (env, name, k)
