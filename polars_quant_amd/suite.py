@@ -346,8 +346,19 @@ class Suite:
                 self._stale_warned = True
                 warnings.warn(f"Suite.run(): columns {sorted(self._housed)} were re-housed at record time; this replay reads those copies, not the "
                               f"caller's tensors -- pass the tensors to run() or call refresh_inputs() after changing them", PqLayoutWarning, stacklevel=2)
+        if not Suite._stream_warned and torch.cuda.current_stream(self.dev).cuda_stream != 0:
+            # (a replay needs four hardware queues on four compute pipes: the NULL stream + the three side streams of the context are a
+            #  process's first four; a created stream shifts them and two chains share a pipe -- DESIGN.md section 6)
+            import warnings
+            from .api import PqLayoutWarning
+            Suite._stream_warned = True
+            warnings.warn("Suite.run() on a created stream: on this runtime a recorded suite replays 17-38 % slower there than on the NULL "
+                          "(default) stream -- two of its four chains share a compute pipe of the command processor (INTEGRATION.md); "
+                          "warned once per process", PqLayoutWarning, stacklevel=2)
         with torch.cuda.device(self.dev):
             check(lib().pq_suite_run(ctx(self.dev.index), self._suites[slot]))
+
+    _stream_warned = False
 
     def close(self):
         for hnd in getattr(self, "_suites", []) or []:
